@@ -1,0 +1,121 @@
+"""ctypes binding of libcvae_hip.so — the C ABI declared in include/cvae_hip.h.
+
+There is NO fallback: importing this module without the built library raises, and every op checks the
+device of its tensors — the product path either runs the gfx950 kernels or fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcvae_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY02 = 0, 1, 2, 3
+_ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "leaky02": ACT_LEAKY02}
+
+
+class CvaeError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C causal_vae_amd/csrc`).  causal_vae_amd has no CPU / eager fallback.")
+lib = C.CDLL(LIB_PATH)
+
+_p, _i64, _i, _f, _sz, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/cvae_hip.h one to one.
+SIGNATURES = {
+    "cvae_version": [],
+    "cvae_strerror": [_i],
+    "cvae_ncs_to_nsc": [_p, _p, _i64, _i64, _i64, _i, _i, _p],
+    "cvae_nsc_to_ncs": [_p, _p, _i64, _i64, _i64, _i, _i, _p],
+    "cvae_cast": [_p, _p, _i64, _i, _i, _p],
+    "cvae_copy_panel": [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "cvae_onehot_panel": [_p, _p, _i64, _i64, _i64, _i64, _p],
+    "cvae_conv_packed_weight_bytes": [_i64, _i64, _i, _i],
+    "cvae_conv_pack_weight": [_p, _p, _i64, _i64, _i, _i, _i, _p],
+    "cvae_conv_down": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p],
+    "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p],
+    "cvae_conv_wgrad_workspace_bytes": [_i64, _i64, _i],
+    "cvae_conv_wgrad": [_p, _p, _p, _p, _sz] + [_i64] * 9 + [_i, _i, _p],
+    "cvae_channel_sum": [_p, _p, _i64, _i64, _i, _p],
+    "cvae_act_fwd": [_p, _p, _i64, _i, _i, _p],
+    "cvae_act_bwd": [_p, _p, _p, _i64, _i, _i, _p],
+    "cvae_adaptive_avgpool_fwd": [_p, _p] + [_i64] * 9 + [_i, _p],
+    "cvae_adaptive_avgpool_bwd": [_p, _p, _p] + [_i64] * 9 + [_i, _p],
+    "cvae_upsample_linear_fwd": [_p, _p] + [_i64] * 8 + [_i, _p],
+    "cvae_upsample_linear_bwd": [_p, _p] + [_i64] * 8 + [_i, _p],
+    "cvae_linear_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p],
+    "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "cvae_bn1d_train_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _p],
+    "cvae_bn1d_train_bwd": [_p] * 8 + [_i64, _i64, _p],
+    "cvae_bn1d_eval_fwd": [_p] * 6 + [_i64, _i64, _f, _p],
+    "cvae_philox_normal": [_p, _i64, _u64, _u64, _p],
+    "cvae_reparam_kld_fwd": [_p, _p, _p, _p, _p, _i64, _p],
+    "cvae_reparam_kld_bwd": [_p] * 7 + [_i64, _p],
+    "cvae_sse_fwd": [_p, _p, _p, _i64, _p],
+    "cvae_sse_bwd": [_p, _p, _p, _p, _i64, _p],
+    "cvae_bce_fwd": [_p, _p, _p, _i64, _p],
+    "cvae_bce_bwd": [_p, _p, _p, _p, _i64, _p],
+    "cvae_sum_fwd": [_p, _p, _i64, _p],
+    "cvae_wmse_sparsity_fwd": [_p, _p, _p, _p, _i64, _p],
+    "cvae_wmse_sparsity_bwd": [_p] * 6 + [_i64, _p],
+    "cvae_gauss_nll_fwd": [_p, _p, _p, _p, _i64, _p],
+    "cvae_gauss_nll_bwd": [_p] * 6 + [_i64, _p],
+    "cvae_softmax_ce_fwd": [_p, _p, _p, _i64, _i64, _p],
+    "cvae_softmax_ce_bwd": [_p, _p, _p, _p, _i64, _i64, _p],
+    "cvae_uniform_kl_fwd": [_p, _p, _i64, _i64, _p],
+    "cvae_uniform_kl_bwd": [_p, _p, _p, _i64, _i64, _p],
+    "cvae_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
+    "cvae_sqnorm": [_p, _p, _i64, _p],
+    "cvae_scale": [_p, _i64, _p, _p],
+    "cvae_clip_coef": [_p, _p, _f, _p],
+}
+_RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header and library disagree: fail at import
+    _fn.argtypes = _args
+    _fn.restype = _RESTYPE.get(_name, _i)
+
+
+def strerror(code):
+    return lib.cvae_strerror(code).decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CvaeError(f"{what} failed: {strerror(rc)} (code {rc})")
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise CvaeError(f"unsupported compute dtype {dt}; the gfx950 kernels take float32 or bfloat16")
+
+
+def act_code(act):
+    return _ACT[act]
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CvaeError("causal_vae_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback; "
+                            "move the model and its inputs to 'cuda')")

@@ -1,0 +1,95 @@
+"""CausalBioVAE on MI355X — drop-in for the reference class (causal_cascade/models.py:5-89) and its 3D lift.
+
+Same constructor, same sub-module attribute tree (enc_conv / enc_fc / fc_mu / fc_logvar / mechanism_net / dec_input /
+dec_conv), same state_dict keys and shapes, same forward(x, m, t) -> (recon_x, m_hat, mu, logvar); every sub-module stays
+individually callable (the reference's analysis scripts call `model.mechanism_net(...)`, causal_cascade/analyze.py:15,23).
+`CausalBioVAE3D` is the volume model of SURVEY.md §8(a): Conv3d / ConvTranspose3d / AdaptiveAvgPool3d((4,4,4)) /
+trilinear, flatten_dim 16384.
+"""
+import torch
+import torch.nn as nn
+
+from .. import layers as hl
+from .. import ops
+
+
+class CausalBioVAE(nn.Module):
+    _ND = 2
+
+    def __init__(self, img_channels=1, m_dim=12, t_dim=19, latent_dim=64):
+        super().__init__()
+        nd = self._ND
+        Conv = hl.Conv2d if nd == 2 else hl.Conv3d
+        ConvT = hl.ConvTranspose2d if nd == 2 else hl.ConvTranspose3d
+        Pool = nn.AdaptiveAvgPool2d if nd == 2 else nn.AdaptiveAvgPool3d
+        self.m_dim, self.t_dim = m_dim, t_dim
+        # layer construction order == the reference's, so a given torch seed yields the reference's weights
+        self.enc_conv = hl.ConvStack(
+            Conv(img_channels, 32, 4, 2, 1), nn.ReLU(),
+            Conv(32, 64, 4, 2, 1), nn.ReLU(),
+            Conv(64, 128, 4, 2, 1), nn.ReLU(),
+            Conv(128, 256, 4, 2, 1), nn.ReLU(),
+            Pool((4,) * nd), nn.Flatten())
+        self.flatten_dim = 256 * 4 ** nd
+        self.enc_fc = hl.MLP(hl.Linear(self.flatten_dim + m_dim + t_dim, 512), nn.ReLU(), hl.Linear(512, 256), nn.ReLU())
+        self.fc_mu = hl.Linear(256, latent_dim)
+        self.fc_logvar = hl.Linear(256, latent_dim)
+        self.mechanism_net = hl.MLP(hl.Linear(t_dim, 64), hl.BatchNorm1d(64), nn.ReLU(), hl.Linear(64, 64), nn.ReLU(),
+                                    hl.Linear(64, m_dim))
+        self.dec_input = hl.Linear(latent_dim + m_dim, self.flatten_dim)
+        self.dec_conv = hl.DeconvStack(
+            ConvT(256, 128, 4, 2, 1), nn.ReLU(),
+            ConvT(128, 64, 4, 2, 1), nn.ReLU(),
+            ConvT(64, 32, 4, 2, 1), nn.ReLU(),
+            ConvT(32, img_channels, 4, 2, 1))
+        self._eps_calls = 0
+
+    # ---- precision -------------------------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (exact-fp32 MFMA; parity mode) or torch.bfloat16 (bf16 MFMA, fp32 accumulate) for the convs."""
+        hl.set_compute_dtype(self, dtype)
+        return self
+
+    # ---- reference surface -----------------------------------------------------------------------------------
+    def encode(self, x, m, t_onehot):
+        x_feat = self.enc_conv(x)
+        h = self.enc_fc(ops.cat([x_feat, m, t_onehot]))
+        return self.fc_mu(h), self.fc_logvar(h)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        """z = mu + eps*exp(logvar/2).  eps defaults to a device Philox draw keyed by torch's seed (the CPU generator stream
+        of the reference cannot be reproduced on a GPU — parity runs pass `eps` explicitly)."""
+        if eps is None:
+            eps = ops.philox_normal(mu.shape, torch.initial_seed(), self._eps_calls << 24, mu.device)
+            self._eps_calls += 1
+        return ops.Reparameterize.apply(mu, logvar, eps)
+
+    def decode_cl(self, z_m_input):
+        x_feat = self.dec_input(z_m_input).view(-1, 256, *([4] * self._ND))
+        return self.dec_conv.forward_cl(x_feat)              # channels-last [B, D, H, W, C], compute dtype
+
+    def forward(self, x, m, t, eps=None):
+        nd = self._ND
+        if x.dim() != nd + 2:
+            raise RuntimeError(f"{type(self).__name__} expects a {nd + 2}-D input [B, C, {'D, ' if nd == 3 else ''}H, W], got {tuple(x.shape)}")
+        t_onehot = ops.one_hot(t, self.t_dim)
+        mu, logvar = self.encode(x, m, t_onehot)
+        z = self.reparameterize(mu, logvar, eps)
+        m_hat = self.mechanism_net(t_onehot)
+        out_cl = self.decode_cl(ops.cat([z, m_hat]))
+        size = tuple(x.shape[2:]) if nd == 3 else (1,) + tuple(x.shape[2:])
+        if tuple(out_cl.shape[1:4]) == size:
+            recon_cl = ops.Cast.apply(out_cl, torch.float32)   # F.interpolate to the same size is the identity
+        else:
+            recon_cl = ops.UpsampleLinear.apply(out_cl, size)
+        B, C = x.shape[0], out_cl.shape[-1]
+        if C != 1:
+            recon_x = ops.FromChannelsLast.apply(recon_cl, nd)
+        else:
+            recon_x = recon_cl.view(B, 1, *x.shape[2:])        # C == 1: channels-last and NC(D)HW coincide
+        return recon_x, m_hat, mu, logvar
+
+
+class CausalBioVAE3D(CausalBioVAE):
+    """The 3D vessel-volume model: x is [B, 1, D, H, W]."""
+    _ND = 3

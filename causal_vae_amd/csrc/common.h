@@ -1,0 +1,69 @@
+// common.h — shared device helpers for libcvae_hip (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cvae_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CVAE_WAVE 64
+
+#define CVAE_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return CVAE_E_LAUNCH;          \
+    } while (0)
+
+static inline int cvae_grid_1d(int64_t n, int block, int max_blocks = 256 * 8) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case CVAE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case CVAE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case CVAE_ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
+        default: return v;
+    }
+}
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    switch (act) {
+        case CVAE_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case CVAE_ACT_SIGMOID: return y * (1.f - y);
+        case CVAE_ACT_LEAKY02: return y > 0.f ? 1.f : 0.2f;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum; result valid in thread 0. `red` must hold blockDim.x/64 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}

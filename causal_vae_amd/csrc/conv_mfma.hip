@@ -1,0 +1,514 @@
+// conv_mfma.hip — the k4/s2/p1 convolution family on the CDNA4 matrix cores, channels-last.
+//
+// Every strided conv of the model relates a SMALL tensor S [B, sd, sh, sw, Cs] and a LARGE tensor L [B, ld, lh, lw, Cl]
+// (l = 2 s - 1 + k, k = 0..3 per strided dim; nd = 2 has one depth tap).  Three products cover all six ops
+// (include/cvae_hip.h): down (S from L), up (L from S), wgrad (dW from S and L).
+//
+// down / up  — implicit GEMM, M = output positions, N = output channels, K = (tap, input channel):
+//   * a workgroup owns a spatial tile of M (3D: 4x4x8 or 4x8x8 positions; 2D: 8x16 or 16x16) and loads the INPUT
+//     HALO of that tile ONCE per 16-channel chunk into LDS with coalesced 16-byte rows; all 64 (down) / 8 (up, per
+//     output parity) taps then read their A fragments straight out of that tile — the im2col matrix is never
+//     materialised and each input byte crosses L2->LDS ~1.8x instead of 8x.
+//   * `up` is the transposed conv in its parity form: the 2x2x2 output parity classes are 8 independent k2/s1
+//     sub-convolutions (8 taps each), so no zero-insertion FLOPs are spent.
+//   * B (weights, pre-packed [tap][K/16][N][16] by cvae_conv_pack_weight) streams through a double-buffered LDS
+//     panel, 4 taps per barrier.
+//   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain).
+//   * epilogue fuses bias + ReLU/Sigmoid (forward use) or the ReLU mask of the saved activation (backward use).
+// wgrad — M = Cs, N = Cl, K = positions.  Both operands are [position][channel] in memory, i.e. K-strided: bf16 uses
+//   the gfx950 transposing LDS read (ds_read_b64_tr_b16) to build K-contiguous fragments; fp32's 32x32x2 MFMA takes
+//   one element per lane and needs no transpose.  Partial sums leave as 128-byte-row fp32 atomics into a
+//   [tap][Cs][Cl] workspace, then one pass rewrites them in the reference [Cs][Cl][taps] layout.
+#include "common.h"
+
+namespace {
+
+struct ConvGeom {
+    int B;
+    int sd, sh, sw, Cs;
+    int ld, lh, lw, Cl;
+    int tiles_d, tiles_h, tiles_w;   // tiling of the M grid (S grid for down / wgrad, q grid for up)
+};
+
+// ---------------------------------------------------------------------------------------------- fragments
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { bf16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+__device__ __forceinline__ void lds_load(Frag<bf16>& f, const char* p) { f.v = *(const bf16x8*)p; }
+__device__ __forceinline__ void lds_load(Frag<float>& f, const char* p) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 16);
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+// lane (r = lane & 31, h = lane >> 5) holds elements k = 8h .. 8h+7 of its row/column in both precisions
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+template <int ND, int BM> struct Tile;
+template <> struct Tile<3, 128> { static constexpr int TD = 4, TH = 4, TW = 8; };
+template <> struct Tile<3, 256> { static constexpr int TD = 4, TH = 8, TW = 8; };
+template <> struct Tile<2, 128> { static constexpr int TD = 1, TH = 8, TW = 16; };
+template <> struct Tile<2, 256> { static constexpr int TD = 1, TH = 16, TW = 16; };
+
+// copy one 8-element fragment piece global -> LDS (zero if !ok)
+template <typename T>
+__device__ __forceinline__ void stage_piece(char* dst, const T* src, bool ok) {
+    constexpr int NU = (8 * sizeof(T)) / 16;
+    uint4 v[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) v[u] = ok ? ((const uint4*)src)[u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) ((uint4*)dst)[u] = v[u];
+}
+
+// ---------------------------------------------------------------------------------------------- down / up
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
+                                                                  const T* __restrict__ mask, T* __restrict__ out, ConvGeom g, int act) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    using TL = Tile<ND, BM>;
+    constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
+    constexpr int STR = UP ? 1 : 2;
+    constexpr int ID = (ND == 3) ? (UP ? TD + 2 : 2 * TD + 2) : 1;
+    constexpr int IH = UP ? TH + 2 : 2 * TH + 2, IW = UP ? TW + 2 : 2 * TW + 2;
+    constexpr int NPOS = ID * IH * IW;
+    constexpr int FB = 8 * sizeof(T);                    // bytes of one fragment piece (8 channels)
+    constexpr int NG = UP ? (ND == 3 ? 2 : 1) : (ND == 3 ? 16 : 4);   // tap groups of 4
+    constexpr int HALO_BYTES = 2 * NPOS * FB;
+    constexpr int BT_BYTES = 4 * 2 * BN * FB;            // one B buffer: [4 taps][2 halves][BN]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* bt = smem + HALO_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int Cin = UP ? g.Cs : g.Cl, Cout = UP ? g.Cl : g.Cs;
+    const int nblocks = Cout / BN;
+    const int nb = blockIdx.y % nblocks, par = blockIdx.y / nblocks;    // par: output parity class (UP only)
+    const int prd = (UP && ND == 3) ? ((par >> 2) & 1) : 0, prh = UP ? ((par >> 1) & 1) : 0, prw = UP ? (par & 1) : 0;
+    const int n0 = nb * BN;
+    int tile = blockIdx.x;
+    const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
+    const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
+    const int td_i = tile;
+    const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;       // tile origin in the M grid
+    // input dims
+    const int in_d = UP ? g.sd : g.ld, in_h = UP ? g.sh : g.lh, in_w = UP ? g.sw : g.lw;
+    const int g0d = (ND == 3) ? (UP ? o0d - 1 : 2 * o0d - 1) : 0;
+    const int g0h = UP ? o0h - 1 : 2 * o0h - 1, g0w = UP ? o0w - 1 : 2 * o0w - 1;
+    const int nchunks = Cin / 16;
+
+    // per-lane halo base position of each M sub-tile row
+    int pbase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = (wm * MI + mi) * 32 + r;
+        const int w = m % TW, hh = (m / TW) % TH, d = m / (TW * TH);
+        pbase[mi] = ((d * STR) * IH + hh * STR) * IW + w * STR;
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    auto tap_halo_off = [&](int grp, int j) -> int {
+        if (!UP) {
+            const int kd = (ND == 3) ? (grp >> 2) : 0, kh = (ND == 3) ? (grp & 3) : grp;
+            return (kd * IH + kh) * IW + j;
+        } else {
+            const int a = (ND == 3) ? grp : 0, bb = j >> 1, c = j & 1;
+            return ((prd + a) * IH + (prh + bb)) * IW + (prw + c);
+        }
+    };
+    auto tap_weight_idx = [&](int grp, int j) -> int {
+        if (!UP) return grp * 4 + j;
+        const int a = (ND == 3) ? grp : 0, bb = j >> 1, c = j & 1;
+        const int kd = (ND == 3) ? (3 - prd - 2 * a) : 0, kh = 3 - prh - 2 * bb, kw = 3 - prw - 2 * c;
+        return (kd * 4 + kh) * 4 + kw;
+    };
+    auto stage_b = [&](int chunk, int grp, int buf) {
+        char* dstb = bt + buf * BT_BYTES;
+        for (int it = t; it < 4 * 2 * BN; it += NT) {
+            const int half = it & 1, n = (it >> 1) % BN, j = it / (2 * BN);
+            const int wt = tap_weight_idx(grp, j);
+            const T* src = wp + (((size_t)wt * nchunks + chunk) * Cout + n0 + n) * 16 + 8 * half;
+            stage_piece<T>(dstb + ((j * 2 + half) * BN + n) * FB, src, true);
+        }
+    };
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();                                   // previous chunk's readers are done with halo + B buffers
+        for (int it = t; it < NPOS * 2; it += NT) {
+            const int half = it & 1, pos = it >> 1;
+            const int x = pos % IW, y = (pos / IW) % IH, z = pos / (IW * IH);
+            const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
+            const bool ok = (gz >= 0) && (gz < in_d) && (gy >= 0) && (gy < in_h) && (gx >= 0) && (gx < in_w);
+            const T* src = in + ((((size_t)b * in_d + gz) * in_h + gy) * in_w + gx) * Cin + chunk * 16 + 8 * half;
+            stage_piece<T>(halo + ((size_t)half * NPOS + pos) * FB, src, ok);
+        }
+        stage_b(chunk, 0, 0);
+        __syncthreads();
+#pragma unroll 1
+        for (int grp = 0; grp < NG; ++grp) {
+            const int buf = grp & 1;
+            if (grp + 1 < NG) stage_b(chunk, grp + 1, buf ^ 1);
+            const char* btb = bt + buf * BT_BYTES;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int toff = tap_halo_off(grp, j);
+                Frag<T> a[MI], bf[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)h * NPOS + pbase[mi] + toff) * FB);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) lds_load(bf[ni], btb + ((j * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], a[mi], bf[ni]);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue.  32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
+    const int out_d = UP ? g.ld : g.sd, out_h = UP ? g.lh : g.sh, out_w = UP ? g.lw : g.sw;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (wm * MI + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+            int od, oh, ow;
+            if (UP) { od = (ND == 3) ? 2 * (o0d + d) + prd : 0; oh = 2 * (o0h + hh) + prh; ow = 2 * (o0w + w) + prw; }
+            else { od = o0d + d; oh = o0h + hh; ow = o0w + w; }
+            if (od >= out_d || oh >= out_h || ow >= out_w) continue;
+            const size_t pidx = ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int c = n0 + (wn * NI + ni) * 32 + r;
+                float v = acc[mi][ni][e] + (bias ? bias[c] : 0.f);
+                v = apply_act(v, act);
+                if (mask && !(to_f32(mask[pidx + c]) > 0.f)) v = 0.f;
+                out[pidx + c] = from_f32<T>(v);
+            }
+        }
+}
+
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
+int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream) {
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    using TL = Tile<ND, BM>;
+    constexpr int ID = (ND == 3) ? (UP ? TL::TD + 2 : 2 * TL::TD + 2) : 1;
+    constexpr int IH = UP ? TL::TH + 2 : 2 * TL::TH + 2, IW = UP ? TL::TW + 2 : 2 * TL::TW + 2;
+    constexpr int FB = 8 * sizeof(T);
+    constexpr size_t LDS = (size_t)2 * ID * IH * IW * FB + (size_t)2 * 4 * 2 * BN * FB;
+    static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
+    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
+        attr_set = true;
+    }
+    const int md = UP ? ((ND == 3) ? (g.ld + 1) / 2 : 1) : g.sd, mh = UP ? (g.lh + 1) / 2 : g.sh, mw = UP ? (g.lw + 1) / 2 : g.sw;
+    g.tiles_d = (md + TL::TD - 1) / TL::TD; g.tiles_h = (mh + TL::TH - 1) / TL::TH; g.tiles_w = (mw + TL::TW - 1) / TL::TW;
+    const int Cout = UP ? g.Cl : g.Cs;
+    const int npar = UP ? ((ND == 3) ? 8 : 4) : 1;
+    const long long gy = (long long)(Cout / BN) * npar;
+    if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
+    dim3 grid((unsigned)(g.tiles_d * g.tiles_h * g.tiles_w), (unsigned)gy, (unsigned)g.B);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const T*)mask, (T*)out, g, act);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- weight packing
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cs, int Cl, int taps, int for_up) {
+    const int64_t n = (int64_t)Cs * Cl * taps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // i enumerates the OUTPUT so writes are contiguous
+        const int e = (int)(i & 15);
+        int64_t rr = i >> 4;
+        int cs, cl, tap;
+        if (!for_up) { cs = (int)(rr % Cs); rr /= Cs; const int ch = (int)(rr % (Cl / 16)); tap = (int)(rr / (Cl / 16)); cl = ch * 16 + e; }
+        else { cl = (int)(rr % Cl); rr /= Cl; const int ch = (int)(rr % (Cs / 16)); tap = (int)(rr / (Cs / 16)); cs = ch * 16 + e; }
+        out[i] = from_f32<T>(w[((int64_t)cs * Cl + cl) * taps + tap]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- wgrad
+// Workgroup: 4 waves; block of 64 cs x 32 cl; one depth tap kd (3D) / all taps (2D); wave w owns kh = w, kw = 0..3.
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split) {
+    using TL = Tile<ND, 128>;
+    constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
+    constexpr int IH = 2 * TH + 2, IW = 2 * TW + 2;          // L tile: TD planes (one kd) x IH x IW positions x 32 cl
+    constexpr int SROW = 64 * sizeof(T), LROW = 32 * sizeof(T);
+    constexpr int S_BYTES = 128 * SROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_lds = smem;
+    char* l_lds = smem + S_BYTES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cl_blocks = g.Cl / 32;
+    const int cs0 = (blockIdx.y / cl_blocks) * 64, cl0 = (blockIdx.y % cl_blocks) * 32;
+    const int kd = (ND == 3) ? blockIdx.z : 0;
+    const int kh = wave;
+    const int tiles_per_b = g.tiles_d * g.tiles_h * g.tiles_w, total_tiles = g.B * tiles_per_b;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][k][e] = 0.f;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += n_split) {
+        int tt = tile;
+        const int tw_i = tt % g.tiles_w; tt /= g.tiles_w;
+        const int th_i = tt % g.tiles_h; tt /= g.tiles_h;
+        const int td_i = tt % g.tiles_d;
+        const int b = tt / g.tiles_d;
+        const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
+        __syncthreads();
+        // S tile: 128 positions x 64 channels
+        for (int it = t; it < 128 * 8; it += 256) {
+            const int piece = it & 7, m = it >> 3;
+            const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+            const int od = o0d + d, oh = o0h + hh, ow = o0w + w;
+            const bool ok = od < g.sd && oh < g.sh && ow < g.sw;
+            const T* src = S + ((((size_t)b * g.sd + od) * g.sh + oh) * g.sw + ow) * g.Cs + cs0 + piece * 8;
+            stage_piece<T>(s_lds + m * SROW + piece * 8 * sizeof(T), src, ok);
+        }
+        // L tile: planes lz = 2 (o0d + d) - 1 + kd, rows 2 o0h - 1 + y, cols 2 o0w - 1 + x
+        for (int it = t; it < TD * IH * IW * 4; it += 256) {
+            const int piece = it & 3, pos = it >> 2;
+            const int x = pos % IW, y = pos / IW % IH, d = pos / (IW * IH);
+            const int lz = (ND == 3) ? 2 * (o0d + d) - 1 + kd : 0, ly = 2 * o0h - 1 + y, lx = 2 * o0w - 1 + x;
+            const bool ok = lz >= 0 && lz < g.ld && ly >= 0 && ly < g.lh && lx >= 0 && lx < g.lw;
+            const T* src = L + ((((size_t)b * g.ld + lz) * g.lh + ly) * g.lw + lx) * g.Cl + cl0 + piece * 8;
+            stage_piece<T>(l_lds + pos * LROW + piece * 8 * sizeof(T), src, ok);
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 2) {
+            // bf16: transposing LDS reads.  Lane i of 16-lane group gq supplies the address of k-row q = i>>2,
+            // 4 channels at 4*(i&3); it receives channel i of the 4 k-rows  (cdna_hip_programming.md T10).
+            const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+            const int hk = gq >> 1, colblk = gq & 1;
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#pragma unroll 1
+            for (int c = 0; c < 8; ++c) {
+                bf16x8 a[2];
+                int lpos[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int m = 16 * c + 8 * hk + 4 * jj + q;
+                    const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+                    lpos[jj] = (d * IH + 2 * hh + kh) * IW + 2 * w;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const char* ap = s_lds + m * SROW + (s * 32 + 16 * colblk + 4 * p) * 2;
+                        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)ap);
+                        a[s][4 * jj + 0] = v[0]; a[s][4 * jj + 1] = v[1]; a[s][4 * jj + 2] = v[2]; a[s][4 * jj + 3] = v[3];
+                    }
+                }
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    bf16x8 bv;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const char* bp = l_lds + (lpos[jj] + kw) * LROW + (16 * colblk + 4 * p) * 2;
+                        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)bp);
+                        bv[4 * jj + 0] = v[0]; bv[4 * jj + 1] = v[1]; bv[4 * jj + 2] = v[2]; bv[4 * jj + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) acc[s][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bv, acc[s][kw], 0, 0, 0);
+                }
+            }
+        } else {
+            // fp32: 32x32x2 MFMA, lane (r, h) feeds A[r][k = h], B[k = h][r]: one element each, no transpose needed
+            const int r = lane & 31, hk = lane >> 5;
+#pragma unroll 1
+            for (int mm = 0; mm < 128; mm += 2) {
+                const int m = mm + hk;
+                const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+                const int lp = (d * IH + 2 * hh + kh) * IW + 2 * w;
+                float a[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[s] = *(const float*)(s_lds + m * SROW + (s * 32 + r) * 4);
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const float bv = *(const float*)(l_lds + (lp + kw) * LROW + r * 4);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) acc[s][kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv, acc[s][kw], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- write-out: ws[tap][cs][cl] += acc ; lanes 0-31 / 32-63 each cover one 128-byte row segment ----
+    const int col = lane & 31, hq = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int tap = (kd * 4 + kh) * 4 + kw;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = s * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
+                atomicAdd(&ws[((size_t)tap * g.Cs + cs0 + row) * g.Cl + cl0 + col], acc[s][kw][e]);
+            }
+        }
+}
+
+__global__ void wgrad_unpack_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Cs, int Cl, int taps) {
+    const int64_t n = (int64_t)Cs * Cl * taps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int64_t cc = i / taps;               // cs * Cl + cl
+        dW[i] = ws[(int64_t)tap * Cs * Cl + cc];
+    }
+}
+
+template <typename T, int ND>
+int launch_wgrad(const void* S, const void* L, float* ws, ConvGeom g, hipStream_t stream) {
+    using TL = Tile<ND, 128>;
+    constexpr size_t LDS = (size_t)128 * 64 * sizeof(T) + (size_t)TL::TD * (2 * TL::TH + 2) * (2 * TL::TW + 2) * 32 * sizeof(T);
+    static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
+    auto kern = conv_wgrad_kernel<T, ND>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
+        attr_set = true;
+    }
+    g.tiles_d = (g.sd + TL::TD - 1) / TL::TD; g.tiles_h = (g.sh + TL::TH - 1) / TL::TH; g.tiles_w = (g.sw + TL::TW - 1) / TL::TW;
+    const long long total_tiles = (long long)g.B * g.tiles_d * g.tiles_h * g.tiles_w;
+    const int cb = (g.Cs / 64) * (g.Cl / 32), tg = (ND == 3) ? 4 : 1;
+    long long n_split = 1024 / ((long long)cb * tg);
+    if (n_split < 1) n_split = 1;
+    if (n_split > total_tiles) n_split = total_tiles;
+    if (cb > 65535) return CVAE_E_BADSHAPE;
+    dim3 grid((unsigned)n_split, (unsigned)cb, (unsigned)tg);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, (const T*)S, (const T*)L, ws, g, (int)n_split);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+bool geom_ok(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd) {
+    if (nd != 2 && nd != 3) return false;
+    if (B < 0 || sd <= 0 || sh <= 0 || sw <= 0 || Cs <= 0 || ld <= 0 || lh <= 0 || lw <= 0 || Cl <= 0) return false;
+    if (B > 65535 || sd > 32767 || sh > 32767 || sw > 32767 || ld > 65535 || lh > 65535 || lw > 65535) return false;
+    if (nd == 2 && (sd != 1 || ld != 1)) return false;
+    auto pair_ok = [](int64_t s, int64_t l) { return s == l / 2; };        // floor((l + 2 - 4) / 2) + 1 == l / 2
+    if (nd == 3 && !pair_ok(sd, ld)) return false;
+    return pair_ok(sh, lh) && pair_ok(sw, lw) && lh >= 2 && lw >= 2 && (nd == 2 || ld >= 2);
+}
+
+}  // namespace
+
+// C1 kernels live in conv_c1.hip
+int cvae_conv_down_c1(const void* L, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
+                      int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
+int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
+                    int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
+int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                       int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
+
+extern "C" size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, int dtype) {
+    const int64_t taps = (nd == 3) ? 64 : 16;
+    return (size_t)(Cs * Cl * taps) * (dtype == CVAE_BF16 ? 2 : 4);
+}
+
+extern "C" int cvae_conv_pack_weight(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, int dtype, void* stream) {
+    if ((nd != 2 && nd != 3) || Cs <= 0 || Cl <= 0) return CVAE_E_BADSHAPE;
+    if ((!for_up && Cl % 16) || (for_up && Cs % 16)) return CVAE_E_UNSUPPORTED;
+    if (!w || !packed) return CVAE_E_NULLPTR;
+    const int taps = (nd == 3) ? 64 : 16;
+    const int64_t n = Cs * Cl * taps;
+    if (dtype == CVAE_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)packed, (int)Cs, (int)Cl, taps, for_up);
+    else if (dtype == CVAE_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, (int)Cs, (int)Cl, taps, for_up);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+#define GEOM_INIT() ConvGeom g{(int)B, (int)sd, (int)sh, (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, (int)Cl, 0, 0, 0}
+
+extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
+                              int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                              int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
+    if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (B == 0) return CVAE_OK;
+    if (!L || !w || !S) return CVAE_E_NULLPTR;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cl == 1) return cvae_conv_down_c1(L, (const float*)w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
+    if (Cl % 16 || Cs % 64) return CVAE_E_UNSUPPORTED;
+    GEOM_INIT();
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st)
+                                           : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st);
+    return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st)
+                   : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st);
+}
+
+extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
+                            int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                            int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
+    if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (B == 0) return CVAE_OK;
+    if (!S || !w || !L) return CVAE_E_NULLPTR;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cl == 1) return cvae_conv_up_c1(S, (const float*)w, bias, mask, L, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
+    if (Cs % 16 || Cl % 32) return CVAE_E_UNSUPPORTED;
+    GEOM_INIT();
+    const bool wide = (Cl % 64) == 0;     // N tile 64 (2x2 waves, 128 rows) else N tile 32 (4x1 waves, 256 rows)
+    if (dtype == CVAE_BF16) {
+        if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+        return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+    }
+    if (nd == 3) return wide ? launch_data<float, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<float, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+    return wide ? launch_data<float, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<float, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+}
+
+extern "C" size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd) {
+    if (Cl == 1) return 0;
+    return (size_t)(Cs * Cl * ((nd == 3) ? 64 : 16)) * sizeof(float);
+}
+
+extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, void* workspace, size_t workspace_bytes,
+                               int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                               int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
+    if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (!dW) return CVAE_E_NULLPTR;
+    hipStream_t st = (hipStream_t)stream;
+    const int taps = (nd == 3) ? 64 : 16;
+    if (B == 0) return hipMemsetAsync(dW, 0, (size_t)Cs * Cl * taps * sizeof(float), st) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
+    if (!S || !L) return CVAE_E_NULLPTR;
+    if (Cl == 1) return cvae_conv_wgrad_c1(S, L, dW, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);
+    if (Cs % 64 || Cl % 32) return CVAE_E_UNSUPPORTED;
+    const size_t need = cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd);
+    if (!workspace) return CVAE_E_NULLPTR;
+    if (workspace_bytes < need) return CVAE_E_WORKSPACE;
+    if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return CVAE_E_LAUNCH;
+    GEOM_INIT();
+    int rc;
+    if (dtype == CVAE_BF16) rc = nd == 3 ? launch_wgrad<bf16, 3>(S, L, (float*)workspace, g, st) : launch_wgrad<bf16, 2>(S, L, (float*)workspace, g, st);
+    else rc = nd == 3 ? launch_wgrad<float, 3>(S, L, (float*)workspace, g, st) : launch_wgrad<float, 2>(S, L, (float*)workspace, g, st);
+    if (rc != CVAE_OK) return rc;
+    const int64_t n = Cs * Cl * taps;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, st, (const float*)workspace, dW, (int)Cs, (int)Cl, taps);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}

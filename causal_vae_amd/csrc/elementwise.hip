@@ -1,0 +1,381 @@
+// elementwise.hip — HBM-bound kernels of the CausalVAE step: layout/precision plumbing, pooling, (bi|tri)linear
+// resize, activation backward, channel sums.  All are streaming kernels: coalesced 64-lane rows, grid-stride,
+// grid capped at 8 blocks/CU (cdna_hip_programming.md Guideline 11).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------- cast
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+template <typename F>
+static int dispatch2(int sd, int dd, F&& f) {
+    if (sd == CVAE_F32 && dd == CVAE_F32) return f((const float*)0, (float*)0);
+    if (sd == CVAE_F32 && dd == CVAE_BF16) return f((const float*)0, (bf16*)0);
+    if (sd == CVAE_BF16 && dd == CVAE_F32) return f((const bf16*)0, (float*)0);
+    if (sd == CVAE_BF16 && dd == CVAE_BF16) return f((const bf16*)0, (bf16*)0);
+    return CVAE_E_DTYPE;
+}
+
+extern "C" int cvae_cast(const void* src, void* dst, int64_t n, int sd, int dd, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!src || !dst) return CVAE_E_NULLPTR;
+    return dispatch2(sd, dd, [&](auto* s, auto* d) {
+        using TS = std::remove_const_t<std::remove_pointer_t<decltype(s)>>;
+        using TD = std::remove_pointer_t<decltype(d)>;
+        hipLaunchKernelGGL((cast_kernel<TS, TD>), dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const TS*)src, (TD*)dst, n);
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------- [B,C,S] <-> [B,S,C]
+// 64x64 tile through LDS (+1 pad): reads run along S (contiguous in the source), writes along C.
+template <typename TS, typename TD, bool TO_NSC>
+__global__ void transpose_cs_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t C, int64_t S) {
+    __shared__ float tile[64][65];
+    const int64_t b = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+    if (TO_NSC) {   // src [C][S] -> dst [S][C]
+        for (int r = ty; r < 64; r += 4) {
+            int64_t c = c0 + r, s = s0 + tx;
+            tile[r][tx] = (c < C && s < S) ? to_f32(src[(b * C + c) * S + s]) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {
+            int64_t s = s0 + r, c = c0 + tx;
+            if (s < S && c < C) dst[(b * S + s) * C + c] = from_f32<TD>(tile[tx][r]);
+        }
+    } else {        // src [S][C] -> dst [C][S]
+        for (int r = ty; r < 64; r += 4) {
+            int64_t s = s0 + r, c = c0 + tx;
+            tile[r][tx] = (c < C && s < S) ? to_f32(src[(b * S + s) * C + c]) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {
+            int64_t c = c0 + r, s = s0 + tx;
+            if (s < S && c < C) dst[(b * C + c) * S + s] = from_f32<TD>(tile[tx][r]);
+        }
+    }
+}
+
+template <bool TO_NSC>
+static int transpose_cs(const void* src, void* dst, int64_t B, int64_t C, int64_t S, int sd, int dd, void* stream) {
+    if (B < 0 || C <= 0 || S < 0) return CVAE_E_BADSHAPE;
+    if (B == 0 || S == 0) return CVAE_OK;
+    if (!src || !dst) return CVAE_E_NULLPTR;
+    if (C == 1) return cvae_cast(src, dst, B * S, sd, dd, stream);
+    if (B > 65535 || (C + 63) / 64 > 65535) return CVAE_E_BADSHAPE;
+    return dispatch2(sd, dd, [&](auto* s, auto* d) {
+        using TS = std::remove_const_t<std::remove_pointer_t<decltype(s)>>;
+        using TD = std::remove_pointer_t<decltype(d)>;
+        dim3 grid((unsigned)((S + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+        hipLaunchKernelGGL((transpose_cs_kernel<TS, TD, TO_NSC>), grid, dim3(256), 0, (hipStream_t)stream,
+                           (const TS*)src, (TD*)dst, C, S);
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    });
+}
+extern "C" int cvae_ncs_to_nsc(const void* src, void* dst, int64_t B, int64_t C, int64_t S, int sd, int dd, void* stream) {
+    return transpose_cs<true>(src, dst, B, C, S, sd, dd, stream);
+}
+extern "C" int cvae_nsc_to_ncs(const void* src, void* dst, int64_t B, int64_t C, int64_t S, int sd, int dd, void* stream) {
+    return transpose_cs<false>(src, dst, B, C, S, sd, dd, stream);
+}
+
+// ------------------------------------------------------------------------------------- concat panels
+__global__ void copy_panel_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t B, int64_t cols,
+                                  int64_t ss, int64_t ds, int64_t col0) {
+    const int64_t n = B * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b = i / cols, j = i - b * cols;
+        dst[b * ds + col0 + j] = src[b * ss + j];
+    }
+}
+extern "C" int cvae_copy_panel(const float* src, float* dst, int64_t B, int64_t cols, int64_t ss, int64_t ds, int64_t col0, void* stream) {
+    if (B < 0 || cols < 0 || ss < cols || col0 < 0 || ds < col0 + cols) return CVAE_E_BADSHAPE;
+    if (B * cols == 0) return CVAE_OK;
+    if (!src || !dst) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(copy_panel_kernel, dim3(cvae_grid_1d(B * cols, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, B, cols, ss, ds, col0);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void onehot_panel_kernel(const int64_t* __restrict__ t, float* __restrict__ dst, int64_t B, int64_t nc, int64_t ds, int64_t col0) {
+    const int64_t n = B * nc;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b = i / nc, j = i - b * nc;
+        dst[b * ds + col0 + j] = (t[b] == j) ? 1.f : 0.f;
+    }
+}
+extern "C" int cvae_onehot_panel(const int64_t* t, float* dst, int64_t B, int64_t nc, int64_t ds, int64_t col0, void* stream) {
+    if (B < 0 || nc <= 0 || col0 < 0 || ds < col0 + nc) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!t || !dst) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(onehot_panel_kernel, dim3(cvae_grid_1d(B * nc, 256)), dim3(256), 0, (hipStream_t)stream, t, dst, B, nc, ds, col0);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- activation bwd
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = from_f32<T>(to_f32(dy[i]) * act_grad_from_out(to_f32(y[i]), act));
+}
+extern "C" int cvae_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, int dtype, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!dy || !y || !dx) return CVAE_E_NULLPTR;
+    if (dtype == CVAE_F32)
+        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)y, (float*)dx, n, act);
+    else if (dtype == CVAE_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n, act);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = from_f32<T>(apply_act(to_f32(x[i]), act));
+}
+extern "C" int cvae_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!x || !y) return CVAE_E_NULLPTR;
+    if (dtype == CVAE_F32) hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, act);
+    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(act_fwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n, act);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- channel sum
+// x [P, C] channels-last.  Block = 256 threads covers (256 / CL) rows x CL channel-lanes; lanes run along C so the
+// loads are contiguous; partials meet in LDS, one atomic per (block, channel).
+template <typename T>
+__global__ void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t P, int64_t C) {
+    __shared__ float red[256];
+    const int cl = (C >= 256) ? 256 : (int)C;              // channel lanes per block row
+    const int rows = 256 / cl;
+    const int c_in = threadIdx.x % cl, r_in = threadIdx.x / cl;
+    for (int64_t c0 = 0; c0 < C; c0 += cl) {
+        const int64_t c = c0 + c_in;
+        float acc = 0.f;
+        if (r_in < rows && c < C)
+            for (int64_t p = (int64_t)blockIdx.x * rows + r_in; p < P; p += (int64_t)gridDim.x * rows) acc += to_f32(x[p * C + c]);
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (r_in == 0 && c < C) {
+            float s = 0.f;
+            for (int r = 0; r < rows; ++r) s += red[r * cl + c_in];
+            atomicAdd(&out[c], s);
+        }
+        __syncthreads();
+    }
+}
+extern "C" int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* stream) {
+    if (P < 0 || C <= 0) return CVAE_E_BADSHAPE;
+    if (!out) return CVAE_E_NULLPTR;
+    if (hipMemsetAsync(out, 0, C * sizeof(float), (hipStream_t)stream) != hipSuccess) return CVAE_E_LAUNCH;
+    if (P == 0) return CVAE_OK;
+    if (!x) return CVAE_E_NULLPTR;
+    const int rows = (C >= 256) ? 1 : (int)(256 / C);
+    const int grid = cvae_grid_1d((P + rows - 1) / rows, 1, 1024);
+    if (dtype == CVAE_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, P, C);
+    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, P, C);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- adaptive avg pool
+__device__ __forceinline__ int64_t pool_start(int64_t o, int64_t I, int64_t O) { return (o * I) / O; }
+__device__ __forceinline__ int64_t pool_end(int64_t o, int64_t I, int64_t O) { return ((o + 1) * I + O - 1) / O; }
+
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C,
+                                   int64_t OD, int64_t OH, int64_t OW, int64_t out_stride) {
+    const int64_t OV = OD * OH * OW, n = B * OV * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i % C, o = (i / C) % OV, b = i / (C * OV);
+        const int64_t ow = o % OW, oh = (o / OW) % OH, od = o / (OW * OH);
+        const int64_t d0 = pool_start(od, D, OD), d1 = pool_end(od, D, OD);
+        const int64_t h0 = pool_start(oh, H, OH), h1 = pool_end(oh, H, OH);
+        const int64_t w0 = pool_start(ow, W, OW), w1 = pool_end(ow, W, OW);
+        float acc = 0.f;
+        for (int64_t d = d0; d < d1; ++d)
+            for (int64_t h = h0; h < h1; ++h)
+                for (int64_t w = w0; w < w1; ++w) acc += to_f32(x[(((b * D + d) * H + h) * W + w) * C + c]);
+        out[b * out_stride + c * OV + o] = acc / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
+    }
+}
+extern "C" int cvae_adaptive_avgpool_fwd(const void* x, float* out, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C,
+                                         int64_t OD, int64_t OH, int64_t OW, int64_t out_stride, int dtype, void* stream) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || OD <= 0 || OH <= 0 || OW <= 0 || out_stride < C * OD * OH * OW) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!x || !out) return CVAE_E_NULLPTR;
+    const int64_t n = B * OD * OH * OW * C;
+    if (dtype == CVAE_F32) hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, B, D, H, W, C, OD, OH, OW, out_stride);
+    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(avgpool_fwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, B, D, H, W, C, OD, OH, OW, out_stride);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ mask, T* __restrict__ dx, int64_t B, int64_t D, int64_t H,
+                                   int64_t W, int64_t C, int64_t OD, int64_t OH, int64_t OW, int64_t dstride) {
+    const int64_t V = D * H * W, OV = OD * OH * OW, n = B * V * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i % C, p = (i / C) % V, b = i / (C * V);
+        const int64_t w = p % W, h = (p / W) % H, d = p / (W * H);
+        float acc = 0.f;
+        if (!mask || to_f32(mask[i]) > 0.f) {
+            const int64_t odc = (d * OD) / D, ohc = (h * OH) / H, owc = (w * OW) / W;
+            for (int64_t od = max(odc - 1, (int64_t)0); od <= min(odc + 1, OD - 1); ++od) {
+                const int64_t d0 = pool_start(od, D, OD), d1 = pool_end(od, D, OD);
+                if (d < d0 || d >= d1) continue;
+                for (int64_t oh = max(ohc - 1, (int64_t)0); oh <= min(ohc + 1, OH - 1); ++oh) {
+                    const int64_t h0 = pool_start(oh, H, OH), h1 = pool_end(oh, H, OH);
+                    if (h < h0 || h >= h1) continue;
+                    for (int64_t ow = max(owc - 1, (int64_t)0); ow <= min(owc + 1, OW - 1); ++ow) {
+                        const int64_t w0 = pool_start(ow, W, OW), w1 = pool_end(ow, W, OW);
+                        if (w < w0 || w >= w1) continue;
+                        acc += dout[b * dstride + c * OV + (od * OH + oh) * OW + ow] / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
+                    }
+                }
+            }
+        }
+        dx[i] = from_f32<T>(acc);
+    }
+}
+extern "C" int cvae_adaptive_avgpool_bwd(const float* dout, const void* mask, void* dx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C,
+                                         int64_t OD, int64_t OH, int64_t OW, int64_t dstride, int dtype, void* stream) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || OD <= 0 || OH <= 0 || OW <= 0 || dstride < C * OD * OH * OW) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!dout || !dx) return CVAE_E_NULLPTR;
+    const int64_t n = B * D * H * W * C;
+    if (dtype == CVAE_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, (const float*)mask, (float*)dx, B, D, H, W, C, OD, OH, OW, dstride);
+    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, (const bf16*)mask, (bf16*)dx, B, D, H, W, C, OD, OH, OW, dstride);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- linear resize
+// torch upsample_{bi,tri}linear, align_corners=False: src = scale*(dst+0.5)-0.5 clamped at 0, scale = in/out (float).
+struct LinTap { int64_t i0, i1; float w0, w1; };
+__device__ __forceinline__ LinTap lin_tap(int64_t o, int64_t in, float scale) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    LinTap t;
+    t.i0 = (int64_t)s;
+    if (t.i0 > in - 1) t.i0 = in - 1;
+    t.i1 = t.i0 + ((t.i0 < in - 1) ? 1 : 0);
+    t.w1 = s - (float)t.i0;
+    t.w0 = 1.f - t.w1;
+    return t;
+}
+
+template <typename T>
+__global__ void upsample_fwd_kernel(const T* __restrict__ src, float* __restrict__ dst, int64_t B, int64_t d, int64_t h, int64_t w,
+                                    int64_t D, int64_t H, int64_t W, int64_t C) {
+    const float sd = (float)d / (float)D, sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int64_t n = B * D * H * W * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i % C;
+        int64_t r = i / C;
+        const int64_t ow = r % W; r /= W;
+        const int64_t oh = r % H; r /= H;
+        const int64_t od = r % D;
+        const int64_t b = r / D;
+        const LinTap td = lin_tap(od, d, sd), th = lin_tap(oh, h, sh), tw = lin_tap(ow, w, sw);
+        auto at = [&](int64_t z, int64_t y, int64_t x) { return to_f32(src[(((b * d + z) * h + y) * w + x) * C + c]); };
+        // same association as aten's CPU kernel: depth, then height, then width taps
+        float v = td.w0 * (th.w0 * (tw.w0 * at(td.i0, th.i0, tw.i0) + tw.w1 * at(td.i0, th.i0, tw.i1)) +
+                           th.w1 * (tw.w0 * at(td.i0, th.i1, tw.i0) + tw.w1 * at(td.i0, th.i1, tw.i1))) +
+                  td.w1 * (th.w0 * (tw.w0 * at(td.i1, th.i0, tw.i0) + tw.w1 * at(td.i1, th.i0, tw.i1)) +
+                           th.w1 * (tw.w0 * at(td.i1, th.i1, tw.i0) + tw.w1 * at(td.i1, th.i1, tw.i1)));
+        dst[i] = v;
+    }
+}
+extern "C" int cvae_upsample_linear_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, int64_t w,
+                                        int64_t D, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+    if (B < 0 || d <= 0 || h <= 0 || w <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!src || !dst) return CVAE_E_NULLPTR;
+    const int64_t n = B * D * H * W * C;
+    if (dtype == CVAE_F32) hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, B, d, h, w, D, H, W, C);
+    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(upsample_fwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, dst, B, d, h, w, D, H, W, C);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// Gather form of the transpose: for source index i, the destination indices whose taps touch i lie in
+// [floor((i-0.5)/scale - 0.5), ceil((i+1.5)/scale - 0.5)]; each candidate re-derives its taps with lin_tap, so the
+// weights are bit-identical to the forward's.
+__device__ __forceinline__ void cand_range(int64_t i, int64_t out, float scale, int64_t& lo, int64_t& hi) {
+    const float inv = 1.f / scale;
+    float a = ((float)i - 1.0f + 0.5f) * inv - 0.5f, b = ((float)i + 1.0f + 0.5f) * inv - 0.5f;
+    lo = (int64_t)floorf(a) - 1;
+    hi = (int64_t)ceilf(b) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+template <typename T>
+__global__ void upsample_bwd_kernel(const float* __restrict__ ddst, T* __restrict__ dsrc, int64_t B, int64_t d, int64_t h, int64_t w,
+                                    int64_t D, int64_t H, int64_t W, int64_t C) {
+    const float sd = (float)d / (float)D, sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int64_t n = B * d * h * w * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i % C;
+        int64_t r = i / C;
+        const int64_t x = r % w; r /= w;
+        const int64_t y = r % h; r /= h;
+        const int64_t z = r % d;
+        const int64_t b = r / d;
+        int64_t dlo, dhi, hlo, hhi, wlo, whi;
+        cand_range(z, D, sd, dlo, dhi);
+        cand_range(y, H, sh, hlo, hhi);
+        cand_range(x, W, sw, wlo, whi);
+        float acc = 0.f;
+        for (int64_t od = dlo; od <= dhi; ++od) {
+            const LinTap td = lin_tap(od, d, sd);
+            const float wd = (td.i0 == z ? td.w0 : 0.f) + (td.i1 == z ? td.w1 : 0.f);
+            if (wd == 0.f) continue;
+            for (int64_t oh = hlo; oh <= hhi; ++oh) {
+                const LinTap th = lin_tap(oh, h, sh);
+                const float wh = (th.i0 == y ? th.w0 : 0.f) + (th.i1 == y ? th.w1 : 0.f);
+                if (wh == 0.f) continue;
+                float row = 0.f;
+                for (int64_t ow = wlo; ow <= whi; ++ow) {
+                    const LinTap tw = lin_tap(ow, w, sw);
+                    const float ww = (tw.i0 == x ? tw.w0 : 0.f) + (tw.i1 == x ? tw.w1 : 0.f);
+                    if (ww != 0.f) row += ww * ddst[(((b * D + od) * H + oh) * W + ow) * C + c];
+                }
+                acc += wd * wh * row;
+            }
+        }
+        dsrc[i] = from_f32<T>(acc);
+    }
+}
+extern "C" int cvae_upsample_linear_bwd(const float* ddst, void* dsrc, int64_t B, int64_t d, int64_t h, int64_t w,
+                                        int64_t D, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+    if (B < 0 || d <= 0 || h <= 0 || w <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!ddst || !dsrc) return CVAE_E_NULLPTR;
+    const int64_t n = B * d * h * w * C;
+    if (dtype == CVAE_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, ddst, (float*)dsrc, B, d, h, w, D, H, W, C);
+    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(upsample_bwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, ddst, (bf16*)dsrc, B, d, h, w, D, H, W, C);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}

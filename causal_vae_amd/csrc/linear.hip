@@ -1,0 +1,142 @@
+// linear.hip — fp32 nn.Linear forward / backward-data / backward-weight on the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain, MI355X_MICROARCH.md "Matrix cores").
+//
+// One strided GEMM kernel serves the three products by choosing strides, so no operand is ever transposed in HBM:
+//     C[m, n] (+)= sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
+//   forward     : A = x  (sam = ldx, sak = 1) , B = W^T (sbk = 1,   sbn = K)  -> y  [M, N]
+//   bwd-data    : A = dy (sam = ldy, sak = 1) , B = W   (sbk = K,   sbn = 1)  -> dx [M, K]
+//   bwd-weight  : A = dy^T (sam = 1, sak = ldy), B = x  (sbk = ldx, sbn = 1)  -> dW [N, K]
+// Workgroup = 256 threads = 2x2 waves, tile 64x64x16, each wave 32x32 as 2x2 MFMA tiles.  The 3D model's
+// enc_fc[0] is a 16415x512 weight read by a batch of 4: pure weight streaming, so K is split across
+// workgroups (fp32 atomics into a zeroed C) until the grid covers the chip, and bias/activation run after.
+#include "common.h"
+
+#define LT 64
+#define LK 16
+#define AS_STRIDE 17   // As[64][17]  : A-fragment reads (lane -> row) conflict-free
+#define BS_STRIDE 80   // Bs[16][80]  : B-fragment reads (two k rows per 32-lane half) conflict-free
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                       const float* __restrict__ bias, int64_t M, int64_t N, int64_t K,
+                                                       int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
+                                                       int64_t k_per_split, int act, int use_atomic) {
+    __shared__ float As[LT * AS_STRIDE];
+    __shared__ float Bs[LK * BS_STRIDE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * LT, n0 = (int64_t)blockIdx.x * LT;
+    const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+    const int64_t kend = min(K, kbeg + k_per_split);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool a_k_contig = (sak == 1), b_n_contig = (sbn == 1);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += LK) {
+        // ---- stage A tile [64 m][16 k] and B tile [16 k][64 n] (4 elements per thread each) ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (a_k_contig) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+            const int64_t gm = m0 + m, gk = k0 + k;
+            As[m * AS_STRIDE + k] = (gm < M && gk < kend) ? A[gm * sam + gk * sak] : 0.f;
+            int n, kb;
+            if (b_n_contig) { n = t & 63; kb = (t >> 6) + 4 * i; } else { kb = t & 15; n = (t >> 4) + 16 * i; }
+            const int64_t gn = n0 + n, gkb = k0 + kb;
+            Bs[kb * BS_STRIDE + n] = (gn < N && gkb < kend) ? Bm[gkb * sbk + gn * sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < LK / 4; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 32 + i * 16 + (lane & 15)) * AS_STRIDE + kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(kk * 4 + (lane >> 4)) * BS_STRIDE + wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gm = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, gn = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (gm < M && gn < N) {
+                    float v = acc[i][j][r];
+                    if (use_atomic) atomicAdd(&C[gm * ldc + gn], v);
+                    else C[gm * ldc + gn] = apply_act(v + (bias ? bias[gn] : 0.f), act);
+                }
+            }
+}
+
+__global__ void bias_act_kernel(float* __restrict__ C, const float* __restrict__ bias, int64_t M, int64_t N, int64_t ldc, int act) {
+    const int64_t n = M * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / N, c = i - m * N;
+        C[m * ldc + c] = apply_act(C[m * ldc + c] + (bias ? bias[c] : 0.f), act);
+    }
+}
+
+static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias, int64_t M, int64_t N, int64_t K,
+                    int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int act, hipStream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || ldc < N) return CVAE_E_BADSHAPE;
+    if (M == 0) return CVAE_OK;
+    if (!A || !Bm || !C) return CVAE_E_NULLPTR;
+    const int64_t tm = (M + LT - 1) / LT, tn = (N + LT - 1) / LT;
+    if (tm > 65535) return CVAE_E_BADSHAPE;
+    // long reductions only: split K until ~2 workgroups per CU exist, keeping >= 8 K-steps (128 k) per split
+    int64_t splits = 1;
+    const int64_t ksteps = (K + LK - 1) / LK;
+    if (tm * tn < 512 && K >= 2048) {
+        splits = 512 / (tm * tn);
+        if (splits > ksteps / 8) splits = ksteps / 8;
+        if (splits < 1) splits = 1;
+        if (splits > 1024) splits = 1024;
+    }
+    int64_t k_per_split = ((ksteps + splits - 1) / splits) * LK;
+    splits = (K + k_per_split - 1) / k_per_split;
+    const int use_atomic = splits > 1;
+    if (use_atomic) {
+        if (ldc == N) { if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) return CVAE_E_LAUNCH; }
+        else if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, stream) != hipSuccess) return CVAE_E_LAUNCH;
+    }
+    dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, k_per_split, act, use_atomic);
+    CVAE_CHECK_LAUNCH();
+    if (use_atomic && (bias || act != CVAE_ACT_NONE)) {
+        hipLaunchKernelGGL(bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, C, bias, M, N, ldc, act);
+        CVAE_CHECK_LAUNCH();
+    }
+    return CVAE_OK;
+}
+
+extern "C" int cvae_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N,
+                               int64_t x_stride, int64_t y_stride, int act, void* stream) {
+    if (x_stride < K) return CVAE_E_BADSHAPE;
+    return gemm_f32(x, W, y, b, M, N, K, x_stride, 1, 1, K, y_stride, act, (hipStream_t)stream);
+}
+extern "C" int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N,
+                                    int64_t dy_stride, int64_t dx_stride, void* stream) {
+    if (dy_stride < N) return CVAE_E_BADSHAPE;
+    return gemm_f32(dy, W, dx, nullptr, M, K, N, dy_stride, 1, K, 1, dx_stride, CVAE_ACT_NONE, (hipStream_t)stream);
+}
+extern "C" int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N,
+                                      int64_t dy_stride, int64_t x_stride, void* stream) {
+    if (dy_stride < N || x_stride < K || M <= 0) return CVAE_E_BADSHAPE;
+    int rc = gemm_f32(dy, x, dW, nullptr, N, K, M, 1, dy_stride, x_stride, 1, K, CVAE_ACT_NONE, (hipStream_t)stream);
+    if (rc != CVAE_OK) return rc;
+    if (db) {
+        if (dy_stride != N) return CVAE_E_UNSUPPORTED;
+        return cvae_channel_sum(dy, db, M, N, CVAE_F32, stream);
+    }
+    return CVAE_OK;
+}

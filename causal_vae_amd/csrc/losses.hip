@@ -1,0 +1,419 @@
+// losses.hip — fp32 reductions and small per-row kernels of the ELBO: reparameterise + KLD, SSE / BCE / weighted-MSE
+// reconstruction terms, Gaussian NLL, softmax CE, uniform-KL, BatchNorm1d, Philox sampling, fused Adam, grad norm.
+// Reduction pattern everywhere: float4 grid-stride loads -> per-thread partial -> wave64 xor-shuffle -> LDS across
+// the 4 waves -> ONE atomicAdd per block (cdna_hip_programming.md Guideline 12, Appendix B "Reduction").
+#include "common.h"
+
+#define RED_BLOCK 256
+static inline int red_grid(int64_t n) { return cvae_grid_1d((n + 3) / 4, RED_BLOCK, 1024); }
+
+// Generic two-input streaming reduction: F(a, b) -> float, summed.
+template <typename F>
+__global__ void reduce2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n, F f) {
+    __shared__ float red[RED_BLOCK / 64];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const bool vec = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+    if (vec) {
+        const float4* a4 = (const float4*)a;
+        const float4* b4 = (const float4*)b;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 x = a4[i], y = b4[i];
+            acc += f(x.x, y.x) + f(x.y, y.y) + f(x.z, y.z) + f(x.w, y.w);
+        }
+        for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += f(a[i], b[i]);
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += f(a[i], b[i]);
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+struct SseF { __device__ float operator()(float a, float b) const { const float d = a - b; return d * d; } };
+struct SumF { __device__ float operator()(float a, float) const { return a; } };
+struct SqF { __device__ float operator()(float a, float) const { return a * a; } };
+struct BceF {   // -(x*max(log p, -100) + (1-x)*max(log(1-p), -100))  — aten binary_cross_entropy
+    __device__ float operator()(float p, float x) const {
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(log1pf(-p), -100.f);
+        return -(x * lp + (1.f - x) * lq);
+    }
+};
+
+#define LAUNCH_RED2(F, a, b, out, n, stream)                                                                         \
+    do {                                                                                                              \
+        if ((n) < 0) return CVAE_E_BADSHAPE;                                                                          \
+        if ((n) == 0) return CVAE_OK;                                                                                 \
+        if (!(a) || !(b) || !(out)) return CVAE_E_NULLPTR;                                                            \
+        hipLaunchKernelGGL((reduce2_kernel<F>), dim3(red_grid(n)), dim3(RED_BLOCK), 0, (hipStream_t)(stream), a, b, out, n, F()); \
+        CVAE_CHECK_LAUNCH();                                                                                          \
+        return CVAE_OK;                                                                                               \
+    } while (0)
+
+extern "C" int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* stream) { LAUNCH_RED2(SseF, a, b, out, n, stream); }
+extern "C" int cvae_sum_fwd(const float* x, float* out, int64_t n, void* stream) { LAUNCH_RED2(SumF, x, x, out, n, stream); }
+extern "C" int cvae_sqnorm(const float* g, float* out, int64_t n, void* stream) { LAUNCH_RED2(SqF, g, g, out, n, stream); }
+extern "C" int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* stream) { LAUNCH_RED2(BceF, p, x, out, n, stream); }
+
+// Elementwise two-input map with a device-scalar upstream gradient.
+template <typename F>
+__global__ void map2_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout, float* __restrict__ o, int64_t n, F f) {
+    const float g = gout ? *gout : 1.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = f(a[i], b[i]) * g;
+}
+struct SseB { __device__ float operator()(float a, float b) const { return 2.f * (a - b); } };
+struct BceB {   // d/dp of BceF; aten: (p - x) / max((1-p)*p, 1e-12)
+    __device__ float operator()(float p, float x) const { return (p - x) / fmaxf((1.f - p) * p, 1e-12f); }
+};
+#define LAUNCH_MAP2(F, a, b, g, o, n, stream)                                                                        \
+    do {                                                                                                              \
+        if ((n) < 0) return CVAE_E_BADSHAPE;                                                                          \
+        if ((n) == 0) return CVAE_OK;                                                                                 \
+        if (!(a) || !(b) || !(o)) return CVAE_E_NULLPTR;                                                              \
+        hipLaunchKernelGGL((map2_kernel<F>), dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)(stream), a, b, g, o, n, F()); \
+        CVAE_CHECK_LAUNCH();                                                                                          \
+        return CVAE_OK;                                                                                               \
+    } while (0)
+extern "C" int cvae_sse_bwd(const float* a, const float* b, const float* gout, float* da, int64_t n, void* stream) { LAUNCH_MAP2(SseB, a, b, gout, da, n, stream); }
+extern "C" int cvae_bce_bwd(const float* p, const float* x, const float* gout, float* dp, int64_t n, void* stream) { LAUNCH_MAP2(BceB, p, x, gout, dp, n, stream); }
+
+// ------------------------------------------------------------------------------------- vessel recon terms
+__device__ __forceinline__ float vessel_pos_weight(float sum_x, int64_t n) {
+    const float pf = sum_x / ((float)n + 1e-6f);
+    return fminf(fmaxf((1.f - pf) / (pf + 1e-6f), 1.f), 50.f);
+}
+__global__ void wmse_sparsity_fwd_kernel(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ sum_x,
+                                         float* __restrict__ out2, int64_t n) {
+    __shared__ float red[RED_BLOCK / 64];
+    const float pw = vessel_pos_weight(*sum_x, n);
+    float a0 = 0.f, a1 = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float rv = r[i], xv = x[i], d = rv - xv;
+        a0 += d * d * (1.f + (pw - 1.f) * xv);
+        a1 += (xv < 0.1f) ? fabsf(rv) : 0.f;
+    }
+    const float s0 = block_sum(a0, red);
+    const float s1 = block_sum(a1, red);
+    if (threadIdx.x == 0) { atomicAdd(&out2[0], s0); atomicAdd(&out2[1], s1); }
+}
+extern "C" int cvae_wmse_sparsity_fwd(const float* r, const float* x, const float* sum_x, float* out2, int64_t n, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!r || !x || !sum_x || !out2) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(wmse_sparsity_fwd_kernel, dim3(cvae_grid_1d(n, RED_BLOCK, 1024)), dim3(RED_BLOCK), 0, (hipStream_t)stream, r, x, sum_x, out2, n);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void wmse_sparsity_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ sum_x,
+                                         const float* __restrict__ g_recon, const float* __restrict__ g_sp, float* __restrict__ dr, int64_t n) {
+    const float pw = vessel_pos_weight(*sum_x, n);
+    const float gr = g_recon ? *g_recon : 0.f, gs = g_sp ? *g_sp : 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float rv = r[i], xv = x[i];
+        float g = gr * 2.f * (rv - xv) * (1.f + (pw - 1.f) * xv);
+        if (xv < 0.1f) g += gs * ((rv > 0.f) ? 1.f : ((rv < 0.f) ? -1.f : 0.f));   // d|r|/dr = sign(r), 0 at 0 (aten)
+        dr[i] = g;
+    }
+}
+extern "C" int cvae_wmse_sparsity_bwd(const float* r, const float* x, const float* sum_x, const float* g_recon, const float* g_sp, float* dr, int64_t n, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!r || !x || !sum_x || !dr) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(wmse_sparsity_bwd_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, r, x, sum_x, g_recon, g_sp, dr, n);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- reparameterise + KLD
+__global__ void reparam_kld_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
+                                       float* __restrict__ z, float* __restrict__ kld, int64_t n) {
+    __shared__ float red[RED_BLOCK / 64];
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mu[i], lv = logvar[i];
+        if (z) z[i] = m + eps[i] * expf(0.5f * lv);
+        acc += 1.f + lv - m * m - expf(lv);
+    }
+    if (kld) {
+        const float s = block_sum(acc, red);
+        if (threadIdx.x == 0) atomicAdd(kld, -0.5f * s);
+    }
+}
+extern "C" int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!mu || !logvar || (z && !eps) || (!z && !kld)) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(reparam_kld_fwd_kernel, dim3(cvae_grid_1d(n, RED_BLOCK, 256)), dim3(RED_BLOCK), 0, (hipStream_t)stream, mu, logvar, eps, z, kld, n);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void reparam_kld_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ gkld, const float* __restrict__ mu,
+                                       const float* __restrict__ logvar, const float* __restrict__ eps, float* __restrict__ dmu,
+                                       float* __restrict__ dlogvar, int64_t n) {
+    const float gk = gkld ? *gkld : 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mu[i], lv = logvar[i];
+        float gm = gk * m, gl = gk * 0.5f * (expf(lv) - 1.f);
+        if (dz) { const float g = dz[i]; gm += g; gl += g * eps[i] * 0.5f * expf(0.5f * lv); }
+        dmu[i] = gm;
+        dlogvar[i] = gl;
+    }
+}
+extern "C" int cvae_reparam_kld_bwd(const float* dz, const float* gkld, const float* mu, const float* logvar, const float* eps,
+                                    float* dmu, float* dlogvar, int64_t n, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!mu || !logvar || !dmu || !dlogvar || (dz && !eps)) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(reparam_kld_bwd_kernel, dim3(cvae_grid_1d(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, dz, gkld, mu, logvar, eps, dmu, dlogvar, n);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- Gaussian NLL
+__global__ void gauss_nll_fwd_kernel(const float* __restrict__ m, const float* __restrict__ mu, const float* __restrict__ lv, float* __restrict__ out, int64_t n) {
+    __shared__ float red[RED_BLOCK / 64];
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = m[i] - mu[i];
+        acc += lv[i] + d * d / expf(lv[i]);
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, 0.5f * s);
+}
+extern "C" int cvae_gauss_nll_fwd(const float* m, const float* mu, const float* lv, float* out, int64_t n, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!m || !mu || !lv || !out) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(gauss_nll_fwd_kernel, dim3(cvae_grid_1d(n, RED_BLOCK, 256)), dim3(RED_BLOCK), 0, (hipStream_t)stream, m, mu, lv, out, n);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void gauss_nll_bwd_kernel(const float* __restrict__ m, const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ gout,
+                                     float* __restrict__ dmu, float* __restrict__ dlv, int64_t n) {
+    const float g = gout ? *gout : 1.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = m[i] - mu[i], iv = 1.f / expf(lv[i]);
+        dmu[i] = g * (-d * iv);
+        dlv[i] = g * 0.5f * (1.f - d * d * iv);
+    }
+}
+extern "C" int cvae_gauss_nll_bwd(const float* m, const float* mu, const float* lv, const float* gout, float* dmu, float* dlv, int64_t n, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!m || !mu || !lv || !dmu || !dlv) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(gauss_nll_bwd_kernel, dim3(cvae_grid_1d(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, m, mu, lv, gout, dmu, dlv, n);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- softmax CE / uniform KL (rows of C <= 64 logits)
+// One wave per row, lane = class: max and sum by xor-shuffle.
+template <int MODE>   // 0: cross-entropy vs target; 1: KL(uniform || softmax)
+__global__ void row_softmax_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ gout,
+                                        float* __restrict__ out, float* __restrict__ dlogits, int64_t B, int64_t C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nrow = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float acc = 0.f;
+    const float g = (dlogits && gout) ? *gout : 1.f;
+    for (int64_t b = row0; b < B; b += nrow) {
+        const float v = (lane < C) ? logits[b * C + lane] : -INFINITY;
+        float mx = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float e = (lane < C) ? expf(v - mx) : 0.f;
+        const float se = wave_sum(e);
+        const float logp = v - mx - logf(se);             // log_softmax
+        if (MODE == 0) {
+            const int64_t t = target[b];
+            if (dlogits) { if (lane < C) dlogits[b * C + lane] = g * (e / se - (lane == t ? 1.f : 0.f)) / (float)B; }
+            else if (lane == t) acc += -logp / (float)B;
+        } else {
+            const float u = 1.f / (float)C;
+            if (dlogits) { if (lane < C) dlogits[b * C + lane] = g * (e / se - u) / (float)B; }
+            else if (lane < C) acc += u * (logf(u) - logp) / (float)B;   // kl_div(input=logp, target=u): u*(log u - logp), batchmean
+        }
+    }
+    if (!dlogits) {
+        acc = wave_sum(acc);
+        if (lane == 0) atomicAdd(out, acc);
+    }
+}
+static int row_loss(int mode, const float* logits, const int64_t* target, const float* gout, float* out, float* dl, int64_t B, int64_t C, void* stream) {
+    if (B < 0 || C <= 0 || C > 64) return (C > 64) ? CVAE_E_UNSUPPORTED : CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!logits || (mode == 0 && !target) || (!out && !dl)) return CVAE_E_NULLPTR;
+    const int grid = cvae_grid_1d(B * 64, 256, 256);
+    if (mode == 0) hipLaunchKernelGGL(row_softmax_loss_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, gout, out, dl, B, C);
+    else hipLaunchKernelGGL(row_softmax_loss_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, gout, out, dl, B, C);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+extern "C" int cvae_softmax_ce_fwd(const float* logits, const int64_t* target, float* out, int64_t B, int64_t C, void* stream) { return row_loss(0, logits, target, nullptr, out, nullptr, B, C, stream); }
+extern "C" int cvae_softmax_ce_bwd(const float* logits, const int64_t* target, const float* gout, float* dl, int64_t B, int64_t C, void* stream) { return row_loss(0, logits, target, gout, nullptr, dl, B, C, stream); }
+extern "C" int cvae_uniform_kl_fwd(const float* logits, float* out, int64_t B, int64_t C, void* stream) { return row_loss(1, logits, nullptr, nullptr, out, nullptr, B, C, stream); }
+extern "C" int cvae_uniform_kl_bwd(const float* logits, const float* gout, float* dl, int64_t B, int64_t C, void* stream) { return row_loss(1, logits, nullptr, gout, nullptr, dl, B, C, stream); }
+
+// ------------------------------------------------------------------------------------- BatchNorm1d  (x [B, F], F <= a few hundred)
+// One wave per feature, lanes stride the batch: two shuffle reductions (mean, then centred sum of squares — the
+// two-pass form keeps fp32 accuracy at B = 4 where E[x^2]-E[x]^2 would cancel).
+__global__ void bn1d_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                      float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ rmean, float* __restrict__ rvar,
+                                      int64_t B, int64_t F, float momentum, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (f >= F) return;
+    float s = 0.f;
+    for (int64_t i = lane; i < B; i += 64) s += x[i * F + f];
+    const float mean = wave_sum(s) / (float)B;
+    float q = 0.f;
+    for (int64_t i = lane; i < B; i += 64) { const float d = x[i * F + f] - mean; q += d * d; }
+    q = wave_sum(q);
+    const float var = q / (float)B, rstd = rsqrtf(var + eps);
+    const float ww = w ? w[f] : 1.f, bb = b ? b[f] : 0.f;
+    for (int64_t i = lane; i < B; i += 64) y[i * F + f] = (x[i * F + f] - mean) * rstd * ww + bb;
+    if (lane == 0) {
+        save_mean[f] = mean;
+        save_rstd[f] = rstd;
+        if (rmean) rmean[f] = (1.f - momentum) * rmean[f] + momentum * mean;
+        if (rvar) rvar[f] = (1.f - momentum) * rvar[f] + momentum * (q / (float)(B - 1));
+    }
+}
+extern "C" int cvae_bn1d_train_fwd(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
+                                   float* rmean, float* rvar, int64_t B, int64_t F, float momentum, float eps, void* stream) {
+    if (B < 2 || F <= 0) return CVAE_E_BADSHAPE;      // nn.BatchNorm1d raises for B == 1 in train mode; the Python side raises ValueError first
+    if (!x || !y || !save_mean || !save_rstd) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(bn1d_train_fwd_kernel, dim3((unsigned)((F * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, save_mean, save_rstd, rmean, rvar, B, F, momentum, eps);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void bn1d_train_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ save_mean,
+                                      const float* __restrict__ save_rstd, float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int64_t B, int64_t F) {
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (f >= F) return;
+    const float mean = save_mean[f], rstd = save_rstd[f], ww = w ? w[f] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = lane; i < B; i += 64) { const float g = dy[i * F + f], xh = (x[i * F + f] - mean) * rstd; s1 += g; s2 += g * xh; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const float inv = 1.f / (float)B;
+    for (int64_t i = lane; i < B; i += 64) {
+        const float g = dy[i * F + f], xh = (x[i * F + f] - mean) * rstd;
+        dx[i * F + f] = ww * rstd * (g - s1 * inv - xh * s2 * inv);
+    }
+    if (lane == 0) { if (dw) dw[f] = s2; if (db) db[f] = s1; }
+}
+extern "C" int cvae_bn1d_train_bwd(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_rstd,
+                                   float* dx, float* dw, float* db, int64_t B, int64_t F, void* stream) {
+    if (B < 2 || F <= 0) return CVAE_E_BADSHAPE;
+    if (!dy || !x || !save_mean || !save_rstd || !dx) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(bn1d_train_bwd_kernel, dim3((unsigned)((F * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x, w, save_mean, save_rstd, dx, dw, db, B, F);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void bn1d_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ rm,
+                                     const float* __restrict__ rv, float* __restrict__ y, int64_t n, int64_t F, float eps) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i % F;
+        y[i] = (x[i] - rm[f]) / sqrtf(rv[f] + eps) * (w ? w[f] : 1.f) + (b ? b[f] : 0.f);
+    }
+}
+extern "C" int cvae_bn1d_eval_fwd(const float* x, const float* w, const float* b, const float* rm, const float* rv, float* y, int64_t B, int64_t F, float eps, void* stream) {
+    if (B < 0 || F <= 0) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!x || !rm || !rv || !y) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(bn1d_eval_fwd_kernel, dim3(cvae_grid_1d(B * F, 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, rm, rv, y, B * F, F, eps);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- Philox4x32-10 normals
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + (uint64_t)i;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+        float v[4];
+        sincosf(6.283185307179586f * u1, &v[1], &v[0]);
+        sincosf(6.283185307179586f * u3, &v[3], &v[2]);
+        v[0] *= r0; v[1] *= r0; v[2] *= r1; v[3] *= r1;
+        for (int j = 0; j < 4; ++j) if (i * 4 + j < n) out[i * 4 + j] = v[j];
+    }
+}
+extern "C" int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!out) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------- Adam + clip
+// 28 B/param of HBM traffic (read p, g, m, v; write p, m, v) in float4 rows.
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step, float rbc2) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= step * (m / (sqrtf(v) * rbc2 + eps));
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2, const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.f;
+    const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
+    const int64_t n4 = n >> 2;
+    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    if (vec) {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+            adam1(P.x, G.x * gs, M.x, V.x, b1, b2, eps, step, rbc2);
+            adam1(P.y, G.y * gs, M.y, V.y, b1, b2, eps, step, rbc2);
+            adam1(P.z, G.z * gs, M.z, V.z, b1, b2, eps, step, rbc2);
+            adam1(P.w, G.w * gs, M.w, V.w, b1, b2, eps, step, rbc2);
+            ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+        }
+        for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            adam1(p[i], g[i] * gs, m[i], v[i], b1, b2, eps, step, rbc2);
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            adam1(p[i], g[i] * gs, m[i], v[i], b1, b2, eps, step, rbc2);
+    }
+}
+extern "C" int cvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                              float bc1, float bc2, const float* gscale, void* stream) {
+    if (n < 0 || bc1 <= 0.f || bc2 <= 0.f) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!p || !g || !m || !v) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(adam_kernel, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2, gscale);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ scale) {
+    const float s = *scale;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] *= s;
+}
+extern "C" int cvae_scale(float* g, int64_t n, const float* scale, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!g || !scale) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(scale_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, g, n, scale);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void clip_coef_kernel(const float* __restrict__ sq, float* __restrict__ scale, float max_norm) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *scale = fminf(1.f, max_norm / (sqrtf(*sq) + 1e-6f));
+}
+extern "C" int cvae_clip_coef(const float* sq, float* scale, float max_norm, void* stream) {
+    if (!sq || !scale) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sq, scale, max_norm);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}

@@ -1,0 +1,198 @@
+"""Drop-in nn.Module layers whose arithmetic runs in libcvae_hip.so.
+
+Each class subclasses the stock torch layer it replaces, so constructor arguments, default initialisation (and therefore
+the RNG draws of `torch.manual_seed(42); Model()`), parameter names, shapes and `state_dict()` keys are the reference's;
+only `forward` changes.  The containers (ConvStack / DeconvStack / MLP) are `nn.Sequential`s with the reference's child
+indices (so `enc_conv.0.weight` etc. interchange with reference checkpoints) whose forward runs the fused channels-last
+pipeline: conv+bias+ReLU in one kernel, ReLU masks folded into the neighbouring backward kernels.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import CvaeError, require_gpu
+
+
+def _check_k4s2p1(mod, nd):
+    ok = (tuple(mod.kernel_size) == (4,) * nd and tuple(mod.stride) == (2,) * nd and tuple(mod.padding) == (1,) * nd
+          and tuple(mod.dilation) == (1,) * nd and mod.groups == 1)
+    if hasattr(mod, "output_padding"):
+        ok = ok and tuple(mod.output_padding) == (0,) * nd
+    if getattr(mod, "padding_mode", "zeros") != "zeros" or not ok:
+        raise CvaeError(f"{type(mod).__name__}: the gfx950 kernels implement kernel 4 / stride 2 / padding 1 only "
+                        f"(got k={mod.kernel_size}, s={mod.stride}, p={mod.padding})")
+
+
+class _ConvBase:
+    """Shared by the four conv classes: `compute_dtype` and the channels-last entry point `forward_cl`."""
+    compute_dtype = torch.float32
+    _nd = 2
+    _fn = ops.ConvDown
+
+    def forward_cl(self, x_cl, act=None, in_is_relu_out=False, grad_premasked=False):
+        return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked)
+
+    def forward(self, x):                                   # NC(D)HW fp32 in / out, like the stock layer
+        require_gpu(x)
+        y = self.forward_cl(ops.ToChannelsLast.apply(x, self.compute_dtype))
+        return ops.FromChannelsLast.apply(y, self._nd)
+
+
+class Conv2d(_ConvBase, nn.Conv2d):
+    _nd, _fn = 2, ops.ConvDown
+
+    def __init__(self, *a, **k):
+        nn.Conv2d.__init__(self, *a, **k)
+        _check_k4s2p1(self, 2)
+
+
+class Conv3d(_ConvBase, nn.Conv3d):
+    _nd, _fn = 3, ops.ConvDown
+
+    def __init__(self, *a, **k):
+        nn.Conv3d.__init__(self, *a, **k)
+        _check_k4s2p1(self, 3)
+
+
+class ConvTranspose2d(_ConvBase, nn.ConvTranspose2d):
+    _nd, _fn = 2, ops.ConvUp
+
+    def __init__(self, *a, **k):
+        nn.ConvTranspose2d.__init__(self, *a, **k)
+        _check_k4s2p1(self, 2)
+
+
+class ConvTranspose3d(_ConvBase, nn.ConvTranspose3d):
+    _nd, _fn = 3, ops.ConvUp
+
+    def __init__(self, *a, **k):
+        nn.ConvTranspose3d.__init__(self, *a, **k)
+        _check_k4s2p1(self, 3)
+
+
+class Linear(nn.Linear):
+    def forward(self, x, act=None):
+        require_gpu(x)
+        return ops.Linear.apply(x, self.weight, self.bias, act)
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    def forward(self, x):
+        require_gpu(x)
+        if x.dim() != 2:
+            raise CvaeError("BatchNorm1d: [B, F] input expected")
+        if self.training:
+            if x.shape[0] <= 1:           # same error, same wording as torch (reference behaviour)
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.size()}")
+            if self.momentum is None:
+                raise CvaeError("BatchNorm1d: cumulative-average momentum=None is not implemented")
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            rm = self.running_mean if self.track_running_stats else None
+            rv = self.running_var if self.track_running_stats else None
+            return ops.BatchNorm1dTrain.apply(x, self.weight, self.bias, rm, rv, float(self.momentum), float(self.eps))
+        if x.requires_grad and torch.is_grad_enabled():
+            raise CvaeError("BatchNorm1d in eval mode is forward-only here (the reference consumers run it under no_grad)")
+        return ops.bn1d_eval(x, self.weight, self.bias, self.running_mean, self.running_var, float(self.eps))
+
+
+_ACT_NAME = {nn.ReLU: "relu", nn.Sigmoid: "sigmoid"}
+
+
+def _act_of(mod):
+    if isinstance(mod, nn.LeakyReLU):
+        if abs(mod.negative_slope - 0.2) > 1e-12:
+            raise CvaeError("only LeakyReLU(0.2) is implemented")
+        return "leaky02"
+    return _ACT_NAME.get(type(mod))
+
+
+class ConvStack(nn.Sequential):
+    """Encoder: [Conv, ReLU]* (+ AdaptiveAvgPool) + Flatten.  forward(x NC(D)HW fp32) -> [B, F] fp32."""
+    compute_dtype = torch.float32
+
+    def features_cl(self, x):
+        """Run the conv chain; returns the last activation channels-last (compute dtype) and the layers left over."""
+        mods = list(self)
+        convs = [m for m in mods if isinstance(m, _ConvBase)]
+        if not convs or x.shape[1] != convs[0].in_channels:
+            raise RuntimeError(f"expected input with {convs[0].in_channels if convs else '?'} channels, got {tuple(x.shape)}")
+        h = ops.ToChannelsLast.apply(x, self.compute_dtype)
+        i, prev_act = 0, None
+        while i < len(mods) and isinstance(mods[i], _ConvBase):
+            act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
+            # every consumer of a ReLU output inside this stack (next conv, final pool) folds that ReLU's mask
+            h = mods[i].forward_cl(h, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu"))
+            prev_act = act
+            i += 2 if act else 1
+        return h, mods[i:], prev_act
+
+    def forward(self, x):
+        require_gpu(x)
+        h, rest, last_act = self.features_cl(x)
+        nd = x.dim() - 2
+        out_size = tuple(h.shape[1:4])                       # bare Flatten == pooling with 1-voxel windows
+        for m in rest:
+            if isinstance(m, (nn.AdaptiveAvgPool2d, nn.AdaptiveAvgPool3d)):
+                o = m.output_size if isinstance(m.output_size, tuple) else (m.output_size,) * nd
+                out_size = ((1,) + tuple(o)) if nd == 2 else tuple(o)
+            elif not isinstance(m, nn.Flatten):
+                raise CvaeError(f"ConvStack: unsupported trailing layer {type(m).__name__}")
+        return ops.AdaptiveAvgPoolFlatten.apply(h, out_size, last_act == "relu")
+
+
+class DeconvStack(nn.Sequential):
+    """Decoder: [ConvTranspose, ReLU]* + ConvTranspose (+ Sigmoid).  forward(h NC(D)HW fp32) -> NC(D)HW fp32."""
+    compute_dtype = torch.float32
+
+    def forward_cl(self, h):
+        mods = list(self)
+        x = ops.ToChannelsLast.apply(h, self.compute_dtype)
+        i, prev_act = 0, None
+        while i < len(mods):
+            if not isinstance(mods[i], _ConvBase):
+                raise CvaeError(f"DeconvStack: unexpected layer {type(mods[i]).__name__} at index {i}")
+            act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
+            nxt = i + (2 if act else 1)
+            x = mods[i].forward_cl(x, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu" and nxt < len(mods)))
+            prev_act = act
+            i = nxt
+        return x
+
+    def forward(self, h):
+        require_gpu(h)
+        return ops.FromChannelsLast.apply(self.forward_cl(h), h.dim() - 2)
+
+
+class MLP(nn.Sequential):
+    """Sequential of Linear / BatchNorm1d / activation layers; Linear + activation pairs run as one kernel."""
+
+    def forward(self, x):
+        require_gpu(x)
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Linear):
+                act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
+                x = m(x, act=act)
+                i += 2 if act else 1
+            elif isinstance(m, BatchNorm1d):
+                x = m(x)
+                i += 1
+            elif _act_of(m):
+                x = ops.Activation.apply(x, _act_of(m))
+                i += 1
+            else:
+                raise CvaeError(f"MLP: unsupported layer {type(m).__name__}")
+        return x
+
+
+def set_compute_dtype(module, dtype):
+    """bf16 or fp32 conv arithmetic (weights stay fp32 masters; linears, losses and BN always fp32)."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise CvaeError(f"compute dtype must be float32 or bfloat16, got {dtype}")
+    for m in module.modules():
+        if isinstance(m, (_ConvBase, ConvStack, DeconvStack)):
+            m.compute_dtype = dtype
+    return module

@@ -1,0 +1,591 @@
+"""torch.autograd.Function wrappers over the C ABI (include/cvae_hip.h).
+
+The reference reaches its arithmetic through autograd (`loss.backward()`, causal_cascade/train.py:33), so the kernels hook
+in here: every Function.forward / backward enqueues HIP kernels on torch's current stream and nothing else.  Conv
+activations are channels-last [B, D, H, W, C] (D = 1 for 2D) in the compute dtype (float32 or bfloat16); linear layers,
+losses, BN and sampling are fp32.
+"""
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, ptr, stream
+
+
+def _cl_dims(t):
+    assert t.dim() == 5 and t.is_contiguous(), "channels-last [B, D, H, W, C] contiguous tensor expected"
+    return t.shape
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _scalar(like):
+    return torch.zeros((), dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------ layout plumbing
+class ToChannelsLast(torch.autograd.Function):
+    """NC(D)HW fp32 -> channels-last [B, D, H, W, C] in `dtype` (cvae_ncs_to_nsc)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        L.require_gpu(x)
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        sp = tuple(x.shape[2:])
+        S = 1
+        for s in sp:
+            S *= s
+        d5 = (1,) + sp if len(sp) == 2 else sp
+        out = _empty((B,) + d5 + (C,), dtype, x)
+        check(lib.cvae_ncs_to_nsc(ptr(x), ptr(out), B, C, S, L.dtype_code(x.dtype), L.dtype_code(dtype), stream()), "ncs_to_nsc")
+        ctx.meta = (x.shape, x.dtype, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dt, S = ctx.meta
+        g = g.contiguous()
+        out = _empty(shape, dt, g)
+        check(lib.cvae_nsc_to_ncs(ptr(g), ptr(out), shape[0], shape[1], S, L.dtype_code(g.dtype), L.dtype_code(dt), stream()), "nsc_to_ncs")
+        return out, None
+
+
+class FromChannelsLast(torch.autograd.Function):
+    """channels-last [B, D, H, W, C] -> NC(D)HW fp32; nd selects whether D is dropped."""
+
+    @staticmethod
+    def forward(ctx, x, nd):
+        L.require_gpu(x)
+        B, D, H, W, Cc = _cl_dims(x)
+        sp = (H, W) if nd == 2 else (D, H, W)
+        out = _empty((B, Cc) + sp, torch.float32, x)
+        check(lib.cvae_nsc_to_ncs(ptr(x), ptr(out), B, Cc, D * H * W, L.dtype_code(x.dtype), L.F32, stream()), "nsc_to_ncs")
+        ctx.meta = (x.shape, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dt = ctx.meta
+        g = g.contiguous()
+        out = _empty(shape, dt, g)
+        B, D, H, W, Cc = shape
+        check(lib.cvae_ncs_to_nsc(ptr(g), ptr(out), B, Cc, D * H * W, L.dtype_code(g.dtype), L.dtype_code(dt), stream()), "ncs_to_nsc")
+        return out, None
+
+
+class Cat(torch.autograd.Function):
+    """torch.cat(tensors, dim=1) for fp32 [B, n_i] matrices (cvae_copy_panel)."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        L.require_gpu(*ts)
+        B = ts[0].shape[0]
+        widths = [t.shape[1] for t in ts]
+        out = _empty((B, sum(widths)), torch.float32, ts[0])
+        col = 0
+        for t, w in zip(ts, widths):
+            t = t.contiguous()
+            check(lib.cvae_copy_panel(ptr(t), ptr(out), B, w, w, out.shape[1], col, stream()), "copy_panel")
+            col += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, tot = g.shape
+        outs, col = [], 0
+        for i, w in enumerate(ctx.widths):
+            if ctx.needs_input_grad[i]:
+                o = _empty((B, w), torch.float32, g)
+                # a panel copy with the roles of the strides swapped: src row stride = tot, start at column `col`
+                check(lib.cvae_copy_panel(g.data_ptr() + 4 * col, ptr(o), B, w, tot, w, 0, stream()), "copy_panel")
+                outs.append(o)
+            else:
+                outs.append(None)
+            col += w
+        return tuple(outs)
+
+
+def cat(tensors):
+    return Cat.apply(*tensors)
+
+
+def one_hot(t, n_classes):
+    """F.one_hot(t, n).float() (causal_cascade/models.py:71)."""
+    L.require_gpu(t)
+    t = t.contiguous()
+    if t.dtype != torch.int64:
+        raise L.CvaeError("class index tensor must be int64")
+    out = _empty((t.shape[0], n_classes), torch.float32, t)
+    check(lib.cvae_onehot_panel(ptr(t), ptr(out), t.shape[0], n_classes, n_classes, 0, stream()), "onehot_panel")
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty_like(x, dtype=dtype)
+    check(lib.cvae_cast(ptr(x), ptr(out), x.numel(), L.dtype_code(x.dtype), L.dtype_code(dtype), stream()), "cast")
+    return out
+
+
+class Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast(g.contiguous(), ctx.src), None
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+def _taps(nd):
+    return 64 if nd == 3 else 16
+
+
+def pack_weight(w, nd, for_up, dtype):
+    """fp32 [Cs][Cl][k..] -> MFMA operand panels (cvae_conv_pack_weight); the fp32 weight itself when Cl == 1."""
+    Cs, Cl = w.shape[0], w.shape[1]
+    w = w.contiguous()
+    if Cl == 1:
+        return w
+    out = torch.empty(Cs * Cl * _taps(nd), dtype=dtype, device=w.device)
+    check(lib.cvae_conv_pack_weight(ptr(w), ptr(out), Cs, Cl, nd, int(for_up), L.dtype_code(dtype), stream()), "conv_pack_weight")
+    return out
+
+
+def _conv_down(Lt, wp, bias, mask, Cs, nd, act):
+    B, ld, lh, lw, Cl = _cl_dims(Lt)
+    sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
+    S = _empty((B, sd, sh, sw, Cs), Lt.dtype, Lt)
+    check(lib.cvae_conv_down(ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd,
+                             L.dtype_code(Lt.dtype), L.act_code(act), stream()), "conv_down")
+    return S
+
+
+def _conv_up(St, wp, bias, mask, Cl, nd, act):
+    B, sd, sh, sw, Cs = _cl_dims(St)
+    ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
+    Lt = _empty((B, ld, lh, lw, Cl), St.dtype, St)
+    check(lib.cvae_conv_up(ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd,
+                           L.dtype_code(St.dtype), L.act_code(act), stream()), "conv_up")
+    return Lt
+
+
+def _conv_wgrad(St, Lt, nd, wshape):
+    B, sd, sh, sw, Cs = _cl_dims(St)
+    _, ld, lh, lw, Cl = _cl_dims(Lt)
+    dW = torch.empty(wshape, dtype=torch.float32, device=St.device)
+    nbytes = lib.cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd)
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=St.device)
+    check(lib.cvae_conv_wgrad(ptr(St), ptr(Lt), ptr(dW), ptr(ws), nbytes, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd,
+                              L.dtype_code(St.dtype), stream()), "conv_wgrad")
+    return dW
+
+
+def _channel_sum(x):
+    Cc = x.shape[-1]
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    check(lib.cvae_channel_sum(ptr(x), ptr(out), x.numel() // Cc, Cc, L.dtype_code(x.dtype), stream()), "channel_sum")
+    return out
+
+
+def _act_bwd(g, y, act):
+    out = torch.empty_like(g)
+    check(lib.cvae_act_bwd(ptr(g), ptr(y), ptr(out), g.numel(), L.act_code(act), L.dtype_code(g.dtype), stream()), "act_bwd")
+    return out
+
+
+class ConvDown(torch.autograd.Function):
+    """nn.Conv{2,3}d(k=4, s=2, p=1) + bias + activation on channels-last tensors.
+
+    in_is_relu_out: the input is itself a ReLU output, so the ReLU mask of the *producer* is fused into this op's
+      backward-data epilogue (the gradient it returns is already masked).
+    grad_premasked: the consumer of this op's output fuses this op's ReLU mask the same way, so the incoming
+      gradient needs no separate activation-backward pass.  (ReLU masking is idempotent; the flags only save traffic.)
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked):
+        L.require_gpu(x, weight, bias)
+        Cs = weight.shape[0]
+        wp = pack_weight(weight, nd, False, x.dtype)
+        y = _conv_down(x, wp, bias, None, Cs, nd, act)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (nd, act, in_is_relu_out, grad_premasked, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        nd, act, in_relu, premasked, has_bias = ctx.cfg
+        g = g.contiguous()
+        if act not in (None, "none") and not (premasked and act == "relu"):
+            g = _act_bwd(g, y, act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp_up = pack_weight(weight, nd, True, g.dtype)
+            dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None)
+        if ctx.needs_input_grad[1]:
+            dw = _conv_wgrad(g, x, nd, weight.shape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(g)
+        return dx, dw, db, None, None, None, None
+
+
+class ConvUp(torch.autograd.Function):
+    """nn.ConvTranspose{2,3}d(k=4, s=2, p=1) + bias + activation on channels-last tensors (flags as ConvDown)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked):
+        L.require_gpu(x, weight, bias)
+        Cl = weight.shape[1]
+        wp = pack_weight(weight, nd, True, x.dtype)
+        y = _conv_up(x, wp, bias, None, Cl, nd, act)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (nd, act, in_is_relu_out, grad_premasked, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        nd, act, in_relu, premasked, has_bias = ctx.cfg
+        g = g.contiguous()
+        if act not in (None, "none") and not (premasked and act == "relu"):
+            g = _act_bwd(g, y, act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp_dn = pack_weight(weight, nd, False, g.dtype)
+            dx = _conv_down(g, wp_dn, None, x if in_relu else None, weight.shape[0], nd, None)
+        if ctx.needs_input_grad[1]:
+            dw = _conv_wgrad(x, g, nd, weight.shape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(g)
+        return dx, dw, db, None, None, None, None
+
+
+class Activation(torch.autograd.Function):
+    """Stand-alone ReLU / Sigmoid / LeakyReLU(0.2) (used where no producer kernel can fuse it, e.g. after BatchNorm1d)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        L.require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.cvae_act_fwd(ptr(x), ptr(y), x.numel(), L.act_code(act), L.dtype_code(x.dtype), stream()), "act_fwd")
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return _act_bwd(g.contiguous(), y, ctx.act), None
+
+
+# ------------------------------------------------------------------------------------------------ pool / resize
+class AdaptiveAvgPoolFlatten(torch.autograd.Function):
+    """nn.AdaptiveAvgPool{2,3}d(out) + nn.Flatten on a channels-last input -> fp32 [B, C*prod(out)] in NC(D)HW flatten order.
+    relu_input: the input is a ReLU output whose mask is fused into the backward."""
+
+    @staticmethod
+    def forward(ctx, x, out_size, relu_input):
+        L.require_gpu(x)
+        B, D, H, W, Cc = _cl_dims(x)
+        OD, OH, OW = out_size
+        F = Cc * OD * OH * OW
+        out = _empty((B, F), torch.float32, x)
+        check(lib.cvae_adaptive_avgpool_fwd(ptr(x), ptr(out), B, D, H, W, Cc, OD, OH, OW, F, L.dtype_code(x.dtype), stream()), "avgpool_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (out_size, relu_input)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        (OD, OH, OW), relu_input = ctx.cfg
+        B, D, H, W, Cc = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.cvae_adaptive_avgpool_bwd(ptr(g), ptr(x) if relu_input else None, ptr(dx), B, D, H, W, Cc, OD, OH, OW, g.shape[1],
+                                            L.dtype_code(x.dtype), stream()), "avgpool_bwd")
+        return dx, None, None
+
+
+class UpsampleLinear(torch.autograd.Function):
+    """F.interpolate(mode='bilinear'|'trilinear', align_corners=False) on a channels-last input -> fp32 channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        L.require_gpu(x)
+        B, d, h, w, Cc = _cl_dims(x)
+        D, H, W = size
+        out = _empty((B, D, H, W, Cc), torch.float32, x)
+        check(lib.cvae_upsample_linear_fwd(ptr(x), ptr(out), B, d, h, w, D, H, W, Cc, L.dtype_code(x.dtype), stream()), "upsample_fwd")
+        ctx.meta = (x.shape, x.dtype, size)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dt, (D, H, W) = ctx.meta
+        B, d, h, w, Cc = shape
+        g = g.contiguous()
+        dx = _empty(shape, dt, g)
+        check(lib.cvae_upsample_linear_bwd(ptr(g), ptr(dx), B, d, h, w, D, H, W, Cc, L.dtype_code(dt), stream()), "upsample_bwd")
+        return dx, None
+
+
+# ------------------------------------------------------------------------------------------------ linear / BN
+class Linear(torch.autograd.Function):
+    """nn.Linear + optional fused activation (fp32, exact-fp32 MFMA)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        L.require_gpu(x, weight, bias)
+        if x.dtype != torch.float32:
+            raise L.CvaeError("linear layers run in float32")
+        x = x.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        y = _empty((M, N), torch.float32, x)
+        check(lib.cvae_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), stream()), "linear_fwd")
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        act, has_bias = ctx.cfg
+        g = g.contiguous()
+        if act not in (None, "none"):
+            g = _act_bwd(g, y, act)
+        M, K = x.shape
+        N = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((M, K), torch.float32, g)
+            check(lib.cvae_linear_bwd_data(ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, stream()), "linear_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = _empty((N,), torch.float32, g)
+            check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, stream()), "linear_bwd_weight")
+        elif has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(g)
+        return dx, dw, db, None
+
+
+class BatchNorm1dTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        L.require_gpu(x)
+        x = x.contiguous()
+        B, F = x.shape
+        y = torch.empty_like(x)
+        mean = _empty((F,), torch.float32, x)
+        rstd = _empty((F,), torch.float32, x)
+        check(lib.cvae_bn1d_train_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                                      B, F, momentum, eps, stream()), "bn1d_train_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, rstd = ctx.saved_tensors
+        g = g.contiguous()
+        B, F = x.shape
+        dx = torch.empty_like(x)
+        dw = _empty((F,), torch.float32, x)
+        db = _empty((F,), torch.float32, x)
+        check(lib.cvae_bn1d_train_bwd(ptr(g), ptr(x), ptr(weight), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), B, F, stream()), "bn1d_train_bwd")
+        return dx, dw, db, None, None, None, None
+
+
+def bn1d_eval(x, weight, bias, running_mean, running_var, eps):
+    L.require_gpu(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib.cvae_bn1d_eval_fwd(ptr(x), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), ptr(y), x.shape[0], x.shape[1], eps, stream()),
+          "bn1d_eval_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ sampling + losses
+def philox_normal(shape, seed, offset, device):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib.cvae_philox_normal(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, stream()), "philox_normal")
+    return out
+
+
+class Reparameterize(torch.autograd.Function):
+    """z = mu + eps * exp(logvar / 2) (causal_cascade/models.py:65-68) with an explicit eps."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        L.require_gpu(mu, logvar, eps)
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        z = torch.empty_like(mu)
+        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), ptr(eps), ptr(z), None, mu.numel(), stream()), "reparam_fwd")
+        ctx.save_for_backward(mu, logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar, eps = ctx.saved_tensors
+        g = g.contiguous()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        check(lib.cvae_reparam_kld_bwd(ptr(g), None, ptr(mu), ptr(logvar), ptr(eps), ptr(dmu), ptr(dlv), mu.numel(), stream()), "reparam_bwd")
+        return dmu, dlv, None
+
+
+class KLD(torch.autograd.Function):
+    """-0.5 * sum(1 + logvar - mu^2 - exp(logvar))   (causal_cascade/train.py:13)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        L.require_gpu(mu, logvar)
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        out = _scalar(mu)
+        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), None, None, ptr(out), mu.numel(), stream()), "kld_fwd")
+        ctx.save_for_backward(mu, logvar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        g = g.contiguous()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        check(lib.cvae_reparam_kld_bwd(None, ptr(g), ptr(mu), ptr(logvar), None, ptr(dmu), ptr(dlv), mu.numel(), stream()), "kld_bwd")
+        return dmu, dlv
+
+
+class _PairLoss(torch.autograd.Function):
+    """sum-reduced elementwise loss of (a, b) with gradient to a only (b is data)."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind):
+        L.require_gpu(a, b)
+        if a.dtype != torch.float32 or b.dtype != torch.float32:
+            raise L.CvaeError("loss inputs must be float32")
+        a, b = a.contiguous(), b.contiguous()
+        if a.shape != b.shape:
+            raise RuntimeError(f"The size of tensor a {tuple(a.shape)} must match the size of tensor b {tuple(b.shape)}")
+        out = _scalar(a)
+        fwd = lib.cvae_sse_fwd if kind == "sse" else lib.cvae_bce_fwd
+        check(fwd(ptr(a), ptr(b), ptr(out), a.numel(), stream()), kind + "_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.kind = kind
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = torch.empty_like(a)
+        bwd = lib.cvae_sse_bwd if ctx.kind == "sse" else lib.cvae_bce_bwd
+        check(bwd(ptr(a), ptr(b), ptr(g), ptr(da), a.numel(), stream()), ctx.kind + "_bwd")
+        return da, None, None
+
+
+def sse(a, b):
+    """F.mse_loss(a, b, reduction='sum') (gradient flows to a)."""
+    return _PairLoss.apply(a, b, "sse")
+
+
+def bce_sum(p, x):
+    """F.binary_cross_entropy(p, x, reduction='sum')."""
+    return _PairLoss.apply(p, x, "bce")
+
+
+class VesselRecon(torch.autograd.Function):
+    """(recon_loss, sparsity_loss) of vessel_analysis/01_train/train.py:27-46 (pos-weighted MSE-sum, background L1)."""
+
+    @staticmethod
+    def forward(ctx, r, x):
+        L.require_gpu(r, x)
+        r, x = r.contiguous(), x.contiguous()
+        sx = _scalar(r)
+        out2 = torch.zeros(2, dtype=torch.float32, device=r.device)
+        check(lib.cvae_sum_fwd(ptr(x), ptr(sx), x.numel(), stream()), "sum_fwd")
+        check(lib.cvae_wmse_sparsity_fwd(ptr(r), ptr(x), ptr(sx), ptr(out2), r.numel(), stream()), "wmse_sparsity_fwd")
+        ctx.save_for_backward(r, x, sx)
+        return out2[0], out2[1]
+
+    @staticmethod
+    def backward(ctx, g_recon, g_sp):
+        r, x, sx = ctx.saved_tensors
+        dr = torch.empty_like(r)
+        g_recon = g_recon.contiguous() if g_recon is not None else None
+        g_sp = g_sp.contiguous() if g_sp is not None else None
+        check(lib.cvae_wmse_sparsity_bwd(ptr(r), ptr(x), ptr(sx), ptr(g_recon), ptr(g_sp), ptr(dr), r.numel(), stream()), "wmse_sparsity_bwd")
+        return dr, None
+
+
+class GaussNLL(torch.autograd.Function):
+    """0.5 * sum(logvar + (m - mu)^2 / exp(logvar))   (vessel_analysis/01_train/train.py:56-58)."""
+
+    @staticmethod
+    def forward(ctx, m, mu, logvar):
+        L.require_gpu(m, mu, logvar)
+        m, mu, logvar = m.contiguous(), mu.contiguous(), logvar.contiguous()
+        out = _scalar(m)
+        check(lib.cvae_gauss_nll_fwd(ptr(m), ptr(mu), ptr(logvar), ptr(out), m.numel(), stream()), "gauss_nll_fwd")
+        ctx.save_for_backward(m, mu, logvar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m, mu, logvar = ctx.saved_tensors
+        g = g.contiguous()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        check(lib.cvae_gauss_nll_bwd(ptr(m), ptr(mu), ptr(logvar), ptr(g), ptr(dmu), ptr(dlv), m.numel(), stream()), "gauss_nll_bwd")
+        return None, dmu, dlv
+
+
+class SoftmaxCE(torch.autograd.Function):
+    """F.cross_entropy(logits, target) with mean reduction (mnist_test/01_baseline_causal_vae/train.py:56)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        L.require_gpu(logits, target)
+        logits, target = logits.contiguous(), target.contiguous()
+        out = _scalar(logits)
+        check(lib.cvae_softmax_ce_fwd(ptr(logits), ptr(target), ptr(out), logits.shape[0], logits.shape[1], stream()), "softmax_ce_fwd")
+        ctx.save_for_backward(logits, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        g = g.contiguous()
+        dl = torch.empty_like(logits)
+        check(lib.cvae_softmax_ce_bwd(ptr(logits), ptr(target), ptr(g), ptr(dl), logits.shape[0], logits.shape[1], stream()), "softmax_ce_bwd")
+        return dl, None
+
+
+class UniformKL(torch.autograd.Function):
+    """F.kl_div(F.log_softmax(logits, 1), full(1/C), reduction='batchmean') (mnist_test/01_baseline_causal_vae/train.py:82-85)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        L.require_gpu(logits)
+        logits = logits.contiguous()
+        out = _scalar(logits)
+        check(lib.cvae_uniform_kl_fwd(ptr(logits), ptr(out), logits.shape[0], logits.shape[1], stream()), "uniform_kl_fwd")
+        ctx.save_for_backward(logits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (logits,) = ctx.saved_tensors
+        g = g.contiguous()
+        dl = torch.empty_like(logits)
+        check(lib.cvae_uniform_kl_bwd(ptr(logits), ptr(g), ptr(dl), logits.shape[0], logits.shape[1], stream()), "uniform_kl_bwd")
+        return dl

@@ -1,0 +1,82 @@
+"""Data parallelism for the train step: one process per GPU, ONE sum all-reduce of the gradients per step over RCCL/xGMI.
+
+The reference is single-process (SURVEY.md §2 "Parallelism"); this layer is the addition named by the north star.  The
+losses are SUM-reduced over the batch (causal_cascade/train.py:7,10,13), so the gradient of the global batch is the SUM
+(not the mean) of the per-rank gradients — `GradAllReducer` therefore reduces with op=SUM and never divides.
+
+Per-rank statistics: BatchNorm1d in `mechanism_net` normalises with the statistics of the rank-local batch (the parity
+definition used by tests/test_parallel_gloo.py: an N-rank step equals a single-process step over the same N micro-batches
+with BN applied per micro-batch and gradients summed).
+
+The bucket is one flat fp32 buffer (61.4 MB for the 3D model): a single large message keeps the xGMI links at their
+bandwidth-bound rate instead of paying per-tensor latency 24 times.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    backend defaults to 'nccl' (= RCCL on ROCm) when a GPU is present, else 'gloo'.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+class GradAllReducer:
+    """Sums `.grad` of `params` across ranks through one flat bucket.  Call it between backward and optimizer.step
+    (the `grad_hook` of causal_cascade.train.train_step)."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self._flat = None
+
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def __call__(self):
+        if self.world_size() == 1:
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        n = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
+            self._flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+        off = 0
+        for g in grads:                       # pack
+            self._flat[off:off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for g in grads:                       # unpack in place
+            g.copy_(self._flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters and buffers."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def all_reduce_scalars(*scalars, group=None):
+    """Sum 0-dim loss tensors over ranks for logging (one tiny message)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return scalars
+    buf = torch.stack([s.detach().float() for s in scalars])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return tuple(buf.unbind(0))

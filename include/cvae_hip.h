@@ -1,0 +1,182 @@
+/* cvae_hip.h — C ABI of libcvae_hip.so: the MI355X (gfx950) kernels behind the CausalVAE train step.
+ *
+ * Boundary contract (SURVEY.md §8(b) "lower boundary"):
+ *   - extern "C", plain device pointers + sizes; no torch / C++ types.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never allocates or
+ *     frees device memory, never synchronises, never throws.  All buffers (inputs, outputs, workspace)
+ *     are owned by the caller (the torch caching allocator on the Python side).
+ *   - return 0 (CVAE_OK) or a negative CVAE_E_* code; cvae_strerror() names it.
+ *
+ * Tensor conventions
+ *   - conv activations are CHANNELS-LAST: [B, D, H, W, C] (D == 1 for 2D), dtype = CVAE_F32 or CVAE_BF16.
+ *   - every k4/s2/p1 convolution pair is described by its SMALL tensor S [B, sd, sh, sw, Cs] and its LARGE
+ *     tensor L [B, ld, lh, lw, Cl] with l = 2*s - 1 + k (k = 0..3) per strided dim; nd = 2 keeps D unstrided
+ *     (sd == ld == 1, one depth tap).  The weight W is fp32 [Cs][Cl][taps] — exactly nn.Conv{2,3}d.weight
+ *     ([C_out][C_in][k..], S = output) and nn.ConvTranspose{2,3}d.weight ([C_in][C_out][k..], S = input).
+ *       down : S = act(gather(L, W) + bias)   = Conv forward            = ConvTranspose backward-data
+ *       up   : L = act(scatter(S, W) + bias)  = ConvTranspose forward   = Conv backward-data
+ *       wgrad: dW[cs][cl][k] = sum S[.., cs] * L[2s-1+k, cl]            = both weight gradients
+ *   - linear layers, losses, BN, reparameterisation and Adam are fp32.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   conv_down/up/wgrad ........ nn.Conv2d / nn.ConvTranspose2d fwd+bwd   causal_cascade/models.py:12-16,50-55;
+ *                                                                        mnist_test/01_baseline_causal_vae/models.py:19-23,45-48
+ *   adaptive_avgpool .......... nn.AdaptiveAvgPool2d((4,4)) + Flatten    causal_cascade/models.py:18-19
+ *   upsample_linear ........... F.interpolate(bilinear, align_corners=False)  causal_cascade/models.py:87
+ *   linear_* .................. nn.Linear (+ReLU/LeakyReLU)              causal_cascade/models.py:24-31,35-44
+ *   bn1d_* .................... nn.BatchNorm1d(64)                       causal_cascade/models.py:36
+ *   reparam_kld_* ............. reparameterize + KLD term                causal_cascade/models.py:65-68, train.py:13
+ *   sse / bce / wmse_sparsity / gauss_nll .. loss terms                  causal_cascade/train.py:7,10;
+ *                                            mnist_test/01_baseline_causal_vae/train.py:70; vessel_analysis/01_train/train.py:27-58
+ *   softmax_ce / uniform_kl ... F.cross_entropy, F.kl_div(log_softmax)   mnist_test/01_baseline_causal_vae/train.py:56,82-85
+ *   adam_step / sqnorm ........ optim.Adam.step, clip_grad_norm_         causal_cascade/main.py:50, train.py:34;
+ *                                                                        vessel_analysis/01_train/train.py:85-86
+ */
+#ifndef CVAE_HIP_H
+#define CVAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVAE_OK             0
+#define CVAE_E_BADSHAPE    (-1)
+#define CVAE_E_DTYPE       (-2)
+#define CVAE_E_UNSUPPORTED (-3)
+#define CVAE_E_WORKSPACE   (-4)
+#define CVAE_E_LAUNCH      (-5)
+#define CVAE_E_NULLPTR     (-6)
+
+#define CVAE_F32  0
+#define CVAE_BF16 1
+
+#define CVAE_ACT_NONE    0
+#define CVAE_ACT_RELU    1
+#define CVAE_ACT_SIGMOID 2
+#define CVAE_ACT_LEAKY02 3   /* LeakyReLU(0.2) */
+
+int         cvae_version(void);
+const char* cvae_strerror(int code);
+
+/* ---- layout / precision plumbing -------------------------------------------------------------- */
+/* [B, C, S] (torch NC(D)HW, S = spatial voxels) -> channels-last [B, S, C], converting dtype on the way. */
+int cvae_ncs_to_nsc(const void* src, void* dst, int64_t B, int64_t C, int64_t S, int src_dtype, int dst_dtype, void* stream);
+int cvae_nsc_to_ncs(const void* src, void* dst, int64_t B, int64_t C, int64_t S, int src_dtype, int dst_dtype, void* stream);
+int cvae_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* dst[b, col0 + j] = src[b, j] for j < cols (fp32): writes one panel of a concatenated [B, dst_stride] matrix. */
+int cvae_copy_panel(const float* src, float* dst, int64_t B, int64_t cols, int64_t src_stride, int64_t dst_stride, int64_t col0, void* stream);
+/* dst[b, col0 + t[b]] = 1, other columns of the panel 0 (F.one_hot(t, n).float() into a concat panel). */
+int cvae_onehot_panel(const int64_t* t, float* dst, int64_t B, int64_t n_classes, int64_t dst_stride, int64_t col0, void* stream);
+
+/* ---- k4 s2 p1 convolution family ---------------------------------------------------------------- */
+/* fp32 W [Cs][Cl][taps] -> MFMA operand panels in the compute dtype.
+ *   for_up == 0: [tap][Cl/16][Cs][16]   (down: N = Cs, K = (tap, cl))
+ *   for_up == 1: [tap][Cs/16][Cl][16]   (up  : N = Cl, K = (tap, cs))
+ * Not needed (pass the fp32 W itself as `w`) when Cl == 1. */
+size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, int dtype);
+int cvae_conv_pack_weight(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, int dtype, void* stream);
+
+/* S = act(gather(L, w) + bias) [then * (mask > 0) if mask != NULL].  bias fp32 [Cs] or NULL; mask has S's shape/dtype. */
+int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
+                   int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                   int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream);
+/* L = act(scatter(S, w) + bias) [then * (mask > 0) if mask != NULL].  bias fp32 [Cl] or NULL; mask has L's shape/dtype. */
+int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
+                 int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                 int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream);
+/* dW fp32 [Cs][Cl][taps] (overwritten) = sum over batch and positions.  workspace: cvae_conv_wgrad_workspace_bytes(). */
+size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd);
+int cvae_conv_wgrad(const void* S, const void* L, float* dW, void* workspace, size_t workspace_bytes,
+                    int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                    int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream);
+/* out[c] = sum_p x[p, c] over a channels-last [P, C] tensor (bias gradients). out is overwritten. */
+int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* stream);
+/* y = act(x) elementwise (nn.ReLU / nn.Sigmoid / nn.LeakyReLU(0.2) when not fused into a producer). */
+int cvae_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
+/* dx = dy * act'(y) elementwise (y = saved activation OUTPUT); dtype applies to all three. */
+int cvae_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
+
+/* ---- pooling / resize ----------------------------------------------------------------------------- */
+/* x channels-last [B, D, H, W, C] -> out fp32 [B, out_stride], columns (c, od, oh, ow) flattened like
+ * nn.AdaptiveAvgPool(d)+Flatten on NC(D)HW; adaptive windows [floor(i*I/O), ceil((i+1)*I/O)). */
+int cvae_adaptive_avgpool_fwd(const void* x, float* out, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C,
+                              int64_t OD, int64_t OH, int64_t OW, int64_t out_stride, int dtype, void* stream);
+/* dx[b, d, h, w, c] = sum over windows containing (d, h, w) of dout / |window|, times (x > 0) when relu_mask_x != NULL. */
+int cvae_adaptive_avgpool_bwd(const float* dout, const void* relu_mask_x, void* dx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C,
+                              int64_t OD, int64_t OH, int64_t OW, int64_t dout_stride, int dtype, void* stream);
+/* (bi|tri)linear resize, align_corners = False, channels-last C channels; src dtype `dtype`, dst fp32. */
+int cvae_upsample_linear_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, int64_t w,
+                             int64_t D, int64_t H, int64_t W, int64_t C, int dtype, void* stream);
+/* transpose of the above: dsrc (dtype `dtype`) = A^T ddst (fp32). */
+int cvae_upsample_linear_bwd(const float* ddst, void* dsrc, int64_t B, int64_t d, int64_t h, int64_t w,
+                             int64_t D, int64_t H, int64_t W, int64_t C, int dtype, void* stream);
+
+/* ---- fp32 linear layers ------------------------------------------------------------------------------ */
+/* y[M, N] = act(x[M, K] @ W[N, K]^T + b).  workspace: 0 bytes needed; kept for ABI stability. */
+int cvae_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N,
+                    int64_t x_stride, int64_t y_stride, int act, void* stream);
+/* dx[M, K] = dy[M, N] @ W[N, K] */
+int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N,
+                         int64_t dy_stride, int64_t dx_stride, void* stream);
+/* dW[N, K] = dy^T x ; db[N] = column sums of dy (db may be NULL).  Both overwritten. */
+int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N,
+                           int64_t dy_stride, int64_t x_stride, void* stream);
+
+/* ---- BatchNorm1d --------------------------------------------------------------------------------------- */
+/* train: batch statistics (biased var) normalise; running stats updated with momentum (unbiased var). B >= 2. */
+int cvae_bn1d_train_fwd(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
+                        float* running_mean, float* running_var, int64_t B, int64_t F, float momentum, float eps, void* stream);
+int cvae_bn1d_train_bwd(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_rstd,
+                        float* dx, float* dw, float* db, int64_t B, int64_t F, void* stream);
+int cvae_bn1d_eval_fwd(const float* x, const float* w, const float* b, const float* running_mean, const float* running_var,
+                       float* y, int64_t B, int64_t F, float eps, void* stream);
+
+/* ---- sampling + losses (all reductions accumulate into a caller-zeroed fp32 scalar) ------------------------- */
+/* eps ~ N(0,1): Philox4x32-10 + Box-Muller, counter-based (seed, offset) -> reproducible per launch. */
+int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* z = mu + eps*exp(logvar/2) (if z != NULL);  *kld += -0.5*sum(1 + logvar - mu^2 - exp(logvar)) (if kld != NULL). */
+int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* stream);
+/* dmu = dz + gk*mu ; dlogvar = dz*eps*0.5*exp(logvar/2) + gk*0.5*(exp(logvar) - 1); dz / gkld (device scalar) may be NULL. */
+int cvae_reparam_kld_bwd(const float* dz, const float* gkld, const float* mu, const float* logvar, const float* eps,
+                         float* dmu, float* dlogvar, int64_t n, void* stream);
+/* *out += sum (a - b)^2 */
+int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* da = 2*(a - b) * (*gout)   (db = -da is formed by the caller when needed) */
+int cvae_sse_bwd(const float* a, const float* b, const float* gout, float* da, int64_t n, void* stream);
+/* F.binary_cross_entropy(p, x, reduction='sum') with torch's log clamp at -100 */
+int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* stream);
+int cvae_bce_bwd(const float* p, const float* x, const float* gout, float* dp, int64_t n, void* stream);
+/* vessel recon terms (vessel_analysis/01_train/train.py:27-46): stats[0] = sum(x) must be produced first by
+ * cvae_sum_fwd; then out[0] += sum (r-x)^2 (1 + (pw-1) x), out[1] += sum |r| [x < 0.1], pw = clamp((1-pf)/(pf+1e-6), 1, 50). */
+int cvae_sum_fwd(const float* x, float* out, int64_t n, void* stream);
+int cvae_wmse_sparsity_fwd(const float* r, const float* x, const float* sum_x, float* out2, int64_t n, void* stream);
+int cvae_wmse_sparsity_bwd(const float* r, const float* x, const float* sum_x, const float* g_recon, const float* g_sparsity,
+                           float* dr, int64_t n, void* stream);
+/* *out += 0.5 * sum(logvar + (m - mu)^2 / exp(logvar)) */
+int cvae_gauss_nll_fwd(const float* m, const float* mu, const float* logvar, float* out, int64_t n, void* stream);
+int cvae_gauss_nll_bwd(const float* m, const float* mu, const float* logvar, const float* gout, float* dmu, float* dlogvar, int64_t n, void* stream);
+/* *out += mean_b CE(logits[b, :], target[b])  (F.cross_entropy, reduction='mean'); dlogits = (softmax - onehot)/B * gout */
+int cvae_softmax_ce_fwd(const float* logits, const int64_t* target, float* out, int64_t B, int64_t C, void* stream);
+int cvae_softmax_ce_bwd(const float* logits, const int64_t* target, const float* gout, float* dlogits, int64_t B, int64_t C, void* stream);
+/* *out += F.kl_div(log_softmax(logits), full(1/C), reduction='batchmean'); dlogits = (softmax - 1/C)/B * gout */
+int cvae_uniform_kl_fwd(const float* logits, float* out, int64_t B, int64_t C, void* stream);
+int cvae_uniform_kl_bwd(const float* logits, const float* gout, float* dlogits, int64_t B, int64_t C, void* stream);
+
+/* ---- optimiser ---------------------------------------------------------------------------------------------- */
+/* torch.optim.Adam (no weight decay / amsgrad) on flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t
+ * computed by the caller.  grad_scale: optional device scalar multiplied into g first (gradient clipping). */
+int cvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float bc1, float bc2, const float* grad_scale, void* stream);
+/* *out += sum g^2 */
+int cvae_sqnorm(const float* g, float* out, int64_t n, void* stream);
+/* g *= *scale  (in place; scale is a device scalar) */
+int cvae_scale(float* g, int64_t n, const float* scale, void* stream);
+/* *scale = min(1, max_norm / (sqrt(*sqnorm) + 1e-6))   (clip_grad_norm_ coefficient, on device) */
+int cvae_clip_coef(const float* sqnorm, float* scale, float max_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVAE_HIP_H */

@@ -1,0 +1,204 @@
+"""GPU parity tests of the whole drop-in models and train steps against (a) the golden vectors captured from the
+reference classes and (b) the CPU oracle on the same seeded inputs.  Tolerances: fp32 path rtol 1e-4 on activations and
+gradients, 1e-4 relative on the ELBO (the BASELINE target); the bf16 path states its own.
+"""
+import copy
+import io
+
+import pytest
+import torch
+
+import oracle
+from oracle import functional as ofn
+
+pytestmark = pytest.mark.gpu
+if torch.cuda.is_available():
+    import causal_vae_amd
+    from causal_vae_amd import FusedAdam
+    from causal_vae_amd._lib import CvaeError
+    from causal_vae_amd.causal_cascade import CausalBioVAE, CausalBioVAE3D, loss_function, train_one_epoch, train_step
+    from causal_vae_amd.mnist_baseline import CausalMorphVAE12, LatentDiscriminator
+    from causal_vae_amd.mnist_baseline import train_step as mnist_train_step
+
+DEV = "cuda"
+NOISE_KEY = "mechanism_net.0.bias"      # exactly-zero gradient (bias before train-mode BN): rounding noise only
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+
+
+@pytest.mark.parametrize("case", ["bio2d_b4_64x96", "bio2d_b2_64x64", "bio2d_b3_128x160"])
+def test_bio2d_matches_reference_golden(golden, case):
+    """CausalBioVAE (fp32 MFMA path) vs tensors produced by the reference class itself: forward, ELBO, grads, Adam."""
+    g = golden(case)
+    torch.manual_seed(42)
+    model = CausalBioVAE().to(DEV)
+    for k, v in model.state_dict().items():
+        g.check("sd0", k, v, rtol=0, atol=0)                     # identical initialisation for the reference's seed
+    model.train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    x, m, t, eps = (g.t("in/" + k).to(DEV) for k in ("x", "m", "t", "eps"))
+    opt.zero_grad()
+    recon_x, m_hat, mu, logvar = model(x, m, t, eps=eps)
+    for k, v in dict(recon_x=recon_x, m_hat=m_hat, mu=mu, logvar=logvar).items():
+        g.check("out", k, v, rtol=1e-4, atol=2e-5)
+    loss, l_recon, l_m = loss_function(recon_x, x, m_hat, m, mu, logvar)
+    assert rel(loss, g.t("loss/loss")) < 1e-4 and rel(l_recon, g.t("loss/recon")) < 1e-4 and rel(l_m, g.t("loss/m_loss")) < 1e-4
+    loss.backward()
+    for k, p in model.named_parameters():
+        if k == NOISE_KEY:
+            assert p.grad.abs().max() < 0.05
+            continue
+        scale = float(g.z[f"grad/{k}#digest"][1]) / max(p.numel(), 1)          # mean |grad|
+        g.check("grad", k, p.grad, rtol=2e-3, atol=2e-3 * scale + 1e-6)
+    opt.step()
+    for k, v in model.state_dict().items():
+        if k == NOISE_KEY:
+            assert (v.cpu() - g.t("sd1/" + k)).abs().max() <= 2.0e-3 + 1e-6
+            continue
+        g.check("sd1", k, v, rtol=1e-4, atol=2.1e-4 if "weight" in k or "bias" in k else 1e-5)
+    model.eval()
+    with torch.no_grad():                                        # causal_cascade/analyze.py:10-23 access pattern
+        from causal_vae_amd import ops
+        m_hat_eval = model.mechanism_net(ops.one_hot(t, 19))
+    g.check("eval", "m_hat", m_hat_eval, rtol=1e-3, atol=1e-3)
+
+
+def test_morph12_matches_reference_golden(golden):
+    g = golden("morph12_b8")
+    torch.manual_seed(42)
+    vae, disc = CausalMorphVAE12().to(DEV), LatentDiscriminator().to(DEV)
+    for k, v in vae.state_dict().items():
+        g.check("sd0", k, v, rtol=0, atol=0)
+    for k, v in disc.state_dict().items():
+        g.check("sdd0", k, v, rtol=0, atol=0)
+    vae.train(); disc.train()
+    x, m, t = (g.t("in/" + k).to(DEV) for k in ("x", "m", "t"))
+    recon_x, m_hat, mu, logvar = vae(x, m, t, eps=g.t("fwd/eps").to(DEV))
+    for k, v in dict(recon_x=recon_x, m_hat=m_hat, mu=mu, logvar=logvar).items():
+        g.check("fwd", k, v, rtol=1e-4, atol=1e-5)
+    opt_vae, opt_d = FusedAdam(vae.parameters(), lr=1e-3), FusedAdam(disc.parameters(), lr=1e-3)
+    eps = tuple(g.t("step/" + k).to(DEV) for k in ("eps_d", "eps_vae", "eps_adv"))
+    r = mnist_train_step(vae, disc, opt_vae, opt_d, x, m, t, eps=eps)
+    for k in ("loss_d", "loss", "recon", "kld", "morph", "adv"):
+        assert rel(r[k], g.t("step/" + k)) < 1e-4, (k, float(r[k]), float(g.t("step/" + k)))
+    for k, v in vae.state_dict().items():
+        g.check("sd1", k, v, rtol=1e-4, atol=2.1e-4)             # Adam's first step moves every weight by ~lr: sign flips of ~0 grads
+    for k, v in disc.state_dict().items():
+        g.check("sdd1", k, v, rtol=1e-4, atol=2.1e-4)
+
+
+def _oracle_step(kind, x, m, t, eps, nd):
+    sd = oracle.init_state_dict(kind, seed=42)
+    sd0 = {k: v.clone() for k, v in sd.items()}
+    st = oracle.cascade_train_step(sd, x, m, t, eps, nd=nd)
+    return sd0, sd, st
+
+
+@pytest.mark.parametrize("B,size", [(2, 32), (2, 64), (2, 48)])
+def test_bio3d_fp32_matches_oracle(B, size):
+    """3D lift vs the CPU oracle: forward, ELBO (<= 1e-4 rel), gradients, one Adam step."""
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 1, size, size, size, generator=g)
+    m = torch.rand(B, 12, generator=g)
+    t = torch.randint(0, 19, (B,), generator=g)
+    eps = torch.randn(B, 64, generator=g)
+    sd0, sd1, st = _oracle_step("bio3d", x, m, t, eps, 3)
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).train()
+    assert all(torch.equal(model.state_dict()[k].cpu(), sd0[k]) for k in sd0)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    loss, l_recon, l_m = train_step(model, opt, x.to(DEV), m.to(DEV), t.to(DEV), eps=eps.to(DEV))
+    assert rel(loss, st["loss"]) < 1e-4, (float(loss), float(st["loss"]))
+    assert rel(l_recon, st["recon"]) < 1e-4 and rel(l_m, st["m_loss"]) < 1e-4
+    for k, p in model.named_parameters():
+        if k == NOISE_KEY:
+            continue
+        gref = st["grads"][k]
+        scale = float(gref.abs().mean())
+        torch.testing.assert_close(p.grad.cpu(), gref, rtol=2e-3, atol=2e-3 * scale + 1e-7, msg=lambda s: f"grad {k}: {s}")
+        torch.testing.assert_close(p.detach().cpu(), sd1[k], rtol=1e-4, atol=2.1e-4, msg=lambda s: f"param {k}: {s}")
+    for k in ("mechanism_net.1.running_mean", "mechanism_net.1.running_var", "mechanism_net.1.num_batches_tracked"):
+        torch.testing.assert_close(model.state_dict()[k].cpu(), sd1[k], rtol=1e-5, atol=1e-6)
+
+
+def test_bio3d_bf16_elbo_vs_fp32_oracle():
+    """bf16 conv path (fp32 accumulate, fp32 heads and losses): ELBO relative error vs the fp32 CPU oracle, stated."""
+    g = torch.Generator().manual_seed(1234)
+    B, size = 2, 64
+    x = torch.randn(B, 1, size, size, size, generator=g)
+    m, t, eps = torch.rand(B, 12, generator=g), torch.randint(0, 19, (B,), generator=g), torch.randn(B, 64, generator=g)
+    _, _, st = _oracle_step("bio3d", x, m, t, eps, 3)
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    loss, l_recon, l_m = train_step(model, opt, x.to(DEV), m.to(DEV), t.to(DEV), eps=eps.to(DEV))
+    err = rel(loss, st["loss"])
+    print(f"bf16 ELBO rel err vs fp32 oracle: {err:.3e} (loss {float(loss):.4f} vs {float(st['loss']):.4f})")
+    assert err < 1e-3
+    # direction of the update agrees with the fp32 gradients
+    for k in ("enc_conv.2.weight", "dec_conv.2.weight", "enc_fc.0.weight", "dec_input.weight"):
+        a, b = dict(model.named_parameters())[k].grad.cpu().flatten(), st["grads"][k].flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        assert cos > 0.99, (k, cos)
+
+
+def test_consumer_access_patterns_and_checkpoint_interchange():
+    """What the reference's analysis scripts do to a trained model (SURVEY.md §8(b) census), on synthetic inputs."""
+    torch.manual_seed(0)
+    vae = CausalMorphVAE12().to(DEV).eval()
+    x, m = torch.rand(5, 1, 28, 28, device=DEV), torch.rand(5, 12, device=DEV)
+    t = torch.eye(10, device=DEV)[torch.tensor([1, 2, 3, 4, 5])]
+    with torch.no_grad():
+        x_feat = vae.enc_conv(x)                                             # visualize.py:26-28
+        mu, logvar = vae.enc_fc(torch.cat([x_feat, m, t], dim=1)).chunk(2, dim=1)
+        z = vae.reparameterize(mu, logvar)                                   # 2-argument call, device RNG
+        m_hat = vae.morph_predictor(t)                                       # visualize.py:34
+        h = vae.dec_fc(torch.cat([m_hat, z], dim=1)).view(-1, 64, 7, 7)      # visualize.py:87-89
+        recon = vae.dec_conv(h)
+    assert x_feat.shape == (5, 3136) and recon.shape == (5, 1, 28, 28) and recon.dtype == torch.float32
+    assert float(recon.min()) >= 0 and float(recon.max()) <= 1 and torch.isfinite(z).all()
+    assert not hasattr(vae, "dec_adapter")                                   # analyze_vessel.py:93 discriminator
+    # state_dict round trip through torch.save / load_state_dict, and interchange with a reference-keyed dict
+    buf = io.BytesIO(); torch.save(vae.state_dict(), buf); buf.seek(0)
+    vae2 = CausalMorphVAE12().to(DEV)
+    vae2.load_state_dict(torch.load(buf, map_location=DEV))
+    ref_sd = oracle.init_state_dict("morph12", seed=7)
+    vae2.load_state_dict(ref_sd)                                             # strict: same keys, same shapes
+    with torch.no_grad():
+        out = vae2(x, m, t, eps=torch.zeros(5, 10, device=DEV))
+    ref = ofn.morph_vae_forward(ref_sd, x.cpu(), m.cpu(), t.cpu(), torch.zeros(5, 10))
+    torch.testing.assert_close(out[0].cpu(), ref["recon_x"], rtol=1e-4, atol=1e-5)
+    # BatchNorm1d with a batch of one raises ValueError in train mode like the reference
+    bio = CausalBioVAE().to(DEV).train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        bio(torch.zeros(1, 1, 64, 64, device=DEV), torch.zeros(1, 12, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
+    with pytest.raises(CvaeError, match="CPU tensor"):
+        bio(torch.zeros(2, 1, 64, 64), torch.zeros(2, 12), torch.zeros(2, dtype=torch.long))
+
+
+def test_train_one_epoch_surface_and_stock_optimizer():
+    """train_one_epoch(model, loader, optimizer, device) with a stock torch optimizer: grads arrive through autograd."""
+    torch.manual_seed(42)
+    model = CausalBioVAE().to(DEV)
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randn(1, 64, 64, generator=g), torch.rand(12, generator=g), torch.randint(0, 19, (), generator=g)) for _ in range(8)]
+    loader = torch.utils.data.DataLoader(data, batch_size=4, shuffle=False)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)                      # the reference's optimizer (main.py:50)
+    l1 = train_one_epoch(model, loader, opt, DEV)
+    l2 = train_one_epoch(model, loader, opt, DEV)
+    assert l1 > 0 and l2 < l1                                                # the ELBO goes down
+    assert all(p.grad is not None for p in model.parameters())
+
+
+def test_bio3d_128_smoke_bf16():
+    """BASELINE config 4 shape on one GPU: B=4, 128^3, bf16: runs, finite, loss decreases over 3 steps."""
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(4, 1, 128, 128, 128, generator=g).to(DEV)
+    m, t = torch.rand(4, 12, generator=g).to(DEV), torch.randint(0, 19, (4,), generator=g).to(DEV)
+    losses = [float(train_step(model, opt, x, m, t)[0]) for _ in range(3)]
+    assert all(map(lambda v: v == v and v < 1e9, losses)) and losses[-1] < losses[0], losses

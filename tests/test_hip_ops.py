@@ -1,0 +1,371 @@
+"""GPU parity tests, op by op: each HIP kernel (called through the C ABI via causal_vae_amd.ops) against the same
+arithmetic in plain PyTorch on the CPU (the aten calls the reference makes: F.conv2d/3d, F.conv_transpose*, F.linear, ...).
+
+Tolerances (stated per SURVEY.md §8(c)):
+  fp32 path  : rtol 1e-4 / atol 1e-4·scale  (exact-fp32 MFMA; only the summation order differs from aten)
+  bf16 path  : inputs and weights are rounded to bf16 FIRST and the CPU reference computes in fp32 on those rounded
+               values, so the only differences are summation order and the final bf16 rounding of the output:
+               rtol 1.6e-2 (2 bf16 ulps), atol 1e-2·scale.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from causal_vae_amd import ops
+    from causal_vae_amd import _lib as L
+    from causal_vae_amd.optim import FusedAdam, clip_grad_norm_
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, scale=1.0):
+    return dict(rtol=1e-4, atol=1e-4 * scale) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1e-2 * scale)
+
+
+def rnd(x, dtype):
+    """round-trip through the compute dtype (what the kernel will see)"""
+    return x.to(dtype).float()
+
+
+def to_cl(x, dtype):
+    """CPU NC(D)HW fp32 -> GPU channels-last [B, D, H, W, C] in dtype"""
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV).to(dtype)
+
+
+def from_cl(y, nd):
+    y = y.float().cpu().permute(0, 4, 1, 2, 3)
+    return y.squeeze(2) if nd == 2 else y
+
+
+def close(got, ref, dtype, what, scale=None):
+    scale = float(ref.abs().max()) if scale is None else scale
+    torch.testing.assert_close(got, ref, **tol(dtype, max(scale, 1e-6)), msg=lambda s: f"{what}: {s}")
+
+
+# --------------------------------------------------------------------------------------------- conv family
+CONV_CASES = [
+    # nd, B, C_big(Cl), C_small(Cs), large spatial size
+    (2, 2, 1, 32, (28, 28)),
+    (2, 3, 32, 64, (14, 14)),
+    (2, 2, 32, 64, (30, 44)),       # ragged tiles
+    (2, 1, 64, 128, (16, 24)),
+    (3, 2, 1, 32, (16, 16, 16)),
+    (3, 2, 32, 64, (16, 16, 16)),
+    (3, 1, 64, 128, (8, 8, 8)),
+    (3, 1, 128, 256, (4, 4, 4)),
+    (3, 1, 32, 64, (10, 12, 18)),   # ragged tiles
+    (3, 1, 1, 32, (6, 20, 10)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("nd,B,Cl,Cs,size", CONV_CASES)
+def test_conv_forward_backward(nd, B, Cl, Cs, size, dtype):
+    """nn.Conv{2,3}d(k4,s2,p1)+bias+ReLU: y, dx, dW, db (down / up / wgrad / channel_sum kernels)."""
+    g = torch.Generator().manual_seed(1)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    x = rnd(torch.randn(B, Cl, *size, generator=g), dtype).requires_grad_(True)
+    w = (torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cl * 4 ** nd)).requires_grad_(True)
+    b = torch.randn(Cs, generator=g).requires_grad_(True)
+    wr = rnd(w.detach(), dtype)
+    y_ref = F.relu(conv(x, wr.requires_grad_(True), b, stride=2, padding=1))
+    gy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, wr, b], gy)
+
+    xg = to_cl(x.detach(), dtype).requires_grad_(True)
+    wg = w.detach().to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True)
+    y = ops.ConvDown.apply(xg, wg, bg, nd, "relu", False, False)
+    close(from_cl(y, nd), y_ref.detach(), dtype, "y")
+    y.backward(to_cl(gy, dtype))
+    # dx is bf16-rounded on the bf16 path; dW/db are fp32 sums of products of rounded inputs
+    close(from_cl(xg.grad, nd), gx_ref, dtype, "dx")
+    close(wg.grad.cpu(), gw_ref, dtype if dtype == torch.float32 else torch.float32, "dW", scale=float(gw_ref.abs().max()) * (1 if dtype == torch.float32 else 30))
+    close(bg.grad.cpu(), gb_ref, torch.float32, "db", scale=float(gb_ref.abs().max()) * 3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("nd,B,Cl,Cs,size", CONV_CASES)
+def test_conv_transpose_forward_backward(nd, B, Cl, Cs, size, dtype):
+    """nn.ConvTranspose{2,3}d(k4,s2,p1)+bias (+ReLU): input is the SMALL tensor (Cs channels), output the large one."""
+    g = torch.Generator().manual_seed(2)
+    convT = F.conv_transpose2d if nd == 2 else F.conv_transpose3d
+    ssize = tuple(s // 2 for s in size)
+    size = tuple(2 * s for s in ssize)
+    act = "relu" if Cl > 1 else None
+    x = rnd(torch.randn(B, Cs, *ssize, generator=g), dtype).requires_grad_(True)
+    w = (torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cs * 2 ** nd))
+    b = torch.randn(Cl, generator=g).requires_grad_(True)
+    wr = rnd(w, dtype).requires_grad_(True)
+    y_ref = convT(x, wr, b, stride=2, padding=1)
+    if act:
+        y_ref = F.relu(y_ref)
+    gy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, wr, b], gy)
+
+    xg = to_cl(x.detach(), dtype).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True)
+    y = ops.ConvUp.apply(xg, wg, bg, nd, act, False, False)
+    close(from_cl(y, nd), y_ref.detach(), dtype, "y")
+    y.backward(to_cl(gy, dtype))
+    close(from_cl(xg.grad, nd), gx_ref, dtype, "dx")
+    close(wg.grad.cpu(), gw_ref, torch.float32, "dW", scale=float(gw_ref.abs().max()) * (1 if dtype == torch.float32 else 30))
+    close(bg.grad.cpu(), gb_ref, torch.float32, "db", scale=float(gb_ref.abs().max()) * 3)
+
+
+def test_conv_relu_mask_fusion_matches_unfused():
+    """in_is_relu_out / grad_premasked only move the ReLU mask into neighbouring kernels: gradients must not change."""
+    g = torch.Generator().manual_seed(3)
+    x = to_cl(torch.randn(2, 1, 16, 16, 16, generator=g), torch.float32)
+    w1 = (torch.randn(32, 1, 4, 4, 4, generator=g) * 0.2).to(DEV)
+    w2 = (torch.randn(64, 32, 4, 4, 4, generator=g) * 0.03).to(DEV)
+    res = []
+    for fused in (False, True):
+        a, b = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        h = ops.ConvDown.apply(x, a, None, 3, "relu", False, fused)
+        y = ops.ConvDown.apply(h, b, None, 3, "relu", fused, False)
+        y.square().sum().backward()
+        res.append((a.grad.clone(), b.grad.clone()))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
+
+
+def test_conv_unsupported_and_bad_shapes_fail_loudly():
+    x = torch.zeros(1, 1, 8, 8, 24, device=DEV)
+    with pytest.raises(L.CvaeError, match="not supported"):
+        ops.ConvDown.apply(x, torch.zeros(64, 24, 4, 4, device=DEV), None, 2, None, False, False)     # Cl % 16 != 0
+    with pytest.raises(L.CvaeError, match="CPU tensor"):
+        ops.ConvDown.apply(torch.zeros(1, 1, 8, 8, 32), torch.zeros(64, 32, 4, 4), None, 2, None, False, False)
+    empty = torch.zeros(0, 1, 8, 8, 32, device=DEV)
+    y = ops.ConvDown.apply(empty, torch.zeros(64, 32, 4, 4, device=DEV), None, 2, None, False, False)
+    assert y.shape == (0, 1, 4, 4, 64)
+
+
+# --------------------------------------------------------------------------------------------- pool / resize / layout
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("nd,size,out", [(2, (4, 6), (4, 4)), (2, (8, 10), (4, 4)), (2, (7, 7), (7, 7)), (3, (8, 8, 8), (4, 4, 4)),
+                                         (3, (4, 4, 4), (4, 4, 4)), (3, (5, 6, 9), (4, 4, 4))])
+def test_adaptive_avgpool_flatten(nd, size, out, dtype):
+    g = torch.Generator().manual_seed(4)
+    x = rnd(torch.randn(3, 40, *size, generator=g).relu(), dtype).requires_grad_(True)
+    pool = F.adaptive_avg_pool2d if nd == 2 else F.adaptive_avg_pool3d
+    y_ref = pool(x, out).flatten(1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    gx_ref = gx_ref * (x.detach() > 0)                           # relu_input=True folds the producer's ReLU mask
+    xg = to_cl(x.detach(), dtype).requires_grad_(True)
+    o3 = out if nd == 3 else (1,) + out
+    y = ops.AdaptiveAvgPoolFlatten.apply(xg, o3, True)
+    close(y.cpu(), y_ref.detach(), torch.float32, "pool")
+    y.backward(gy.to(DEV))
+    close(from_cl(xg.grad, nd), gx_ref, dtype, "dpool")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("nd,src,dst", [(2, (64, 64), (64, 96)), (2, (64, 64), (128, 160)), (2, (16, 16), (9, 11)), (3, (16, 16, 16), (32, 32, 32)),
+                                        (3, (8, 8, 8), (12, 20, 9)), (3, (8, 8, 8), (8, 8, 8))])
+def test_upsample_linear(nd, src, dst, dtype):
+    g = torch.Generator().manual_seed(5)
+    x = rnd(torch.randn(2, 1, *src, generator=g), dtype).requires_grad_(True)
+    y_ref = F.interpolate(x, size=dst, mode="bilinear" if nd == 2 else "trilinear", align_corners=False)
+    gy = torch.randn(y_ref.shape, generator=g)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    xg = to_cl(x.detach(), dtype).requires_grad_(True)
+    d3 = dst if nd == 3 else (1,) + dst
+    y = ops.UpsampleLinear.apply(xg, d3)
+    close(from_cl(y, nd), y_ref.detach(), torch.float32, "upsample")
+    y.backward(to_cl(gy, torch.float32))
+    close(from_cl(xg.grad, nd), gx_ref, dtype, "dupsample")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_layout_roundtrip_cat_onehot(dtype):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 70, 5, 6, 7, generator=g)
+    cl = ops.ToChannelsLast.apply(x.to(DEV), dtype)
+    close(cl.float().cpu(), x.permute(0, 2, 3, 4, 1), dtype, "to_cl")
+    back = ops.FromChannelsLast.apply(cl, 3)
+    close(back.cpu(), rnd(x, dtype), torch.float32, "from_cl")
+    a, b, c = torch.randn(5, 33, generator=g), torch.randn(5, 12, generator=g), torch.randn(5, 19, generator=g)
+    ag = a.to(DEV).requires_grad_(True)
+    out = ops.cat([ag, b.to(DEV), c.to(DEV)])
+    assert torch.equal(out.cpu(), torch.cat([a, b, c], 1))
+    out.backward(torch.arange(5 * 64, dtype=torch.float32, device=DEV).view(5, 64))
+    assert torch.equal(ag.grad.cpu(), torch.arange(5 * 64, dtype=torch.float32).view(5, 64)[:, :33])
+    t = torch.tensor([0, 18, 3, 7], dtype=torch.int64)
+    assert torch.equal(ops.one_hot(t.to(DEV), 19).cpu(), F.one_hot(t, 19).float())
+
+
+# --------------------------------------------------------------------------------------------- linear / BN
+@pytest.mark.parametrize("M,K,N,act", [(4, 16415, 512, "relu"), (4, 76, 16384, None), (4, 256, 64, None), (128, 3158, 512, "relu"),
+                                       (1024, 22, 3136, "relu"), (7, 10, 64, "leaky02"), (2, 19, 64, None)])
+def test_linear_forward_backward(M, K, N, act):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(M, K, generator=g).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    y_ref = F.linear(x, w, b)
+    y_ref = {"relu": F.relu, "leaky02": lambda v: F.leaky_relu(v, 0.2), None: lambda v: v}[act](y_ref)
+    gy = torch.randn(M, N, generator=g)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, w, b], gy)
+    xg, wg, bg = (v.detach().to(DEV).requires_grad_(True) for v in (x, w, b))
+    y = ops.Linear.apply(xg, wg, bg, act)
+    close(y.cpu(), y_ref.detach(), torch.float32, "y")
+    y.backward(gy.to(DEV))
+    close(xg.grad.cpu(), gx_ref, torch.float32, "dx")
+    close(wg.grad.cpu(), gw_ref, torch.float32, "dW")
+    close(bg.grad.cpu(), gb_ref, torch.float32, "db")
+
+
+@pytest.mark.parametrize("B", [2, 4, 100])
+def test_batchnorm1d_train_and_eval(B):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 64, generator=g).requires_grad_(True)
+    w, b = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.batch_norm(x, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5)
+    gy = torch.randn(B, 64, generator=g)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, wr, br], gy)
+    xg, wg, bg = (v.detach().to(DEV).requires_grad_(True) for v in (x, w, b))
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    y = ops.BatchNorm1dTrain.apply(xg, wg, bg, rmg, rvg, 0.1, 1e-5)
+    close(y.cpu(), y_ref.detach(), torch.float32, "bn y")
+    close(rmg.cpu(), rm_ref, torch.float32, "running_mean")
+    close(rvg.cpu(), rv_ref, torch.float32, "running_var")
+    y.backward(gy.to(DEV))
+    sc = float(gx_ref.abs().max())
+    torch.testing.assert_close(xg.grad.cpu(), gx_ref, rtol=1e-3, atol=1e-4 * max(sc, 1.0))     # cancelling sums at small B
+    close(wg.grad.cpu(), gw_ref, torch.float32, "bn dw")
+    close(bg.grad.cpu(), gb_ref, torch.float32, "bn db")
+    ye = ops.bn1d_eval(xg.detach(), wg.detach(), bg.detach(), rmg, rvg, 1e-5)
+    close(ye.cpu(), F.batch_norm(x.detach(), rm_ref, rv_ref, w, b, False, 0.1, 1e-5), torch.float32, "bn eval")
+
+
+def test_activation_standalone():
+    x = torch.randn(1000)
+    for act, f in (("relu", F.relu), ("sigmoid", torch.sigmoid), ("leaky02", lambda v: F.leaky_relu(v, 0.2))):
+        xr = x.clone().requires_grad_(True)
+        y_ref = f(xr)
+        (g_ref,) = torch.autograd.grad(y_ref, xr, torch.ones_like(x) * 0.7)
+        xg = x.to(DEV).requires_grad_(True)
+        y = ops.Activation.apply(xg, act)
+        y.backward(torch.full_like(y, 0.7))
+        torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(xg.grad.cpu(), g_ref, rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------- losses / sampling
+@pytest.mark.parametrize("n", [1, 48, 4 * 64 * 64 * 64 + 3])
+def test_sse_and_bce(n):
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(n, generator=g).requires_grad_(True)
+    b = torch.rand(n, generator=g)
+    for name, ref_fn, fn in (("sse", lambda p, q: F.mse_loss(p, q, reduction="sum"), ops.sse),
+                             ("bce", lambda p, q: F.binary_cross_entropy(p, q, reduction="sum"), ops.bce_sum)):
+        ref = ref_fn(a, b)
+        (ga_ref,) = torch.autograd.grad(ref * 1.5, a)
+        ag = a.detach().to(DEV).requires_grad_(True)
+        out = fn(ag, b.to(DEV))
+        (out * 1.5).backward()
+        torch.testing.assert_close(out.cpu(), ref.detach(), rtol=2e-5, atol=1e-5, msg=name)
+        torch.testing.assert_close(ag.grad.cpu(), ga_ref, rtol=1e-5, atol=1e-6, msg=name)
+    with pytest.raises(RuntimeError):
+        ops.sse(torch.zeros(3, device=DEV), torch.zeros(4, device=DEV))
+
+
+def test_bce_saturated_probabilities_match_aten_clamps():
+    p = torch.tensor([0.0, 1.0, 1e-30, 1 - 1e-7, 0.5])
+    x = torch.tensor([1.0, 0.0, 1.0, 0.0, 0.3])
+    ref = F.binary_cross_entropy(p, x, reduction="sum")
+    out = ops.bce_sum(p.to(DEV), x.to(DEV))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_reparam_kld_gauss_nll_vessel(golden):
+    g = torch.Generator().manual_seed(10)
+    mu, lv, eps = (torch.randn(16, 64, generator=g).requires_grad_(i < 2) for i in range(3))
+    z_ref = mu + eps * torch.exp(0.5 * lv)
+    kld_ref = -0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp())
+    gz = torch.randn(16, 64, generator=g)
+    gm_ref, gl_ref = torch.autograd.grad((z_ref * gz).sum() + 0.7 * kld_ref, [mu, lv])
+    mug, lvg = mu.detach().to(DEV).requires_grad_(True), lv.detach().to(DEV).requires_grad_(True)
+    z = ops.Reparameterize.apply(mug, lvg, eps.to(DEV))
+    kld = ops.KLD.apply(mug, lvg)
+    ((z * gz.to(DEV)).sum() + 0.7 * kld).backward()
+    torch.testing.assert_close(z.cpu(), z_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(kld.cpu(), kld_ref.detach(), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(mug.grad.cpu(), gm_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lvg.grad.cpu(), gl_ref, rtol=1e-5, atol=1e-5)
+    # vessel recipe against the reference's own loss_function outputs (golden fixture)
+    from causal_vae_amd.vessel import loss_function, total_loss
+    gold = golden("vessel_loss")
+    for tag in ("d10", "d001", "d60"):
+        a = {k: gold.t(f"{tag}/{k}").to(DEV) for k in ("x", "recon_x", "m", "m_mu", "m_logvar", "mu", "logvar")}
+        for k in ("recon_x", "m_mu", "m_logvar", "mu", "logvar"):
+            a[k].requires_grad_(True)
+        recon, kld, morph, sp = loss_function(a["recon_x"], a["x"], a["m_mu"], a["m"], a["mu"], a["logvar"], a["m_mu"], a["m_logvar"])
+        total = total_loss(recon, kld, morph, sp, beta=0.5)
+        total.backward()
+        for k, v in dict(recon=recon, kld=kld, morph=morph, sparsity=sp, total=total).items():
+            gold.check(tag, k, v, rtol=2e-5, atol=1e-3)
+        for k in ("recon_x", "m_mu", "m_logvar", "mu", "logvar"):
+            gold.check(tag, "g_" + k, a[k].grad, rtol=2e-5, atol=1e-5)
+
+
+def test_softmax_ce_and_uniform_kl():
+    g = torch.Generator().manual_seed(11)
+    logits = (torch.randn(37, 10, generator=g) * 3).requires_grad_(True)
+    tgt = torch.randint(0, 10, (37,), generator=g)
+    ce_ref = F.cross_entropy(logits, tgt)
+    kl_ref = F.kl_div(F.log_softmax(logits, 1), torch.full_like(logits, 0.1), reduction="batchmean")
+    g1, = torch.autograd.grad(ce_ref * 2.0, logits, retain_graph=True)
+    g2, = torch.autograd.grad(kl_ref * 1000.0, logits)
+    for fn, ref, gref, scale in ((lambda l: ops.SoftmaxCE.apply(l, tgt.to(DEV)), ce_ref, g1, 2.0), (ops.UniformKL.apply, kl_ref, g2, 1000.0)):
+        lg = logits.detach().to(DEV).requires_grad_(True)
+        out = fn(lg)
+        (out * scale).backward()
+        torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(lg.grad.cpu(), gref, rtol=1e-4, atol=1e-6)
+
+
+def test_philox_normal_statistics_and_determinism():
+    a = ops.philox_normal((1 << 20,), 42, 0, DEV)
+    b = ops.philox_normal((1 << 20,), 42, 0, DEV)
+    c = ops.philox_normal((1 << 20,), 43, 0, DEV)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.var()) - 1.0) < 1e-2
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.1 and torch.isfinite(a).all()
+    odd = ops.philox_normal((7,), 42, 0, DEV)
+    assert torch.equal(odd, a[:7])
+
+
+def test_fused_adam_and_clip_match_torch():
+    g = torch.Generator().manual_seed(12)
+    shapes = [(512, 331), (64,), (32, 1, 4, 4, 4), (5,)]
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    o_ref, o_mine = torch.optim.Adam(ref, lr=1e-3), FusedAdam(mine, lr=1e-3)
+    for step in range(3):
+        for r, m in zip(ref, mine):
+            gr = torch.randn(r.shape, generator=g) * (10.0 if step == 1 else 0.1)
+            r.grad, m.grad = gr.clone(), gr.clone().to(DEV)
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        sq, coef = clip_grad_norm_(mine, 5.0)
+        torch.testing.assert_close(sq.sqrt().cpu(), n_ref, rtol=1e-5, atol=1e-6)
+        for r, m in zip(ref, mine):
+            torch.testing.assert_close(m.grad.cpu(), r.grad, rtol=1e-5, atol=1e-7)
+        o_ref.step(); o_mine.step()
+    for r, m in zip(ref, mine):
+        torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
