@@ -75,7 +75,7 @@ def test_conv_forward_backward(nd, B, Cl, Cs, size, dtype):
     x = rnd(torch.randn(B, Cl, *size, generator=g), dtype).requires_grad_(True)
     w = (torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cl * 4 ** nd)).requires_grad_(True)
     b = torch.randn(Cs, generator=g).requires_grad_(True)
-    wr = rnd(w.detach(), dtype)
+    wr = rnd(w.detach(), dtype) if Cl > 1 else w.detach().clone()     # single-channel layers keep fp32 weights
     y_ref = F.relu(conv(x, wr.requires_grad_(True), b, stride=2, padding=1))
     gy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
     gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, wr, b], gy)
@@ -104,7 +104,7 @@ def test_conv_transpose_forward_backward(nd, B, Cl, Cs, size, dtype):
     x = rnd(torch.randn(B, Cs, *ssize, generator=g), dtype).requires_grad_(True)
     w = (torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cs * 2 ** nd))
     b = torch.randn(Cl, generator=g).requires_grad_(True)
-    wr = rnd(w, dtype).requires_grad_(True)
+    wr = (rnd(w, dtype) if Cl > 1 else w).clone().requires_grad_(True)
     y_ref = convT(x, wr, b, stride=2, padding=1)
     if act:
         y_ref = F.relu(y_ref)
@@ -112,7 +112,7 @@ def test_conv_transpose_forward_backward(nd, B, Cl, Cs, size, dtype):
     gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, wr, b], gy)
 
     xg = to_cl(x.detach(), dtype).requires_grad_(True)
-    wg = w.to(DEV).requires_grad_(True)
+    wg = w.detach().to(DEV).requires_grad_(True)
     bg = b.detach().to(DEV).requires_grad_(True)
     y = ops.ConvUp.apply(xg, wg, bg, nd, act, False, False)
     close(from_cl(y, nd), y_ref.detach(), dtype, "y")
