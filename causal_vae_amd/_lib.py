@@ -85,6 +85,36 @@ for _name, _args in SIGNATURES.items():
     _fn.restype = _RESTYPE.get(_name, _i)
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual C-ABI launches (bench.py's roofline leg).  Events are recorded on torch's
+    current stream — the stream the kernels are enqueued on — and only read after a device sync, so timing adds no sync."""
+
+    def __init__(self):
+        self.events = {}
+
+    def run(self, name, fn, *args):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        self.events.setdefault(name, []).append((s, e))
+        return rc
+
+    def summary(self):
+        """name -> (launches, mean milliseconds).  Call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+TIMER = None          # set to a KernelTimer to time conv launches
+
+
+def timed(name, fn, *args):
+    if TIMER is None:
+        return fn(*args)
+    return TIMER.run(name, fn, *args)
+
+
 def strerror(code):
     return lib.cvae_strerror(code).decode()
 

@@ -164,8 +164,8 @@ def _conv_down(Lt, wp, bias, mask, Cs, nd, act):
     B, ld, lh, lw, Cl = _cl_dims(Lt)
     sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
     S = _empty((B, sd, sh, sw, Cs), Lt.dtype, Lt)
-    check(lib.cvae_conv_down(ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd,
-                             L.dtype_code(Lt.dtype), L.act_code(act), stream()), "conv_down")
+    check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down, ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S),
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(Lt.dtype), L.act_code(act), stream()), "conv_down")
     return S
 
 
@@ -173,8 +173,8 @@ def _conv_up(St, wp, bias, mask, Cl, nd, act):
     B, sd, sh, sw, Cs = _cl_dims(St)
     ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
     Lt = _empty((B, ld, lh, lw, Cl), St.dtype, St)
-    check(lib.cvae_conv_up(ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd,
-                           L.dtype_code(St.dtype), L.act_code(act), stream()), "conv_up")
+    check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up, ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt),
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), L.act_code(act), stream()), "conv_up")
     return Lt
 
 
@@ -184,8 +184,8 @@ def _conv_wgrad(St, Lt, nd, wshape):
     dW = torch.empty(wshape, dtype=torch.float32, device=St.device)
     nbytes = lib.cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=St.device)
-    check(lib.cvae_conv_wgrad(ptr(St), ptr(Lt), ptr(dW), ptr(ws), nbytes, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd,
-                              L.dtype_code(St.dtype), stream()), "conv_wgrad")
+    check(L.timed(f"conv_wgrad nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L{Cl}", lib.cvae_conv_wgrad, ptr(St), ptr(Lt), ptr(dW), ptr(ws), nbytes,
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), stream()), "conv_wgrad")
     return dW
 
 
