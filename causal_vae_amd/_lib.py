@@ -42,7 +42,7 @@ SIGNATURES = {
     "cvae_conv_down": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p],
     "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p],
     "cvae_conv_wgrad_workspace_bytes": [_i64, _i64, _i],
-    "cvae_conv_wgrad": [_p, _p, _p, _p, _sz] + [_i64] * 9 + [_i, _i, _p],
+    "cvae_conv_wgrad": [_p, _p, _p, _p, _p, _sz] + [_i64] * 9 + [_i, _i, _p],
     "cvae_channel_sum": [_p, _p, _i64, _i64, _i, _p],
     "cvae_act_fwd": [_p, _p, _i64, _i, _i, _p],
     "cvae_act_bwd": [_p, _p, _p, _i64, _i, _i, _p],
@@ -73,6 +73,8 @@ SIGNATURES = {
     "cvae_uniform_kl_fwd": [_p, _p, _i64, _i64, _p],
     "cvae_uniform_kl_bwd": [_p, _p, _p, _i64, _i64, _p],
     "cvae_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
+    "cvae_adam_multi": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p],
+    "cvae_counter_add": [_p, _i, _p],
     "cvae_sqnorm": [_p, _p, _i64, _p],
     "cvae_scale": [_p, _i64, _p, _p],
     "cvae_clip_coef": [_p, _p, _f, _p],

@@ -13,61 +13,102 @@ template <> struct TileC1<3> { static constexpr int TD = 4, TH = 8, TW = 8; };
 template <> struct TileC1<2> { static constexpr int TD = 1, TH = 16, TW = 16; };
 
 // -------------------------------------------------------------------------------------- down, Cl == 1
+// S[pos][cs] = act(bias + sum_tap L[2 pos - 1 + k] W[cs][tap]) as a [256 positions x 64 taps] x [64 taps x 32 cs] MFMA product per
+// workgroup: the A fragments are gathered straight out of the 1-channel halo tile in LDS (im2col is never written), the
+// whole weight lives in registers as B fragments for the lifetime of the workgroup.  What remains is streaming:
+// ~6.5 KB of halo in, 16 KB of outputs out per tile.
+template <typename T> struct C1Ops;
+template <> struct C1Ops<bf16> {
+    // k-block = one depth tap (16 taps = kh x kw); lane (r, h) holds k = 8h + j  <->  kh = 2h + (j >> 2), kw = j & 3
+    static constexpr int KB_TAPS = 16;
+    struct BFrag { bf16x8 v; };
+    static __device__ __forceinline__ void load_b(BFrag& f, const float* wrow, int kb, int h) {       // wrow = W[cs = r][.]
+        const float4 a = *(const float4*)(wrow + kb * 16 + 8 * h), b = *(const float4*)(wrow + kb * 16 + 8 * h + 4);
+        f.v[0] = (bf16)a.x; f.v[1] = (bf16)a.y; f.v[2] = (bf16)a.z; f.v[3] = (bf16)a.w;
+        f.v[4] = (bf16)b.x; f.v[5] = (bf16)b.y; f.v[6] = (bf16)b.z; f.v[7] = (bf16)b.w;
+    }
+    template <int IW>
+    static __device__ __forceinline__ void mma_block(f32x16& acc, const bf16* halo, int pb, int h, const BFrag& bfr) {
+        // two rows (kh = 2h, 2h+1) of 4 consecutive bf16: 8-byte groups at 4-byte alignment -> 2 x ds_read_b32 each
+        const uint32_t* p0 = (const uint32_t*)(halo + pb + (2 * h) * IW);
+        const uint32_t* p1 = (const uint32_t*)(halo + pb + (2 * h + 1) * IW);
+        union { uint32_t u[4]; bf16x8 v; } a;
+        a.u[0] = p0[0]; a.u[1] = p0[1]; a.u[2] = p1[0]; a.u[3] = p1[1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bfr.v, acc, 0, 0, 0);
+    }
+};
+template <> struct C1Ops<float> {
+    // fp32: 32x32x2 MFMA, lane (r, h) feeds tap 2s + h at step s; a k-block is again 16 taps = 8 steps
+    static constexpr int KB_TAPS = 16;
+    struct BFrag { float v[8]; };
+    static __device__ __forceinline__ void load_b(BFrag& f, const float* wrow, int kb, int h) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) f.v[s] = wrow[kb * 16 + 2 * s + h];
+    }
+    template <int IW>
+    static __device__ __forceinline__ void mma_block(f32x16& acc, const float* halo, int pb, int h, const BFrag& bfr) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {                     // tap (within the block) = 2s + h: kh = s >> 1, kw = 2 (s & 1) + h
+            const float a = halo[pb + (s >> 1) * IW + 2 * (s & 1) + h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr.v[s], acc, 0, 0, 0);
+        }
+    }
+};
+
 template <typename T, int ND, int CS>
 __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, const float* __restrict__ w, const float* __restrict__ bias,
                                                       const T* __restrict__ mask, T* __restrict__ S, int sd, int sh, int sw, int ld, int lh, int lw,
                                                       int tiles_h, int tiles_w, int act) {
+    static_assert(CS == 32, "one 32-wide N sub-tile");
     using TL = TileC1<ND>;
+    using OP = C1Ops<T>;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
     constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, IW = 2 * TW + 2;
-    constexpr int NPOS = ID * IH * IW, TAPS = (ND == 3) ? 64 : 16, CH = CS / 2;
-    __shared__ float halo[NPOS];
-    __shared__ __attribute__((aligned(16))) float wl[TAPS * CS];      // [tap][cs]
-    const int t = threadIdx.x, b = blockIdx.z;
+    constexpr int NPOS = ID * IH * IW, TAPS = (ND == 3) ? 64 : 16, NKB = TAPS / 16;
+    constexpr int HN = (NPOS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) T halo[NPOS + 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5, b = blockIdx.z;
     int tile = blockIdx.x;
     const int tw_i = tile % tiles_w; tile /= tiles_w;
     const int th_i = tile % tiles_h; tile /= tiles_h;
     const int o0d = tile * TD, o0h = th_i * TH, o0w = tw_i * TW;
-    for (int i = t; i < TAPS * CS; i += 256) { const int tap = i / CS, cs = i % CS; wl[i] = w[cs * TAPS + tap]; }
-    for (int pos = t; pos < NPOS; pos += 256) {
+    // ---- all halo loads in flight at once, weights into B fragments meanwhile ----
+    T hv[HN];
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+        const int pos = t + i * 256;
         const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
         const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - 1 + x;
-        const bool ok = gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
-        halo[pos] = ok ? to_f32(L[(((size_t)b * ld + gz) * lh + gy) * lw + gx]) : 0.f;
+        const bool ok = pos < NPOS && gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
+        hv[i] = ok ? L[(((size_t)b * ld + gz) * lh + gy) * lw + gx] : from_f32<T>(0.f);
     }
+    typename OP::BFrag bfr[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) OP::load_b(bfr[kb], w + (size_t)r * TAPS, kb, h);
+    const float bv = bias ? bias[r] : 0.f;
+#pragma unroll
+    for (int i = 0; i < HN; ++i) if (t + i * 256 < NPOS) halo[t + i * 256] = hv[i];
     __syncthreads();
-    const int half = t & 1, pp = t >> 1;
-    const int m0 = 2 * pp;                                  // two adjacent-w positions per thread
-    const int w0 = m0 % TW, hh = m0 / TW % TH, d = m0 / (TW * TH);
-    const int pb = ((2 * d) * IH + 2 * hh) * IW + 2 * w0;
-    float acc0[CH], acc1[CH];
+    // ---- each wave: 2 sub-tiles of 32 positions ----
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
-#pragma unroll 4
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const int kd = (ND == 3) ? (tap >> 4) : 0, kh = (tap >> 2) & 3, kw = tap & 3;
-        const int off = (kd * IH + kh) * IW + kw;
-        const float v0 = halo[pb + off], v1 = halo[pb + off + 2];
-        const float4* wr = (const float4*)&wl[tap * CS + half * CH];
+    for (int ms = 0; ms < 2; ++ms) {
+        const int m = (wave * 2 + ms) * 32 + r;
+        const int w0 = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+        const int pb = ((2 * d) * IH + 2 * hh) * IW + 2 * w0;
+        f32x16 acc;
 #pragma unroll
-        for (int c4 = 0; c4 < CH / 4; ++c4) {
-            const float4 ww = wr[c4];
-            acc0[4 * c4 + 0] += v0 * ww.x; acc0[4 * c4 + 1] += v0 * ww.y; acc0[4 * c4 + 2] += v0 * ww.z; acc0[4 * c4 + 3] += v0 * ww.w;
-            acc1[4 * c4 + 0] += v1 * ww.x; acc1[4 * c4 + 1] += v1 * ww.y; acc1[4 * c4 + 2] += v1 * ww.z; acc1[4 * c4 + 3] += v1 * ww.w;
-        }
-    }
-    const int od = o0d + d, oh = o0h + hh;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int ow = o0w + w0 + q;
-        if (od >= sd || oh >= sh || ow >= sw) continue;
-        const size_t base = ((((size_t)b * sd + od) * sh + oh) * sw + ow) * CS + half * CH;
+        for (int kb = 0; kb < NKB; ++kb) OP::template mma_block<IW>(acc, halo, pb + kb * IH * IW, h, bfr[kb]);
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            float v = (q ? acc1[c] : acc0[c]) + (bias ? bias[half * CH + c] : 0.f);
-            v = apply_act(v, act);
-            if (mask && !(to_f32(mask[base + c]) > 0.f)) v = 0.f;
-            S[base + c] = from_f32<T>(v);
+        for (int e = 0; e < 16; ++e) {
+            const int mo = (wave * 2 + ms) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int ow = o0w + mo % TW, oh = o0h + mo / TW % TH, od = o0d + mo / (TW * TH);
+            if (od >= sd || oh >= sh || ow >= sw) continue;
+            const size_t idx = ((((size_t)b * sd + od) * sh + oh) * sw + ow) * CS + r;
+            float v = apply_act(acc[e] + bv, act);
+            if (mask && !(to_f32(mask[idx]) > 0.f)) v = 0.f;
+            S[idx] = from_f32<T>(v);
         }
     }
 }
@@ -123,73 +164,161 @@ __global__ __launch_bounds__(256) void up_c1_kernel(const T* __restrict__ S, con
 }
 
 // -------------------------------------------------------------------------------------- wgrad, Cl == 1
+// dW[cs][tap] = sum_pos S[pos][cs] * L[2 pos - 1 + k(tap)]  ==  S^T [32 x K] . im2col(L) [K x taps],  K = positions.
+//   bf16: A fragments (S^T) by the transposing LDS read; B fragments gathered from the 1-channel halo (8 stride-2
+//         elements per lane); v_mfma_f32_32x32x16_bf16.  A third accumulator S^T . ones yields the bias gradient.
+//   fp32: v_mfma_f32_32x32x2_f32, one element per lane per operand.
+// Each workgroup walks `total / n_split` tiles of 128 positions and leaves with fp32 atomics directly in [Cs][1][taps].
 template <typename T, int ND>
-__global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ dW, int B, int sd, int sh, int sw,
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, bool want_bias, int B, int sd, int sh, int sw,
                                                        int Cs, int ld, int lh, int lw, int tiles_d, int tiles_h, int tiles_w, int n_split) {
     constexpr int TD = (ND == 3) ? 4 : 1, TH = (ND == 3) ? 4 : 8, TW = (ND == 3) ? 8 : 16;     // 128 positions
     constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, IW = 2 * TW + 2, NPOS = ID * IH * IW;
     constexpr int TAPS = (ND == 3) ? 64 : 16, NTS = (TAPS + 31) / 32;
-    __shared__ float s_lds[128 * 32];
-    __shared__ float l_lds[NPOS];
+    constexpr int NU = (8 * sizeof(T)) / 16, HN = (NPOS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) T s_lds[128 * 32];
+    __shared__ __attribute__((aligned(16))) T l_lds[NPOS + 8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hk = lane >> 5;
     const int cs0 = blockIdx.y * 32;
     const int total = B * tiles_d * tiles_h * tiles_w;
-    f32x16 acc[NTS];
+    f32x16 acc[NTS], accb;
 #pragma unroll
     for (int s = 0; s < NTS; ++s)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
-    // per-lane tap offsets inside the halo tile (tap = ts*32 + r)
-    int toff[NTS]; bool tvalid[NTS];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+    int toff[NTS]; bool tvalid[NTS];                        // per-lane tap offsets inside the halo tile (tap = ts*32 + r)
 #pragma unroll
     for (int s = 0; s < NTS; ++s) {
         const int tap = s * 32 + r;
         tvalid[s] = tap < TAPS;
         const int kd = (ND == 3) ? (tap >> 4) & 3 : 0, kh = (tap >> 2) & 3, kw = tap & 3;
-        toff[s] = (kd * IH + kh) * IW + kw;
+        toff[s] = tvalid[s] ? (kd * IH + kh) * IW + kw : 0;
     }
-    for (int tile = blockIdx.x; tile < total; tile += n_split) {
+    // Software pipeline over the workgroup's tiles: the global loads of tile i+1 are in flight (in registers) while tile i
+    // is consumed from LDS, so the HBM latency hides under the barriers, LDS traffic and MFMAs of the previous tile.
+    uint4 sv[2][NU];
+    T hv[HN];
+    auto issue = [&](int tile) {
         int tt = tile;
         const int tw_i = tt % tiles_w; tt /= tiles_w;
         const int th_i = tt % tiles_h; tt /= tiles_h;
         const int td_i = tt % tiles_d;
         const int b = tt / tiles_d;
         const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
-        __syncthreads();
-        for (int it = t; it < 128 * 32; it += 256) {
-            const int c = it & 31, m = it >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int it = t + i * 256, piece = it & 3, m = it >> 2;
             const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
             const int od = o0d + d, oh = o0h + hh, ow = o0w + w;
             const bool ok = od < sd && oh < sh && ow < sw;
-            s_lds[it] = ok ? to_f32(S[((((size_t)b * sd + od) * sh + oh) * sw + ow) * Cs + cs0 + c]) : 0.f;
+            const T* src = S + (ok ? ((((size_t)b * sd + od) * sh + oh) * sw + ow) * Cs + cs0 + piece * 8 : 0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) sv[i][u] = ok ? ((const uint4*)src)[u] : make_uint4(0, 0, 0, 0);
         }
-        for (int pos = t; pos < NPOS; pos += 256) {
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int pos = t + i * 256;
             const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
             const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - 1 + x;
-            const bool ok = gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
-            l_lds[pos] = ok ? to_f32(L[(((size_t)b * ld + gz) * lh + gy) * lw + gx]) : 0.f;
+            const bool ok = pos < NPOS && gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
+            hv[i] = ok ? L[(((size_t)b * ld + gz) * lh + gy) * lw + gx] : from_f32<T>(0.f);
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int jj = 0; jj < 16; ++jj) {
-            const int m = wave * 32 + 2 * jj + hk;
-            const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
-            const int pb = ((2 * d) * IH + 2 * hh) * IW + 2 * w;
-            const float a = s_lds[m * 32 + r];
+    };
+    if ((int)blockIdx.x < total) issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < total; tile += n_split) {
+        __syncthreads();                                    // the previous tile's readers are done with LDS
 #pragma unroll
-            for (int s = 0; s < NTS; ++s) {
-                const float bv = tvalid[s] ? l_lds[pb + toff[s]] : 0.f;
-                acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[s], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            const int it = t + i * 256;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) ((uint4*)(s_lds + it * 8))[u] = sv[i][u];       // row-major [pos][32 cs], 16-byte stores
+        }
+#pragma unroll
+        for (int i = 0; i < HN; ++i) if (t + i * 256 < NPOS) l_lds[t + i * 256] = hv[i];
+        __syncthreads();
+        if (tile + n_split < total) issue(tile + n_split);
+        if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3, colblk = gq & 1;     // gq >> 1 == hk
+            bf16x8 ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int m0 = (wave * 2 + c) * 16 + 8 * hk;                                // 8 consecutive-w positions m0 .. m0+7
+                bf16x8 a;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s_lds + (m0 + 4 * jj + q) * 32 + 16 * colblk + 4 * p));
+                    a[4 * jj + 0] = v[0]; a[4 * jj + 1] = v[1]; a[4 * jj + 2] = v[2]; a[4 * jj + 3] = v[3];
+                }
+                if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);
+                const int w = m0 % TW, hh = m0 / TW % TH, d = m0 / (TW * TH);
+                const int pb = ((2 * d) * IH + 2 * hh) * IW + 2 * w;
+#pragma unroll
+                for (int s = 0; s < NTS; ++s) {
+                    bf16x8 bv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[j] = tvalid[s] ? l_lds[pb + toff[s] + 2 * j] : (bf16)0.0f;
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[s], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int jj = 0; jj < 16; ++jj) {
+                const int m = wave * 32 + 2 * jj + hk;
+                const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+                const int pb = ((2 * d) * IH + 2 * hh) * IW + 2 * w;
+                const float a = s_lds[m * 32 + r];
+                if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, accb, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < NTS; ++s) {
+                    const float bv = tvalid[s] ? l_lds[pb + toff[s]] : 0.f;
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[s], 0, 0, 0);
+                }
             }
         }
     }
+    // ---- the 4 waves hold partial sums over different positions: combine them in LDS and store ONE partial slab per
+    // workgroup with plain stores; wgrad_c1_finish sums the slabs (no atomics: fp32 atomics of hundreds of workgroups onto
+    // the same 8 KB run at ~1/14 of the spread-out rate, MI355X_MICROARCH.md "Global float atomics") ----
+    constexpr int RW = NTS * 32 + 1;
+    __shared__ float red[4][32 * RW];
 #pragma unroll
     for (int s = 0; s < NTS; ++s)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * hk, tap = s * 32 + r;
-            if (tap < TAPS) atomicAdd(&dW[(size_t)(cs0 + row) * TAPS + tap], acc[s][e]);
-        }
+        for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * hk) * RW + s * 32 + r] = acc[s][e];
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * hk) * RW + NTS * 32] = accb[e];
+    }
+    __syncthreads();
+    float* slab = ws + ((size_t)blockIdx.y * n_split + blockIdx.x) * (32 * RW);
+    for (int i = t; i < 32 * RW; i += 256) slab[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+// Sum the per-workgroup slabs: block (x, y, z) adds 64 slabs (z-th group) for 64 outputs, then one atomic per output
+// (n_split/64 <= 16 adders per address).  dW / dbias are zeroed by the launcher.
+template <int ND>
+__global__ void wgrad_c1_finish_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias, int n_split) {
+    constexpr int TAPS = (ND == 3) ? 64 : 16, NTS = (TAPS + 31) / 32, RW = NTS * 32 + 1;
+    __shared__ float part[4][64];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const float* base = ws + (size_t)blockIdx.y * n_split * (32 * RW);
+    const int x0 = blockIdx.z * 64, x1 = min(n_split, x0 + 64);
+    float acc = 0.f;
+    if (o < 32 * RW)
+        for (int x = x0 + q; x < x1; x += 4) acc += base[(size_t)x * (32 * RW) + o];
+    part[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && o < 32 * RW) {
+        const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        const int row = o / RW, col = o % RW, cs = blockIdx.y * 32 + row;
+        if (col == NTS * 32) { if (dbias) atomicAdd(&dbias[cs], v); }
+        else if (col < TAPS) atomicAdd(&dW[(size_t)cs * TAPS + col], v);
+    }
 }
 
 }  // namespace
@@ -225,24 +354,37 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
     return CVAE_OK;
 }
 
-int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                       int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream) {
-    if (Cs % 32) return CVAE_E_UNSUPPORTED;
-    const int taps = (nd == 3) ? 64 : 16;
-    if (hipMemsetAsync(dW, 0, (size_t)Cs * taps * sizeof(float), stream) != hipSuccess) return CVAE_E_LAUNCH;
+size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd) {
+    const int rw = ((nd == 3) ? 64 : 32) + 1;
+    return (size_t)1024 * 32 * rw * sizeof(float);           // (Cs/32) * n_split <= 1024 slabs of [32][rw]
+}
+
+int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
+                       int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream) {
+    if (Cs % 32 || Cs > 1024 * 32) return CVAE_E_UNSUPPORTED;
+    if (!workspace) return CVAE_E_NULLPTR;
+    if (workspace_bytes < cvae_conv_wgrad_c1_workspace_bytes(Cs, nd)) return CVAE_E_WORKSPACE;
     const int td = (nd == 3) ? 4 : 1, th = (nd == 3) ? 4 : 8, tw = (nd == 3) ? 8 : 16;
     const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
     const long long total = (long long)B * tiles_d * tiles_h * tiles_w;
-    long long n_split = 1024 / (Cs / 32);
+    long long n_split = 1024 / (Cs / 32);                   // ~4 workgroups per CU; slabs leave with plain stores
     if (n_split > total) n_split = total;
     if (n_split < 1) n_split = 1;
     dim3 grid((unsigned)n_split, (unsigned)(Cs / 32), 1);
+    float* ws = (float*)workspace;
 #define LAUNCH_WG_C1(T, ND)                                                                                                           \
-    hipLaunchKernelGGL((wgrad_c1_kernel<T, ND>), grid, dim3(256), 0, stream, (const T*)S, (const T*)L, dW, (int)B, (int)sd, (int)sh, (int)sw, \
-                       (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split)
+    hipLaunchKernelGGL((wgrad_c1_kernel<T, ND>), grid, dim3(256), 0, stream, (const T*)S, (const T*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
+                       (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split)
     if (dtype == CVAE_BF16) { if (nd == 3) LAUNCH_WG_C1(bf16, 3); else LAUNCH_WG_C1(bf16, 2); }
     else { if (nd == 3) LAUNCH_WG_C1(float, 3); else LAUNCH_WG_C1(float, 2); }
 #undef LAUNCH_WG_C1
+    CVAE_CHECK_LAUNCH();
+    const int rw = ((nd == 3) ? 64 : 32) + 1, taps = (nd == 3) ? 64 : 16;
+    if (hipMemsetAsync(dW, 0, (size_t)Cs * taps * sizeof(float), stream) != hipSuccess) return CVAE_E_LAUNCH;
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cs * sizeof(float), stream) != hipSuccess) return CVAE_E_LAUNCH;
+    dim3 fgrid((unsigned)((32 * rw + 63) / 64), (unsigned)(Cs / 32), (unsigned)((n_split + 63) / 64));
+    if (nd == 3) hipLaunchKernelGGL(wgrad_c1_finish_kernel<3>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split);
+    else hipLaunchKernelGGL(wgrad_c1_finish_kernel<2>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

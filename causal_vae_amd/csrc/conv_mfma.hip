@@ -55,19 +55,31 @@ template <> struct Tile<3, 256> { static constexpr int TD = 4, TH = 8, TW = 8; }
 template <> struct Tile<2, 128> { static constexpr int TD = 1, TH = 8, TW = 16; };
 template <> struct Tile<2, 256> { static constexpr int TD = 1, TH = 16, TW = 16; };
 
-// copy one 8-element fragment piece global -> LDS (zero if !ok)
+// One 8-element fragment piece (16 B bf16 / 32 B fp32) in flight between a global load and its LDS store.  Staging
+// is always written as "issue ALL loads of a tile, then store them": the loads overlap each other (and, for the weight
+// panels, the MFMA work placed between the two halves) instead of paying one memory latency per piece.
+template <typename T> struct Piece { uint4 v[(8 * sizeof(T)) / 16]; };
 template <typename T>
-__device__ __forceinline__ void stage_piece(char* dst, const T* src, bool ok) {
-    constexpr int NU = (8 * sizeof(T)) / 16;
-    uint4 v[NU];
+__device__ __forceinline__ void piece_load(Piece<T>& p, const T* src, bool ok) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) v[u] = ok ? ((const uint4*)src)[u] : make_uint4(0, 0, 0, 0);
+    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) p.v[u] = ok ? ((const uint4*)src)[u] : make_uint4(0, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ void piece_store(const Piece<T>& p, char* dst) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) ((uint4*)dst)[u] = v[u];
+    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) ((uint4*)dst)[u] = p.v[u];
+}
+
+// XCD-aware block -> tile map (cdna_hip_programming.md T1, bijective form): blocks b and b+8 share an XCD (and its L2),
+// so each XCD gets a contiguous run of spatially adjacent tiles whose halos overlap.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
 // ---------------------------------------------------------------------------------------------- down / up
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
+// EPI: 0 = bias only, 1 = bias + ReLU, 2 = generic activation code
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                   const T* __restrict__ mask, T* __restrict__ out, ConvGeom g, int act) {
     constexpr int NT = WM * WN * 64;
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     const int nb = blockIdx.y % nblocks, par = blockIdx.y / nblocks;    // par: output parity class (UP only)
     const int prd = (UP && ND == 3) ? ((par >> 2) & 1) : 0, prh = UP ? ((par >> 1) & 1) : 0, prw = UP ? (par & 1) : 0;
     const int n0 = nb * BN;
-    int tile = blockIdx.x;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
     const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
     const int td_i = tile;
@@ -137,32 +149,57 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
         const int kd = (ND == 3) ? (3 - prd - 2 * a) : 0, kh = 3 - prh - 2 * bb, kw = 3 - prw - 2 * c;
         return (kd * 4 + kh) * 4 + kw;
     };
-    auto stage_b = [&](int chunk, int grp, int buf) {
-        char* dstb = bt + buf * BT_BYTES;
-        for (int it = t; it < 4 * 2 * BN; it += NT) {
-            const int half = it & 1, n = (it >> 1) % BN, j = it / (2 * BN);
+    // ---- halo staging plan: the (position, half) pieces this thread moves are the same for every channel chunk ----
+    constexpr int HN = (NPOS * 2 + NT - 1) / NT;
+    int hoff[HN];                                          // element offset of the piece at chunk 0, or -1 (zero fill)
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+        const int it = t + i * NT, half = it & 1, pos = it >> 1;
+        const int x = pos % IW, y = (pos / IW) % IH, z = pos / (IW * IH);
+        const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
+        const bool ok = (it < NPOS * 2) && (gz >= 0) && (gz < in_d) && (gy >= 0) && (gy < in_h) && (gx >= 0) && (gx < in_w);
+        hoff[i] = ok ? (((gz * in_h + gy) * in_w + gx) * Cin + 8 * half) : -1;
+    }
+    const T* in_b = in + (size_t)b * in_d * in_h * in_w * Cin;
+    constexpr int BP = (4 * 2 * BN) / NT;                  // weight pieces per thread per tap group
+    static_assert((4 * 2 * BN) % NT == 0, "weight panel must divide evenly over the workgroup");
+    auto load_b = [&](Piece<T> (&pb)[BP], int chunk, int grp) {
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int it = t + i * NT, half = it & 1, n = (it >> 1) % BN, j = it / (2 * BN);
             const int wt = tap_weight_idx(grp, j);
-            const T* src = wp + (((size_t)wt * nchunks + chunk) * Cout + n0 + n) * 16 + 8 * half;
-            stage_piece<T>(dstb + ((j * 2 + half) * BN + n) * FB, src, true);
+            piece_load<T>(pb[i], wp + (((size_t)wt * nchunks + chunk) * Cout + n0 + n) * 16 + 8 * half, true);
+        }
+    };
+    auto store_b = [&](const Piece<T> (&pb)[BP], int buf) {
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int it = t + i * NT, half = it & 1, n = (it >> 1) % BN, j = it / (2 * BN);
+            piece_store<T>(pb[i], bt + buf * BT_BYTES + ((j * 2 + half) * BN + n) * FB);
         }
     };
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();                                   // previous chunk's readers are done with halo + B buffers
-        for (int it = t; it < NPOS * 2; it += NT) {
-            const int half = it & 1, pos = it >> 1;
-            const int x = pos % IW, y = (pos / IW) % IH, z = pos / (IW * IH);
-            const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
-            const bool ok = (gz >= 0) && (gz < in_d) && (gy >= 0) && (gy < in_h) && (gx >= 0) && (gx < in_w);
-            const T* src = in + ((((size_t)b * in_d + gz) * in_h + gy) * in_w + gx) * Cin + chunk * 16 + 8 * half;
-            stage_piece<T>(halo + ((size_t)half * NPOS + pos) * FB, src, ok);
+        {
+            Piece<T> hp[HN], pb0[BP];
+#pragma unroll
+            for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * 16, hoff[i] >= 0);
+            load_b(pb0, chunk, 0);
+            __syncthreads();                               // previous chunk's readers are done with halo + B buffers
+#pragma unroll
+            for (int i = 0; i < HN; ++i) {
+                const int it = t + i * NT;
+                if (it < NPOS * 2) piece_store<T>(hp[i], halo + ((size_t)(it & 1) * NPOS + (it >> 1)) * FB);
+            }
+            store_b(pb0, 0);
         }
-        stage_b(chunk, 0, 0);
         __syncthreads();
 #pragma unroll 1
         for (int grp = 0; grp < NG; ++grp) {
             const int buf = grp & 1;
-            if (grp + 1 < NG) stage_b(chunk, grp + 1, buf ^ 1);
+            Piece<T> pbn[BP];
+            const bool more = grp + 1 < NG;
+            if (more) load_b(pbn, chunk, grp + 1);         // issue next panel's loads; they land while the MFMAs run
             const char* btb = bt + buf * BT_BYTES;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -177,12 +214,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], a[mi], bf[ni]);
             }
+            if (more) store_b(pbn, buf ^ 1);               // the other buffer was last read before the previous barrier
             __syncthreads();
         }
     }
 
     // ---- epilogue.  32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
     const int out_d = UP ? g.ld : g.sd, out_h = UP ? g.lh : g.sh, out_w = UP ? g.lw : g.sw;
+    float bv[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bv[ni] = bias ? bias[n0 + (wn * NI + ni) * 32 + r] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -197,16 +238,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int c = n0 + (wn * NI + ni) * 32 + r;
-                float v = acc[mi][ni][e] + (bias ? bias[c] : 0.f);
-                v = apply_act(v, act);
+                float v = acc[mi][ni][e] + bv[ni];
+                if (EPI == 1) v = fmaxf(v, 0.f);
+                else if (EPI == 2) v = apply_act(v, act);
                 if (mask && !(to_f32(mask[pidx + c]) > 0.f)) v = 0.f;
                 out[pidx + c] = from_f32<T>(v);
             }
         }
 }
 
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
-int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream) {
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI>
+int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
     constexpr int ID = (ND == 3) ? (UP ? TL::TD + 2 : 2 * TL::TD + 2) : 1;
@@ -214,7 +256,7 @@ int launch_data(const void* in, const void* wp, const float* bias, const void* m
     constexpr int FB = 8 * sizeof(T);
     constexpr size_t LDS = (size_t)2 * ID * IH * IW * FB + (size_t)2 * 4 * 2 * BN * FB;
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
-    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI>;
+    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
@@ -230,6 +272,13 @@ int launch_data(const void* in, const void* wp, const float* bias, const void* m
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const T*)mask, (T*)out, g, act);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
+}
+
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
+int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream) {
+    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0>(in, wp, bias, mask, out, g, act, stream);
+    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1>(in, wp, bias, mask, out, g, act, stream);
+    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2>(in, wp, bias, mask, out, g, act, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -250,7 +299,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 // ---------------------------------------------------------------------------------------------- wgrad
 // Workgroup: 4 waves; block of 64 cs x 32 cl; one depth tap kd (3D) / all taps (2D); wave w owns kh = w, kw = 0..3.
 template <typename T, int ND>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split) {
     using TL = Tile<ND, 128>;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
     constexpr int IH = 2 * TH + 2, IW = 2 * TW + 2;          // L tile: TD planes (one kd) x IH x IW positions x 32 cl
@@ -281,24 +330,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ S
         const int td_i = tt % g.tiles_d;
         const int b = tt / g.tiles_d;
         const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
-        __syncthreads();
-        // S tile: 128 positions x 64 channels
-        for (int it = t; it < 128 * 8; it += 256) {
-            const int piece = it & 7, m = it >> 3;
+        // S tile: 128 positions x 64 channels; L tile: planes lz = 2 (o0d + d) - 1 + kd, rows 2 o0h - 1 + y, cols 2 o0w - 1 + x.
+        // All loads are issued before the barrier that retires the previous tile's readers, then stored.
+        constexpr int SN = (128 * 8) / 256, LNPOS = TD * IH * IW, LN = (LNPOS * 4 + 255) / 256;
+        Piece<T> sp[SN], lp[LN];
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+            const int it = t + i * 256, piece = it & 7, m = it >> 3;
             const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
             const int od = o0d + d, oh = o0h + hh, ow = o0w + w;
             const bool ok = od < g.sd && oh < g.sh && ow < g.sw;
-            const T* src = S + ((((size_t)b * g.sd + od) * g.sh + oh) * g.sw + ow) * g.Cs + cs0 + piece * 8;
-            stage_piece<T>(s_lds + m * SROW + piece * 8 * sizeof(T), src, ok);
+            piece_load<T>(sp[i], S + (ok ? ((((size_t)b * g.sd + od) * g.sh + oh) * g.sw + ow) * g.Cs + cs0 + piece * 8 : 0), ok);
         }
-        // L tile: planes lz = 2 (o0d + d) - 1 + kd, rows 2 o0h - 1 + y, cols 2 o0w - 1 + x
-        for (int it = t; it < TD * IH * IW * 4; it += 256) {
-            const int piece = it & 3, pos = it >> 2;
+#pragma unroll
+        for (int i = 0; i < LN; ++i) {
+            const int it = t + i * 256, piece = it & 3, pos = it >> 2;
             const int x = pos % IW, y = pos / IW % IH, d = pos / (IW * IH);
             const int lz = (ND == 3) ? 2 * (o0d + d) - 1 + kd : 0, ly = 2 * o0h - 1 + y, lx = 2 * o0w - 1 + x;
-            const bool ok = lz >= 0 && lz < g.ld && ly >= 0 && ly < g.lh && lx >= 0 && lx < g.lw;
-            const T* src = L + ((((size_t)b * g.ld + lz) * g.lh + ly) * g.lw + lx) * g.Cl + cl0 + piece * 8;
-            stage_piece<T>(l_lds + pos * LROW + piece * 8 * sizeof(T), src, ok);
+            const bool ok = it < LNPOS * 4 && lz >= 0 && lz < g.ld && ly >= 0 && ly < g.lh && lx >= 0 && lx < g.lw;
+            piece_load<T>(lp[i], L + (ok ? ((((size_t)b * g.ld + lz) * g.lh + ly) * g.lw + lx) * g.Cl + cl0 + piece * 8 : 0), ok);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+            const int it = t + i * 256;
+            piece_store<T>(sp[i], s_lds + (it >> 3) * SROW + (it & 7) * 8 * sizeof(T));
+        }
+#pragma unroll
+        for (int i = 0; i < LN; ++i) {
+            const int it = t + i * 256;
+            if (it < LNPOS * 4) piece_store<T>(lp[i], l_lds + (it >> 2) * LROW + (it & 3) * 8 * sizeof(T));
         }
         __syncthreads();
         if constexpr (sizeof(T) == 2) {
@@ -394,7 +455,7 @@ int launch_wgrad(const void* S, const void* L, float* ws, ConvGeom g, hipStream_
     g.tiles_d = (g.sd + TL::TD - 1) / TL::TD; g.tiles_h = (g.sh + TL::TH - 1) / TL::TH; g.tiles_w = (g.sw + TL::TW - 1) / TL::TW;
     const long long total_tiles = (long long)g.B * g.tiles_d * g.tiles_h * g.tiles_w;
     const int cb = (g.Cs / 64) * (g.Cl / 32), tg = (ND == 3) ? 4 : 1;
-    long long n_split = 1024 / ((long long)cb * tg);
+    long long n_split = 512 / ((long long)cb * tg);         // ~2 workgroups per CU; each ends with 32768 fp32 atomics
     if (n_split < 1) n_split = 1;
     if (n_split > total_tiles) n_split = total_tiles;
     if (cb > 65535) return CVAE_E_BADSHAPE;
@@ -421,8 +482,9 @@ int cvae_conv_down_c1(const void* L, const float* w, const float* bias, const vo
                       int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
-int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                       int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
+size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd);
+int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
+                       int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
 
 extern "C" size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, int dtype) {
     const int64_t taps = (nd == 3) ? 64 : 16;
@@ -482,11 +544,11 @@ extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, con
 }
 
 extern "C" size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd) {
-    if (Cl == 1) return 0;
+    if (Cl == 1) return cvae_conv_wgrad_c1_workspace_bytes(Cs, nd);
     return (size_t)(Cs * Cl * ((nd == 3) ? 64 : 16)) * sizeof(float);
 }
 
-extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, void* workspace, size_t workspace_bytes,
+extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                                int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                                int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
@@ -494,10 +556,17 @@ extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, void* wo
     if (!dW) return CVAE_E_NULLPTR;
     hipStream_t st = (hipStream_t)stream;
     const int taps = (nd == 3) ? 64 : 16;
-    if (B == 0) return hipMemsetAsync(dW, 0, (size_t)Cs * Cl * taps * sizeof(float), st) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
+    if (B == 0) {
+        if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cs * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
+        return hipMemsetAsync(dW, 0, (size_t)Cs * Cl * taps * sizeof(float), st) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
+    }
     if (!S || !L) return CVAE_E_NULLPTR;
-    if (Cl == 1) return cvae_conv_wgrad_c1(S, L, dW, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);
+    if (Cl == 1) return cvae_conv_wgrad_c1(S, L, dW, dbias, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);   // bias sum fused (S^T . ones)
     if (Cs % 64 || Cl % 32) return CVAE_E_UNSUPPORTED;
+    if (dbias) {
+        const int rcb = cvae_channel_sum(S, dbias, B * sd * sh * sw, Cs, dtype, stream);
+        if (rcb != CVAE_OK) return rcb;
+    }
     const size_t need = cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd);
     if (!workspace) return CVAE_E_NULLPTR;
     if (workspace_bytes < need) return CVAE_E_WORKSPACE;

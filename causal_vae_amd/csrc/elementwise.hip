@@ -157,27 +157,25 @@ extern "C" int cvae_act_fwd(const void* x, void* y, int64_t n, int act, int dtyp
 }
 
 // ------------------------------------------------------------------------------------- channel sum
-// x [P, C] channels-last.  Block = 256 threads covers (256 / CL) rows x CL channel-lanes; lanes run along C so the
-// loads are contiguous; partials meet in LDS, one atomic per (block, channel).
+// x [P, C] channels-last.  Block = 256 threads = (256 / CL) rows x CL channel-lanes (CL = min(C, 256)); lanes run along C
+// so loads are contiguous; blockIdx.y walks channel chunks of CL, blockIdx.x strides the rows; partials meet in LDS, one
+// atomic per (block, channel).
 template <typename T>
 __global__ void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t P, int64_t C) {
     __shared__ float red[256];
-    const int cl = (C >= 256) ? 256 : (int)C;              // channel lanes per block row
+    const int cl = (C >= 256) ? 256 : (int)C;
     const int rows = 256 / cl;
     const int c_in = threadIdx.x % cl, r_in = threadIdx.x / cl;
-    for (int64_t c0 = 0; c0 < C; c0 += cl) {
-        const int64_t c = c0 + c_in;
-        float acc = 0.f;
-        if (r_in < rows && c < C)
-            for (int64_t p = (int64_t)blockIdx.x * rows + r_in; p < P; p += (int64_t)gridDim.x * rows) acc += to_f32(x[p * C + c]);
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (r_in == 0 && c < C) {
-            float s = 0.f;
-            for (int r = 0; r < rows; ++r) s += red[r * cl + c_in];
-            atomicAdd(&out[c], s);
-        }
-        __syncthreads();
+    const int64_t c = (int64_t)blockIdx.y * cl + c_in;
+    float acc = 0.f;
+    if (r_in < rows && c < C)
+        for (int64_t p = (int64_t)blockIdx.x * rows + r_in; p < P; p += (int64_t)gridDim.x * rows) acc += to_f32(x[p * C + c]);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (r_in == 0 && c < C) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += red[r * cl + c_in];
+        atomicAdd(&out[c], s);
     }
 }
 extern "C" int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* stream) {
@@ -186,10 +184,17 @@ extern "C" int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C,
     if (hipMemsetAsync(out, 0, C * sizeof(float), (hipStream_t)stream) != hipSuccess) return CVAE_E_LAUNCH;
     if (P == 0) return CVAE_OK;
     if (!x) return CVAE_E_NULLPTR;
-    const int rows = (C >= 256) ? 1 : (int)(256 / C);
-    const int grid = cvae_grid_1d((P + rows - 1) / rows, 1, 1024);
-    if (dtype == CVAE_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, P, C);
-    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, P, C);
+    const int cl = (C >= 256) ? 256 : (int)C, rows = 256 / cl;
+    const int64_t gy = (C + cl - 1) / cl;
+    if (gy > 65535) return CVAE_E_BADSHAPE;
+    // every block ends with `cl` atomics onto the same words: give each block >= 64 row-passes of work
+    int64_t gx = (P + (int64_t)rows * 64 - 1) / ((int64_t)rows * 64);
+    const int64_t cap = (2048 + gy - 1) / gy;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    if (dtype == CVAE_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, P, C);
+    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, P, C);
     else return CVAE_E_DTYPE;
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
@@ -306,11 +311,101 @@ __global__ void upsample_fwd_kernel(const T* __restrict__ src, float* __restrict
         dst[i] = v;
     }
 }
+// ---- exact 2x fast paths (the 64^3 -> 128^3 case of the benchmark): 32-bit index math, 4 outputs per thread along W
+// (one 16-byte store), and for the backward a fixed 4-candidate window per dim [2i-1, 2i+2] whose weights come from the
+// same lin_tap as the forward (bit-identical coefficients, borders included).
+template <typename T>
+__global__ void upsample2x_fwd_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int d, int h, int w, int D, int H, int W) {
+    const float sd = (float)d / (float)D, sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int W4 = W >> 2;
+    const int n = B * D * H * W4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int r = i;
+        const int ow0 = (r % W4) * 4; r /= W4;
+        const int oh = r % H; r /= H;
+        const int od = r % D;
+        const int b = r / D;
+        const LinTap td = lin_tap(od, d, sd), th = lin_tap(oh, h, sh);
+        const T* p00 = src + ((size_t)(b * d + (int)td.i0) * h + (int)th.i0) * w;
+        const T* p01 = src + ((size_t)(b * d + (int)td.i0) * h + (int)th.i1) * w;
+        const T* p10 = src + ((size_t)(b * d + (int)td.i1) * h + (int)th.i0) * w;
+        const T* p11 = src + ((size_t)(b * d + (int)td.i1) * h + (int)th.i1) * w;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const LinTap tw = lin_tap(ow0 + j, w, sw);
+            const int x0 = (int)tw.i0, x1 = (int)tw.i1;
+            o[j] = td.w0 * (th.w0 * (tw.w0 * to_f32(p00[x0]) + tw.w1 * to_f32(p00[x1])) + th.w1 * (tw.w0 * to_f32(p01[x0]) + tw.w1 * to_f32(p01[x1]))) +
+                   td.w1 * (th.w0 * (tw.w0 * to_f32(p10[x0]) + tw.w1 * to_f32(p10[x1])) + th.w1 * (tw.w0 * to_f32(p11[x0]) + tw.w1 * to_f32(p11[x1])));
+        }
+        *(float4*)(dst + (((size_t)(b * D + od) * H + oh) * W + ow0)) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+struct Win4 { int j0; float w[4]; };
+__device__ __forceinline__ Win4 win4(int i, int in, int out, float scale, bool strided) {
+    Win4 r;
+    if (!strided) { r.j0 = i; r.w[0] = 1.f; r.w[1] = r.w[2] = r.w[3] = 0.f; return r; }     // unstrided dim (2D depth)
+    r.j0 = 2 * i - 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int j = r.j0 + c;
+        float wv = 0.f;
+        if (j >= 0 && j < out) {
+            const LinTap t = lin_tap(j, in, scale);
+            wv = (t.i0 == i ? t.w0 : 0.f) + (t.i1 == i ? t.w1 : 0.f);
+        }
+        r.w[c] = wv;
+    }
+    return r;
+}
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ ddst, T* __restrict__ dsrc, int B, int d, int h, int w, int D, int H, int W) {
+    const float sd = (float)d / (float)D, sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int n = B * d * h * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int r = i;
+        const int x = r % w; r /= w;
+        const int y = r % h; r /= h;
+        const int z = r % d;
+        const int b = r / d;
+        const Win4 wz = win4(z, d, D, sd, D != d), wy = win4(y, h, H, sh, true), wx = win4(x, w, W, sw, true);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (wz.w[a] == 0.f) continue;
+            float pl = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if (wy.w[bb] == 0.f) continue;
+                const float* row = ddst + ((size_t)(b * D + wz.j0 + a) * H + (wy.j0 + bb)) * W;
+                float rs = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (wx.w[c] != 0.f) rs += wx.w[c] * row[wx.j0 + c];
+                pl += wy.w[bb] * rs;
+            }
+            acc += wz.w[a] * pl;
+        }
+        dsrc[i] = from_f32<T>(acc);
+    }
+}
+static bool is_exact_2x(int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t C) {
+    return C == 1 && (D == 2 * d || (D == 1 && d == 1)) && H == 2 * h && W == 2 * w && (W % 4) == 0 && B * D * H * W < (int64_t)1 << 31;
+}
+
 extern "C" int cvae_upsample_linear_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, int64_t w,
                                         int64_t D, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
     if (B < 0 || d <= 0 || h <= 0 || w <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return CVAE_E_BADSHAPE;
     if (B == 0) return CVAE_OK;
     if (!src || !dst) return CVAE_E_NULLPTR;
+    if (is_exact_2x(B, d, h, w, D, H, W, C)) {
+        const int64_t n4 = B * D * H * (W / 4);
+        if (dtype == CVAE_F32) hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(cvae_grid_1d(n4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        else if (dtype == CVAE_BF16) hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16>, dim3(cvae_grid_1d(n4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, dst, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        else return CVAE_E_DTYPE;
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
     const int64_t n = B * D * H * W * C;
     if (dtype == CVAE_F32) hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, B, d, h, w, D, H, W, C);
     else if (dtype == CVAE_BF16) hipLaunchKernelGGL(upsample_fwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, dst, B, d, h, w, D, H, W, C);
@@ -372,6 +467,14 @@ extern "C" int cvae_upsample_linear_bwd(const float* ddst, void* dsrc, int64_t B
     if (B < 0 || d <= 0 || h <= 0 || w <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return CVAE_E_BADSHAPE;
     if (B == 0) return CVAE_OK;
     if (!ddst || !dsrc) return CVAE_E_NULLPTR;
+    if (is_exact_2x(B, d, h, w, D, H, W, C)) {
+        const int64_t ns = B * d * h * w;
+        if (dtype == CVAE_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(cvae_grid_1d(ns, 256, 8192)), dim3(256), 0, (hipStream_t)stream, ddst, (float*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        else if (dtype == CVAE_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16>, dim3(cvae_grid_1d(ns, 256, 8192)), dim3(256), 0, (hipStream_t)stream, ddst, (bf16*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        else return CVAE_E_DTYPE;
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
     const int64_t n = B * d * h * w * C;
     if (dtype == CVAE_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, ddst, (float*)dsrc, B, d, h, w, D, H, W, C);
     else if (dtype == CVAE_BF16) hipLaunchKernelGGL(upsample_bwd_kernel<bf16>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, ddst, (bf16*)dsrc, B, d, h, w, D, H, W, C);

@@ -119,20 +119,124 @@ static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias
     return CVAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ skinny (M <= 16)
+// At the model's batch sizes (4 per GPU) the three products of the 16415 x 512 encoder layer are pure weight streaming
+// (33.6 MB each): the MFMA tile would be 94 % padding and its LDS round trip only adds latency.  These kernels read or
+// write every weight element exactly once with fully coalesced dword rows and keep the M partial sums in registers.
+#define SK_M 16
+
+// y[m][n] (+)= sum_{k in chunk} x[m][k] W[n][k].  One wave per (row n, k-chunk); lanes stride k.
+__global__ __launch_bounds__(256) void linear_fwd_skinny_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int M, int64_t K, int64_t N, int64_t ldx, int64_t ldy,
+                                                                int64_t kchunk, int act, int use_atomic) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int64_t k0 = (int64_t)blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
+    float acc[SK_M];
+#pragma unroll
+    for (int m = 0; m < SK_M; ++m) acc[m] = 0.f;
+    const float* wr = W + n * K;
+    for (int64_t k = k0 + lane; k < k1; k += 64) {
+        const float w = wr[k];
+#pragma unroll
+        for (int m = 0; m < SK_M; ++m) if (m < M) acc[m] += w * x[m * ldx + k];
+    }
+#pragma unroll
+    for (int m = 0; m < SK_M; ++m) {
+        if (m >= M) break;
+        const float s = wave_sum(acc[m]);
+        if (lane == 0) {
+            if (use_atomic) atomicAdd(&y[m * ldy + n], s);
+            else y[m * ldy + n] = apply_act(s + (bias ? bias[n] : 0.f), act);
+        }
+    }
+}
+// dx[m][k] += sum_{n in chunk} dy[m][n] W[n][k].  One thread per k (coalesced W rows), blockIdx.y walks n-chunks.
+__global__ __launch_bounds__(256) void linear_bwd_data_skinny_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
+                                                                     int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx, int64_t nchunk) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.y * nchunk, n1 = min(N, n0 + nchunk);
+    float acc[SK_M];
+#pragma unroll
+    for (int m = 0; m < SK_M; ++m) acc[m] = 0.f;
+    if (k < K) {
+        for (int64_t n = n0; n < n1; ++n) {
+            const float w = W[n * K + k];
+#pragma unroll
+            for (int m = 0; m < SK_M; ++m) if (m < M) acc[m] += w * dy[m * ldy + n];     // uniform address: scalar loads
+        }
+#pragma unroll
+        for (int m = 0; m < SK_M; ++m) if (m < M) atomicAdd(&dx[m * ldx + k], acc[m]);
+    }
+}
+// dW[n][k] = sum_m dy[m][n] x[m][k]: one thread per element of the flattened [N*K] weight (coalesced stores).
+__global__ __launch_bounds__(256) void linear_bwd_weight_skinny_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dW,
+                                                                       int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx) {
+    const int64_t total = N * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / K, k = i - n * K;
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < SK_M; ++m) if (m < M) acc += dy[m * ldy + n] * x[m * ldx + k];
+        dW[i] = acc;
+    }
+}
+
 extern "C" int cvae_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N,
                                int64_t x_stride, int64_t y_stride, int act, void* stream) {
     if (x_stride < K) return CVAE_E_BADSHAPE;
+    if (M > 0 && M <= SK_M && N > 0 && K >= 64 && y_stride >= N) {
+        if (!x || !W || !y) return CVAE_E_NULLPTR;
+        hipStream_t st = (hipStream_t)stream;
+        int64_t chunks = (4096 + N - 1) / N;                    // enough waves in flight to cover HBM latency
+        if (chunks > K / 512) chunks = K / 512;
+        if (chunks < 1) chunks = 1;
+        const int64_t kchunk = ((K + chunks - 1) / chunks + 63) / 64 * 64;
+        chunks = (K + kchunk - 1) / kchunk;
+        const int use_atomic = chunks > 1;
+        if (use_atomic && hipMemset2DAsync(y, (size_t)y_stride * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
+        dim3 grid((unsigned)((N + 3) / 4), (unsigned)chunks);
+        hipLaunchKernelGGL(linear_fwd_skinny_kernel, grid, dim3(256), 0, st, x, W, b, y, (int)M, K, N, x_stride, y_stride, kchunk, act, use_atomic);
+        CVAE_CHECK_LAUNCH();
+        if (use_atomic && (b || act != CVAE_ACT_NONE)) {
+            hipLaunchKernelGGL(bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, st, y, b, M, N, y_stride, act);
+            CVAE_CHECK_LAUNCH();
+        }
+        return CVAE_OK;
+    }
     return gemm_f32(x, W, y, b, M, N, K, x_stride, 1, 1, K, y_stride, act, (hipStream_t)stream);
 }
 extern "C" int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N,
                                     int64_t dy_stride, int64_t dx_stride, void* stream) {
     if (dy_stride < N) return CVAE_E_BADSHAPE;
+    if (M > 0 && M <= SK_M && K >= 1024 && N > 0 && dx_stride >= K) {
+        if (!dy || !W || !dx) return CVAE_E_NULLPTR;
+        hipStream_t st = (hipStream_t)stream;
+        if (hipMemset2DAsync(dx, (size_t)dx_stride * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
+        const int64_t kb = (K + 255) / 256;
+        int64_t chunks = (1024 + kb - 1) / kb;
+        if (chunks > N / 16) chunks = N / 16;
+        if (chunks < 1) chunks = 1;
+        const int64_t nchunk = (N + chunks - 1) / chunks;
+        chunks = (N + nchunk - 1) / nchunk;
+        hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk);
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
     return gemm_f32(dy, W, dx, nullptr, M, K, N, dy_stride, 1, K, 1, dx_stride, CVAE_ACT_NONE, (hipStream_t)stream);
 }
 extern "C" int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N,
                                       int64_t dy_stride, int64_t x_stride, void* stream) {
     if (dy_stride < N || x_stride < K || M <= 0) return CVAE_E_BADSHAPE;
-    int rc = gemm_f32(dy, x, dW, nullptr, N, K, M, 1, dy_stride, x_stride, 1, K, CVAE_ACT_NONE, (hipStream_t)stream);
+    int rc = CVAE_OK;
+    if (M <= SK_M && N > 0 && K > 0) {
+        if (!dy || !x || !dW) return CVAE_E_NULLPTR;
+        hipLaunchKernelGGL(linear_bwd_weight_skinny_kernel, dim3(cvae_grid_1d(N * K, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, x, dW, (int)M, K, N, dy_stride, x_stride);
+        CVAE_CHECK_LAUNCH();
+    } else {
+        rc = gemm_f32(dy, x, dW, nullptr, N, K, M, 1, dy_stride, x_stride, 1, K, CVAE_ACT_NONE, (hipStream_t)stream);
+    }
     if (rc != CVAE_OK) return rc;
     if (db) {
         if (dy_stride != N) return CVAE_E_UNSUPPORTED;

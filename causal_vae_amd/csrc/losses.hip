@@ -396,6 +396,83 @@ extern "C" int cvae_adam_step(float* p, const float* g, float* m, float* v, int6
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
+// Multi-tensor Adam: ONE launch for the whole parameter list (the pointer table travels as a kernel argument), each block
+// owns a 4096-element span of one tensor.  `step_dev` (optional) is a device step counter: when given, the bias
+// corrections are computed in-kernel so that a captured HIP graph replays with advancing corrections.
+#define ADAM_MAX_TENSORS 32
+#define ADAM_SPAN 4096
+struct AdamTable {
+    float* p[ADAM_MAX_TENSORS];
+    const float* g[ADAM_MAX_TENSORS];
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    long long n[ADAM_MAX_TENSORS];
+    int blk_start[ADAM_MAX_TENSORS + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                         const int* __restrict__ step_dev, const float* __restrict__ gscale) {
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    if (step_dev) { const float st = (float)(*step_dev); bc1 = 1.f - powf(b1, st); bc2 = 1.f - powf(b2, st); }
+    const float gs = gscale ? *gscale : 1.f;
+    const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
+    float* p = tb.p[ti]; const float* g = tb.g[ti]; float* m = tb.m[ti]; float* v = tb.v[ti];
+    const long long n = tb.n[ti];
+    const long long base = (long long)((int)blockIdx.x - tb.blk_start[ti]) * ADAM_SPAN;
+    const long long end = min(n, base + ADAM_SPAN);
+    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    if (vec && end - base == ADAM_SPAN) {
+#pragma unroll
+        for (int k = 0; k < ADAM_SPAN / (256 * 4); ++k) {
+            const long long i = base / 4 + k * 256 + threadIdx.x;
+            float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+            adam1(P.x, G.x * gs, M.x, V.x, b1, b2, eps, step, rbc2);
+            adam1(P.y, G.y * gs, M.y, V.y, b1, b2, eps, step, rbc2);
+            adam1(P.z, G.z * gs, M.z, V.z, b1, b2, eps, step, rbc2);
+            adam1(P.w, G.w * gs, M.w, V.w, b1, b2, eps, step, rbc2);
+            ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+        }
+    } else {
+        for (long long i = base + threadIdx.x; i < end; i += 256) adam1(p[i], g[i] * gs, m[i], v[i], b1, b2, eps, step, rbc2);
+    }
+}
+extern "C" int cvae_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, int count,
+                               float lr, float b1, float b2, float eps, float bc1, float bc2, const int* step_dev, const float* gscale, void* stream) {
+    if (count < 0) return CVAE_E_BADSHAPE;
+    if (count == 0) return CVAE_OK;
+    if (!p || !g || !m || !v || !n) return CVAE_E_NULLPTR;
+    if (!step_dev && (bc1 <= 0.f || bc2 <= 0.f)) return CVAE_E_BADSHAPE;
+    for (int c0 = 0; c0 < count; c0 += ADAM_MAX_TENSORS) {
+        AdamTable tb;
+        const int cnt = (count - c0 < ADAM_MAX_TENSORS) ? count - c0 : ADAM_MAX_TENSORS;
+        int blocks = 0, used = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t ni = n[c0 + i];
+            if (ni < 0) return CVAE_E_BADSHAPE;
+            if (ni == 0) continue;
+            if (!p[c0 + i] || !g[c0 + i] || !m[c0 + i] || !v[c0 + i]) return CVAE_E_NULLPTR;
+            tb.p[used] = p[c0 + i]; tb.g[used] = g[c0 + i]; tb.m[used] = m[c0 + i]; tb.v[used] = v[c0 + i]; tb.n[used] = ni;
+            tb.blk_start[used] = blocks;
+            blocks += (int)((ni + ADAM_SPAN - 1) / ADAM_SPAN);
+            ++used;
+        }
+        if (!used) continue;
+        tb.blk_start[used] = blocks;
+        tb.count = used;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb, lr, b1, b2, eps, bc1, bc2, step_dev, gscale);
+        CVAE_CHECK_LAUNCH();
+    }
+    return CVAE_OK;
+}
+__global__ void add_int_kernel(int* c, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta; }
+extern "C" int cvae_counter_add(int* counter, int delta, void* stream) {
+    if (!counter) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
 __global__ void scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ scale) {
     const float s = *scale;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] *= s;

@@ -178,15 +178,17 @@ def _conv_up(St, wp, bias, mask, Cl, nd, act):
     return Lt
 
 
-def _conv_wgrad(St, Lt, nd, wshape):
+def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False):
+    """dW (and, when want_sbias, the per-channel sum of S = the bias gradient of a Conv layer)."""
     B, sd, sh, sw, Cs = _cl_dims(St)
     _, ld, lh, lw, Cl = _cl_dims(Lt)
     dW = torch.empty(wshape, dtype=torch.float32, device=St.device)
+    db = torch.empty(Cs, dtype=torch.float32, device=St.device) if want_sbias else None
     nbytes = lib.cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=St.device)
-    check(L.timed(f"conv_wgrad nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L{Cl}", lib.cvae_conv_wgrad, ptr(St), ptr(Lt), ptr(dW), ptr(ws), nbytes,
+    check(L.timed(f"conv_wgrad nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L{Cl}", lib.cvae_conv_wgrad, ptr(St), ptr(Lt), ptr(dW), ptr(db), ptr(ws), nbytes,
                   B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), stream()), "conv_wgrad")
-    return dW
+    return (dW, db) if want_sbias else dW
 
 
 def _channel_sum(x):
@@ -232,9 +234,13 @@ class ConvDown(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wp_up = pack_weight(weight, nd, True, g.dtype)
             dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = _conv_wgrad(g, x, nd, weight.shape)
-        if has_bias and ctx.needs_input_grad[2]:
+            if want_db:
+                dw, db = _conv_wgrad(g, x, nd, weight.shape, want_sbias=True)
+            else:
+                dw = _conv_wgrad(g, x, nd, weight.shape)
+        elif want_db:
             db = _channel_sum(g)
         return dx, dw, db, None, None, None, None
 

@@ -11,24 +11,34 @@ from ._lib import lib, check, ptr, stream
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (no weight decay, no amsgrad): one kernel launch per parameter tensor, 28 B/param."""
+    """torch.optim.Adam semantics (no weight decay, no amsgrad).  One multi-tensor launch per parameter group
+    (cvae_adam_multi: the pointer table rides in the kernel arguments), 28 B/param of HBM traffic.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    device_step=True keeps the step counter on the device and derives the bias corrections in-kernel, which makes
+    `step()` safe to capture into a HIP graph (the captured launch replays with an advancing counter)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, device_step=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.device_step = device_step
+        self._step_dev = None
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
         """grad_scale: optional 0-dim device tensor multiplied into every gradient (clip_grad_norm_ coefficient)."""
+        import ctypes as C
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                L.require_gpu(p)
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            L.require_gpu(*ps)
+            t = None
+            gs = []
+            for p in ps:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise L.CvaeError("FusedAdam: contiguous float32 parameters expected")
                 st = self.state[p]
@@ -37,10 +47,24 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                t = st["step"]
-                g = p.grad.contiguous()
-                check(lib.cvae_adam_step(ptr(p), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(), group["lr"], b1, b2,
-                                         group["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, ptr(grad_scale), stream()), "adam_step")
+                if t is None:
+                    t = st["step"]
+                elif t != st["step"]:
+                    raise L.CvaeError("FusedAdam: parameters of one group must share a step count")
+                gs.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+            n = len(ps)
+            arr = lambda vals: (C.c_void_p * n)(*vals)
+            sizes = (C.c_int64 * n)(*[p.numel() for p in ps])
+            step_ptr = None
+            if self.device_step:
+                if self._step_dev is None:
+                    self._step_dev = torch.zeros((), dtype=torch.int32, device=ps[0].device)
+                check(lib.cvae_counter_add(ptr(self._step_dev), 1, stream()), "counter_add")
+                step_ptr = ptr(self._step_dev)
+            check(lib.cvae_adam_multi(arr([p.data_ptr() for p in ps]), arr([g.data_ptr() for g in gs]),
+                                      arr([self.state[p]["exp_avg"].data_ptr() for p in ps]),
+                                      arr([self.state[p]["exp_avg_sq"].data_ptr() for p in ps]), sizes, n, group["lr"], b1, b2,
+                                      group["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, step_ptr, ptr(grad_scale), stream()), "adam_multi")
         return loss
 
 

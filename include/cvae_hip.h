@@ -86,9 +86,11 @@ int cvae_conv_down(const void* L, const void* w, const float* bias, const void* 
 int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
                  int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                  int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream);
-/* dW fp32 [Cs][Cl][taps] (overwritten) = sum over batch and positions.  workspace: cvae_conv_wgrad_workspace_bytes(). */
+/* dW fp32 [Cs][Cl][taps] (overwritten) = sum over batch and positions.  workspace: cvae_conv_wgrad_workspace_bytes().
+ * dbias (optional, fp32 [Cs], overwritten) = sum over batch and positions of S: the bias gradient of a Conv layer, whose
+ * S is the output gradient (fused into the weight-gradient pass where S is read anyway). */
 size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd);
-int cvae_conv_wgrad(const void* S, const void* L, float* dW, void* workspace, size_t workspace_bytes,
+int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                     int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                     int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream);
 /* out[c] = sum_p x[p, c] over a channels-last [P, C] tensor (bias gradients). out is overwritten. */
@@ -169,6 +171,13 @@ int cvae_uniform_kl_bwd(const float* logits, const float* gout, float* dlogits, 
  * computed by the caller.  grad_scale: optional device scalar multiplied into g first (gradient clipping). */
 int cvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float bc1, float bc2, const float* grad_scale, void* stream);
+/* The same update for a LIST of tensors in one launch (host arrays of `count` device pointers / sizes).  step_dev: optional
+ * device int holding the step number t; when non-NULL the kernel derives bc1/bc2 from it (HIP-graph replay safe). */
+int cvae_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, int count,
+                    float lr, float beta1, float beta2, float eps, float bc1, float bc2, const int* step_dev,
+                    const float* grad_scale, void* stream);
+/* *counter += delta (device int; step counters that must advance inside a captured graph) */
+int cvae_counter_add(int* counter, int delta, void* stream);
 /* *out += sum g^2 */
 int cvae_sqnorm(const float* g, float* out, int64_t n, void* stream);
 /* g *= *scale  (in place; scale is a device scalar) */

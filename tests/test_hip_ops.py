@@ -75,7 +75,7 @@ def test_conv_forward_backward(nd, B, Cl, Cs, size, dtype):
     x = rnd(torch.randn(B, Cl, *size, generator=g), dtype).requires_grad_(True)
     w = (torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cl * 4 ** nd)).requires_grad_(True)
     b = torch.randn(Cs, generator=g).requires_grad_(True)
-    wr = rnd(w.detach(), dtype) if Cl > 1 else w.detach().clone()     # single-channel layers keep fp32 weights
+    wr = rnd(w.detach(), dtype).clone()
     y_ref = F.relu(conv(x, wr.requires_grad_(True), b, stride=2, padding=1))
     gy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
     gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, wr, b], gy)

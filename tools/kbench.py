@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark of the conv family at the BASELINE shapes (B = 4, 128^3 model), through the C ABI.
+
+    python tools/kbench.py [filter-substring ...] [--dtype bf16|f32] [--iters N]
+
+Prints, per case, the mean launch time (HIP events over N back-to-back launches), algorithmic TFLOP/s and the
+algorithmic HBM GB/s (inputs + outputs once).  Used to iterate on one kernel at a time; bench.py remains the metric."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from causal_vae_amd import ops  # noqa: E402
+
+# name, kind, B, (sd, sh, sw), Cs, Cl   (L spatial = 2x S spatial)
+CASES = [
+    ("enc1.fwd", "down", 4, (64, 64, 64), 32, 1), ("enc2.fwd", "down", 4, (32, 32, 32), 64, 32),
+    ("enc3.fwd", "down", 4, (16, 16, 16), 128, 64), ("enc4.fwd", "down", 4, (8, 8, 8), 256, 128),
+    ("enc2.bwd_data", "up", 4, (32, 32, 32), 64, 32), ("enc3.bwd_data", "up", 4, (16, 16, 16), 128, 64),
+    ("enc4.bwd_data", "up", 4, (8, 8, 8), 256, 128),
+    ("enc1.wgrad", "wgrad", 4, (64, 64, 64), 32, 1), ("enc2.wgrad", "wgrad", 4, (32, 32, 32), 64, 32),
+    ("enc3.wgrad", "wgrad", 4, (16, 16, 16), 128, 64), ("enc4.wgrad", "wgrad", 4, (8, 8, 8), 256, 128),
+    ("dec1.fwd", "up", 4, (4, 4, 4), 256, 128), ("dec2.fwd", "up", 4, (8, 8, 8), 128, 64),
+    ("dec3.fwd", "up", 4, (16, 16, 16), 64, 32), ("dec4.fwd", "up", 4, (32, 32, 32), 32, 1),
+    ("dec1.bwd_data", "down", 4, (4, 4, 4), 256, 128), ("dec2.bwd_data", "down", 4, (8, 8, 8), 128, 64),
+    ("dec3.bwd_data", "down", 4, (16, 16, 16), 64, 32), ("dec4.bwd_data", "down", 4, (32, 32, 32), 32, 1),
+    ("dec1.wgrad", "wgrad", 4, (4, 4, 4), 256, 128), ("dec2.wgrad", "wgrad", 4, (8, 8, 8), 128, 64),
+    ("dec3.wgrad", "wgrad", 4, (16, 16, 16), 64, 32), ("dec4.wgrad", "wgrad", 4, (32, 32, 32), 32, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("filters", nargs="*")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    esz = 2 if dt == torch.bfloat16 else 4
+    dev = "cuda"
+    tot = 0.0
+    for name, kind, B, sp, Cs, Cl in CASES:
+        if args.filters and not any(f in name for f in args.filters):
+            continue
+        lp = tuple(2 * s for s in sp)
+        S = (torch.randn(B, *sp, Cs, device=dev) * 0.5).to(dt)
+        Lt = (torch.randn(B, *lp, Cl, device=dev) * 0.5).to(dt)
+        w = torch.randn(Cs, Cl, 4, 4, 4, device=dev) * 0.05
+        bias_s, bias_l = torch.randn(Cs, device=dev), torch.randn(Cl, device=dev)
+        if kind == "down":
+            wp = ops.pack_weight(w, 3, False, dt)
+            fn = lambda: ops._conv_down(Lt, wp, bias_s, None, Cs, 3, "relu")
+        elif kind == "up":
+            wp = ops.pack_weight(w, 3, True, dt)
+            fn = lambda: ops._conv_up(S, wp, bias_l, None, Cl, 3, "relu")
+        else:
+            fn = lambda: ops._conv_wgrad(S, Lt, 3, w.shape, want_sbias=True)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        npos = B * sp[0] * sp[1] * sp[2]
+        flops = 2.0 * npos * Cs * Cl * 64
+        byts = (S.numel() + Lt.numel()) * esz
+        tot += ms
+        print(f"{name:16s} {kind:6s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TFLOP/s  {byts / ms / 1e6:8.1f} GB/s   (S {tuple(S.shape)} L {tuple(Lt.shape)})")
+    print(f"total {tot * 1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main()
