@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--lr", type=float, default=1e-3, help="Adam learning rate (reference: 1e-3, causal_cascade/main.py:50)")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--roofline-steps", type=int, default=5, help="eager steps with per-launch HIP events after the timed region")
     args = ap.parse_args()
 
     from causal_vae_amd import FusedAdam, _lib
@@ -110,7 +112,7 @@ def main():
     torch.manual_seed(42)                                            # causal_cascade/main.py:28
     model = CausalBioVAE3D().to(dev).train().set_compute_dtype(dtype)
     broadcast_parameters(model)
-    opt = FusedAdam(model.parameters(), lr=args.lr)                  # main.py:50
+    opt = FusedAdam(model.parameters(), lr=args.lr, device_step=True)   # main.py:50
     reducer = GradAllReducer(model.parameters()) if world > 1 else None
     x, m, t, eps = make_batch(args.batch, args.size, 1234 + rank, dev)
 
@@ -120,32 +122,49 @@ def main():
         elbo0 = float(loss_function(out[0], x, out[1], m, out[2], out[3])[0])
     del out
 
-    def step():
+    def eager_step():
         return train_step(model, opt, x, m, t, grad_hook=reducer)
 
+    use_graph = not args.no_graph
+    n_pre = 0
+    if use_graph:
+        from causal_vae_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, (x, m, t), lambda o, xx, mm: loss_function(o[0], xx, o[1], mm, o[2], o[3]), reducer=reducer, warmup=3)
+        n_pre = 3                                                    # the capture warm-up runs 3 real steps
+        step = lambda: gstep()
+    else:
+        step = eager_step
+
     traj = []
-    for _ in range(args.warmup):
-        traj.append(step()[0])
+    for _ in range(max(args.warmup - n_pre, 1)):
+        traj.append(step()[0].clone())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer = None
-    if not args.no_kernel_timer:
-        timer = _lib.KernelTimer()
-        _lib.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _, _ = step()
-        traj.append(loss)
+        loss = step()[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    _lib.TIMER = None
+    traj.append(loss.clone())
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # ---- roofline leg: the same step issued eagerly with HIP events around every conv launch (events cannot sit inside a
+    # replayed graph); same process, same buffers, directly after the timed region ----
+    timer = None
+    if not args.no_kernel_timer and args.roofline_steps > 0:
+        timer = _lib.KernelTimer()
+        eager_step()
+        torch.cuda.synchronize()
+        _lib.TIMER = timer
+        for _ in range(args.roofline_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        _lib.TIMER = None
     fin = lambda v: float(v) if torch.isfinite(torch.as_tensor(float(v))) else None
     final_loss = fin(loss)
     traj = [fin(v) for v in traj]
@@ -160,20 +179,21 @@ def main():
                                    f"Adam lr 1e-3, ELBO = MSE-sum + 2000*MSE-sum(m) + KLD", "global_batch": world * args.batch,
                        "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}",
                        "params": sum(p.numel() for p in model.parameters())},
-            "final_loss": final_loss, "loss_trajectory": traj[:4] + traj[-2:], "lr": args.lr,
+            "final_loss": final_loss, "loss_trajectory": traj[:4] + traj[-2:], "lr": args.lr, "hip_graph": use_graph,
         }
         if timer is not None:
             summ = timer.summary()
-            per_step = {k: (n / args.steps, ms) for k, (n, ms) in summ.items()}
+            per_step = {k: (n / args.roofline_steps, ms) for k, (n, ms) in summ.items()}
             dom = max(summ, key=lambda k: summ[k][0] * summ[k][1])
             n, ms = summ[dom]
             fl = conv_flops(dom)
             peak = PEAK_BF16_FLOPS if args.dtype == "bf16" else PEAK_F32_FLOPS
             ach = fl / (ms * 1e-3)
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None, "avg_ms": ms, "launches_per_step": n / args.steps,
+                               "frac": ach / peak, "traffic": None, "avg_ms": ms, "launches_per_step": n / args.roofline_steps,
+                               "timing": f"HIP events around each launch over {args.roofline_steps} eager steps run right after the timed region",
                                "algorithmic_gflop_per_launch": fl / 1e9}
-            conv_ms = sum(n_ * ms_ for n_, ms_ in summ.values()) / args.steps
+            conv_ms = sum(n_ * ms_ for n_, ms_ in summ.values()) / args.roofline_steps
             res["conv_ms_per_step"] = conv_ms
             res["kernels"] = {k: {"per_step": v[0], "avg_ms": round(v[1], 4), "tflops": round(conv_flops(k) / (v[1] * 1e-3) / 1e12, 1)}
                               for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0] * kv[1][1])}

@@ -42,7 +42,7 @@ class CausalBioVAE(nn.Module):
             ConvT(128, 64, 4, 2, 1), nn.ReLU(),
             ConvT(64, 32, 4, 2, 1), nn.ReLU(),
             ConvT(32, img_channels, 4, 2, 1))
-        self._eps_calls = 0
+        self._eps = ops.EpsSource()
 
     # ---- precision -------------------------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -60,8 +60,7 @@ class CausalBioVAE(nn.Module):
         """z = mu + eps*exp(logvar/2).  eps defaults to a device Philox draw keyed by torch's seed (the CPU generator stream
         of the reference cannot be reproduced on a GPU — parity runs pass `eps` explicitly)."""
         if eps is None:
-            eps = ops.philox_normal(mu.shape, torch.initial_seed(), self._eps_calls << 24, mu.device)
-            self._eps_calls += 1
+            eps = self._eps.draw(mu)
         return ops.Reparameterize.apply(mu, logvar, eps)
 
     def decode_cl(self, z_m_input):

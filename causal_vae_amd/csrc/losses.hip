@@ -331,7 +331,8 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
-__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, const int* __restrict__ call_dev) {
+    if (call_dev) offset += ((uint64_t)(unsigned)(*call_dev)) << 24;       // device-side call counter: advances under graph replay
     const int64_t n4 = (n + 3) >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t ctr = offset + (uint64_t)i;
@@ -349,11 +350,11 @@ __global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_
         for (int j = 0; j < 4; ++j) if (i * 4 + j < n) out[i * 4 + j] = v[j];
     }
 }
-extern "C" int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+extern "C" int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const int* call_counter, void* stream) {
     if (n < 0) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!out) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(philox_normal_kernel, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, call_counter);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

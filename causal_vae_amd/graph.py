@@ -1,0 +1,73 @@
+"""Whole-step HIP-graph capture: zero_grad -> forward -> ELBO -> backward -> Adam recorded once, replayed per step.
+
+The model's step is ~150 small-to-medium kernel launches; eager Python issues them at ~4-5 us each, which is a third of
+the step at 128^3 / B=4.  Every C-ABI entry point only enqueues on the current stream (include/cvae_hip.h), the Adam step
+count and the Philox call count live on the device, and nothing in the step syncs with the host, so the whole step is
+capturable with torch.cuda.graph (HIP graphs underneath) — no tracing compiler involved.
+
+With a GradAllReducer (N > 1 ranks) the step is captured as two graphs around the eager RCCL all-reduce:
+graph A = zero_grad..backward + pack of the flat gradient bucket, graph B = unpack + Adam.
+"""
+import torch
+
+from ._lib import CvaeError
+from .optim import FusedAdam
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, batch, loss_fn, reducer=None, warmup=3):
+        """batch: (x, m, t) example tensors on the GPU (their storage becomes the static input buffers).
+        loss_fn(model_outputs, x, m) -> (loss, *others): 0-dim tensors; `loss` is back-propagated."""
+        if not isinstance(optimizer, FusedAdam) or not optimizer.device_step:
+            raise CvaeError("GraphedTrainStep needs FusedAdam(..., device_step=True): the step count must live on the device")
+        self.model, self.opt, self.reducer = model, optimizer, reducer
+        self.x, self.m, self.t = (b.clone() for b in batch)
+        self.loss_fn = loss_fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                          # allocator warm-up, lazy kernel attributes, Adam state
+                self._fwd_bwd()
+                self._reduce_eager()
+                self.opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1 = torch.cuda.CUDAGraph()
+        self.g2 = None
+        if reducer is None or reducer.world_size() == 1:
+            with torch.cuda.graph(self.g1):
+                self.out = self._fwd_bwd()
+                self.opt.step()
+        else:
+            with torch.cuda.graph(self.g1):
+                self.out = self._fwd_bwd()
+                reducer.pack()
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+                reducer.unpack()
+                self.opt.step()
+
+    def _fwd_bwd(self):
+        self.opt.zero_grad(set_to_none=True)
+        outs = self.model(self.x, self.m, self.t)
+        res = self.loss_fn(outs, self.x, self.m)
+        res[0].backward()
+        return tuple(r.detach() for r in res)
+
+    def _reduce_eager(self):
+        if self.reducer is not None:
+            self.reducer()
+
+    def __call__(self, x=None, m=None, t=None):
+        """Replay one step; new inputs (same shapes) are copied into the static buffers first.  Returns the static loss tensors."""
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if m is not None:
+            self.m.copy_(m, non_blocking=True)
+        if t is not None:
+            self.t.copy_(t, non_blocking=True)
+        self.g1.replay()
+        if self.g2 is not None:
+            self.reducer.all_reduce()
+            self.g2.replay()
+        return self.out

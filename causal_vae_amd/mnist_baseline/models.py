@@ -22,7 +22,7 @@ class CausalMorphVAE12(nn.Module):
         self.morph_predictor = hl.MLP(hl.Linear(self.t_dim, 128), nn.ReLU(), hl.Linear(128, self.m_dim))
         self.dec_fc = hl.MLP(hl.Linear(self.m_dim + self.z_dim, self.enc_flat_dim), nn.ReLU())
         self.dec_conv = hl.DeconvStack(hl.ConvTranspose2d(64, 32, 4, 2, 1), nn.ReLU(), hl.ConvTranspose2d(32, 1, 4, 2, 1), nn.Sigmoid())
-        self._eps_calls = 0
+        self._eps = ops.EpsSource()
 
     def set_compute_dtype(self, dtype):
         hl.set_compute_dtype(self, dtype)
@@ -30,8 +30,7 @@ class CausalMorphVAE12(nn.Module):
 
     def reparameterize(self, mu, logvar, eps=None):
         if eps is None:
-            eps = ops.philox_normal(mu.shape, torch.initial_seed(), self._eps_calls << 24, mu.device)
-            self._eps_calls += 1
+            eps = self._eps.draw(mu)
         return ops.Reparameterize.apply(mu, logvar, eps)
 
     def forward(self, x, m, t, eps=None):

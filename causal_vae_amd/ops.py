@@ -424,10 +424,27 @@ def bn1d_eval(x, weight, bias, running_mean, running_var, eps):
 
 
 # ------------------------------------------------------------------------------------------------ sampling + losses
-def philox_normal(shape, seed, offset, device):
+def philox_normal(shape, seed, offset, device, call_counter=None):
+    """N(0,1) draws.  call_counter: optional device int32 tensor added (<< 24) to the offset and incremented afterwards —
+    the device-side call count that keeps a captured HIP graph drawing fresh numbers on every replay."""
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(lib.cvae_philox_normal(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, stream()), "philox_normal")
+    check(lib.cvae_philox_normal(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, ptr(call_counter), stream()),
+          "philox_normal")
+    if call_counter is not None:
+        check(lib.cvae_counter_add(ptr(call_counter), 1, stream()), "counter_add")
     return out
+
+
+class EpsSource:
+    """Per-model device Philox stream for `reparameterize(mu, logvar)` (the reference draws torch.randn_like there)."""
+
+    def __init__(self):
+        self.counter = None
+
+    def draw(self, like):
+        if self.counter is None or self.counter.device != like.device:
+            self.counter = torch.zeros((), dtype=torch.int32, device=like.device)
+        return philox_normal(like.shape, torch.initial_seed(), 0, like.device, self.counter)
 
 
 class Reparameterize(torch.autograd.Function):

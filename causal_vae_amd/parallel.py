@@ -45,24 +45,35 @@ class GradAllReducer:
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def __call__(self):
-        if self.world_size() == 1:
-            return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if not grads:
-            return
+    def _grads(self):
+        return [p.grad for p in self.params if p.grad is not None]
+
+    def pack(self):
+        """Copy every gradient into the flat fp32 bucket (capturable: fixed addresses once the bucket exists)."""
+        grads = self._grads()
         n = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
+        if self._flat is None or self._flat.numel() != n or (grads and self._flat.device != grads[0].device):
             self._flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
         off = 0
-        for g in grads:                       # pack
+        for g in grads:
             self._flat[off:off + g.numel()].copy_(g.reshape(-1))
             off += g.numel()
+
+    def all_reduce(self):
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def unpack(self):
         off = 0
-        for g in grads:                       # unpack in place
+        for g in self._grads():
             g.copy_(self._flat[off:off + g.numel()].view_as(g))
             off += g.numel()
+
+    def __call__(self):
+        if self.world_size() == 1 or not self._grads():
+            return
+        self.pack()
+        self.all_reduce()
+        self.unpack()
 
 
 def broadcast_parameters(module, src=0, group=None):

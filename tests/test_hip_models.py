@@ -128,7 +128,7 @@ def test_bio3d_fp32_matches_oracle(B, size):
         gref = st["grads"][k]
         scale = float(gref.abs().mean())
         # atol: fp32 sums over up to 1e6 positions of cancelling terms, in a different order than aten's
-        torch.testing.assert_close(p.grad.cpu(), gref, rtol=2e-3, atol=5e-3 * scale + 2e-6, msg=lambda s: f"grad {k}: {s}")
+        torch.testing.assert_close(p.grad.cpu(), gref, rtol=2e-3, atol=5e-3 * scale + 2e-5 * float(gref.abs().max()) + 2e-6, msg=lambda s: f"grad {k}: {s}")
         adam_close(p, sd1[k], k)
     for k in ("mechanism_net.1.running_mean", "mechanism_net.1.running_var", "mechanism_net.1.num_batches_tracked"):
         torch.testing.assert_close(model.state_dict()[k].cpu(), sd1[k], rtol=1e-5, atol=1e-6)
@@ -231,3 +231,28 @@ def test_bio3d_three_steps_track_the_oracle():
         state = st["adam_state"]
         loss, _, _ = train_step(model, opt, x.to(DEV), m.to(DEV), t.to(DEV), eps=eps.to(DEV))
         assert rel(loss, st["loss"]) < (1e-4 if step == 0 else 1e-3), (step, float(loss), float(st["loss"]))
+
+
+def test_graphed_step_matches_eager_steps():
+    """The captured HIP graph replays the same arithmetic as the eager step (device-side Adam step count and Philox call
+    count advance under replay): 3 capture-warm-up steps + 3 replays == 6 eager steps on the same batch."""
+    from causal_vae_amd.graph import GraphedTrainStep
+    g = torch.Generator().manual_seed(11)
+    x, m = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (2,), generator=g).to(DEV)
+    lf = lambda o, xx, mm: loss_function(o[0], xx, o[1], mm, o[2], o[3])
+    torch.manual_seed(42)
+    m_e = CausalBioVAE3D().to(DEV).train()
+    o_e = FusedAdam(m_e.parameters(), lr=1e-4, device_step=True)
+    eager = [float(train_step(m_e, o_e, x, m, t)[0]) for _ in range(6)]
+    torch.manual_seed(42)
+    m_g = CausalBioVAE3D().to(DEV).train()
+    o_g = FusedAdam(m_g.parameters(), lr=1e-4, device_step=True)
+    gs = GraphedTrainStep(m_g, o_g, (x, m, t), lf, warmup=3)
+    graphed = [float(gs()[0]) for _ in range(3)]
+    for a, b in zip(eager[3:], graphed):
+        assert rel(b, a) < 2e-4, (eager, graphed)
+    assert len(set(graphed)) == 3                                   # the replays really advance (weights + eps change)
+    for (k, p), q in zip(m_e.named_parameters(), m_g.parameters()):
+        if k != NOISE_KEY:
+            assert float((p - q).abs().max()) < 5e-4, k

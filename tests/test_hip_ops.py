@@ -348,6 +348,10 @@ def test_philox_normal_statistics_and_determinism():
     assert abs(float((a ** 4).mean()) - 3.0) < 0.1 and torch.isfinite(a).all()
     odd = ops.philox_normal((7,), 42, 0, DEV)
     assert torch.equal(odd, a[:7])
+    ctr = torch.zeros((), dtype=torch.int32, device=DEV)
+    d0 = ops.philox_normal((64,), 42, 0, DEV, ctr)
+    d1 = ops.philox_normal((64,), 42, 0, DEV, ctr)
+    assert int(ctr) == 2 and torch.equal(d0, a[:64]) and not torch.equal(d0, d1)
 
 
 def test_fused_adam_and_clip_match_torch():
