@@ -20,6 +20,7 @@
 //   one element per lane and needs no transpose.  Partial sums leave as 128-byte-row fp32 atomics into a
 //   [tap][Cs][Cl] workspace, then one pass rewrites them in the reference [Cs][Cl][taps] layout.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -417,32 +418,54 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv_wgrad_kernel
             }
         }
     }
-    // ---- write-out: ws[tap][cs][cl] += acc ; lanes 0-31 / 32-63 each cover one 128-byte row segment ----
+    // ---- write-out: this workgroup's partial sums leave as ONE slab [kh][kw][64 cs][32 cl] of plain 128-byte-row stores;
+    // wgrad_reduce_kernel sums the slabs (fp32 atomics here cost more than the MFMA phase: 67 MB of adds at < 1 TB/s) ----
+    if (!ws) return;                                          // tuning only: measure the accumulate phase alone
     const int col = lane & 31, hq = lane >> 5;
+    float* slab = ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * n_split + blockIdx.x) * 32768;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-            const int tap = (kd * 4 + kh) * 4 + kw;
+        for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = s * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
-                atomicAdd(&ws[((size_t)tap * g.Cs + cs0 + row) * g.Cl + cl0 + col], acc[s][kw][e]);
+                slab[((kh * 4 + kw) * 64 + row) * 32 + col] = acc[s][kw][e];
             }
-        }
 }
 
-__global__ void wgrad_unpack_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Cs, int Cl, int taps) {
-    const int64_t n = (int64_t)Cs * Cl * taps;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % taps);
-        const int64_t cc = i / taps;               // cs * Cl + cl
-        dW[i] = ws[(int64_t)tap * Cs * Cl + cc];
+// dW[cs][cl][kd][kh][0..3] = sum over the n_split slabs of group (kd, channel block).  One thread per (kd, kh, cs, cl)
+// sums the 4 kw values (a 16-byte store into the reference layout); 4 thread groups split the slab range, LDS combines.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Cs, int Cl, int taps, int n_split, int cb) {
+    __shared__ float4 part[4][64];
+    const int cl_blocks = Cl / 32;
+    // blockIdx.x enumerates (group = kd * cb + block, kh, cs row pair) ; 64 threads = 2 cs rows x 32 cl
+    int bi = blockIdx.x;
+    const int rowpair = bi % 32; bi /= 32;
+    const int kh = bi % 4; bi /= 4;
+    const int grp = bi;                                      // kd * cb + channel block
+    const int kd = grp / cb, blk = grp % cb;
+    const int lane64 = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int row = rowpair * 2 + (lane64 >> 5), col = lane64 & 31;
+    const float* base = ws + (size_t)grp * n_split * 32768 + ((kh * 4) * 64 + row) * 32 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int x = q; x < n_split; x += 4) {
+        const float* p = base + (size_t)x * 32768;
+        a.x += p[0]; a.y += p[2048]; a.z += p[4096]; a.w += p[6144];
+    }
+    part[q][lane64] = a;
+    __syncthreads();
+    if (q == 0) {
+        const float4 b = part[1][lane64], c = part[2][lane64], d = part[3][lane64];
+        a.x += b.x + c.x + d.x; a.y += b.y + c.y + d.y; a.z += b.z + c.z + d.z; a.w += b.w + c.w + d.w;
+        const int cs = (blk / cl_blocks) * 64 + row, cl = (blk % cl_blocks) * 32 + col;
+        *(float4*)(dW + ((size_t)cs * Cl + cl) * taps + kd * 16 + kh * 4) = a;
     }
 }
 
+#define WGRAD_MAX_WG 512
 template <typename T, int ND>
-int launch_wgrad(const void* S, const void* L, float* ws, ConvGeom g, hipStream_t stream) {
+int launch_wgrad(const void* S, const void* L, float* ws, float* dW, ConvGeom g, hipStream_t stream) {
     using TL = Tile<ND, 128>;
     constexpr size_t LDS = (size_t)128 * 64 * sizeof(T) + (size_t)TL::TD * (2 * TL::TH + 2) * (2 * TL::TW + 2) * 32 * sizeof(T);
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
@@ -455,12 +478,18 @@ int launch_wgrad(const void* S, const void* L, float* ws, ConvGeom g, hipStream_
     g.tiles_d = (g.sd + TL::TD - 1) / TL::TD; g.tiles_h = (g.sh + TL::TH - 1) / TL::TH; g.tiles_w = (g.sw + TL::TW - 1) / TL::TW;
     const long long total_tiles = (long long)g.B * g.tiles_d * g.tiles_h * g.tiles_w;
     const int cb = (g.Cs / 64) * (g.Cl / 32), tg = (ND == 3) ? 4 : 1;
-    long long n_split = 512 / ((long long)cb * tg);         // ~2 workgroups per CU; each ends with 32768 fp32 atomics
+    // each workgroup ends with a 128 KB slab: ~2 workgroups per CU at most, and >= 4 tiles of work per slab
+    long long n_split = WGRAD_MAX_WG / ((long long)cb * tg);
+    if (n_split > total_tiles / 4) n_split = total_tiles / 4;
+    if (const char* e = getenv("CVAE_TUNE_WGRAD_NSPLIT")) n_split = atoll(e);      // tuning knob (tools/kbench.py)
     if (n_split < 1) n_split = 1;
     if (n_split > total_tiles) n_split = total_tiles;
     if (cb > 65535) return CVAE_E_BADSHAPE;
     dim3 grid((unsigned)n_split, (unsigned)cb, (unsigned)tg);
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, (const T*)S, (const T*)L, ws, g, (int)n_split);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, (const T*)S, (const T*)L, getenv("CVAE_TUNE_WGRAD_NOREDUCE") ? nullptr : ws, g, (int)n_split);
+    CVAE_CHECK_LAUNCH();
+    if (getenv("CVAE_TUNE_WGRAD_NOREDUCE")) return CVAE_OK;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cb * tg * 4 * 32)), dim3(256), 0, stream, (const float*)ws, dW, g.Cs, g.Cl, (ND == 3) ? 64 : 16, (int)n_split, cb);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
@@ -545,7 +574,9 @@ extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, con
 
 extern "C" size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd) {
     if (Cl == 1) return cvae_conv_wgrad_c1_workspace_bytes(Cs, nd);
-    return (size_t)(Cs * Cl * ((nd == 3) ? 64 : 16)) * sizeof(float);
+    const int64_t groups = (Cs / 64) * (Cl / 32) * ((nd == 3) ? 4 : 1);             // slab groups (kd, channel block)
+    const int64_t wgs = groups > WGRAD_MAX_WG ? groups : WGRAD_MAX_WG;             // groups * n_split <= max(WGRAD_MAX_WG, groups)
+    return (size_t)wgs * 32768 * sizeof(float);
 }
 
 extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
@@ -570,14 +601,7 @@ extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* d
     const size_t need = cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd);
     if (!workspace) return CVAE_E_NULLPTR;
     if (workspace_bytes < need) return CVAE_E_WORKSPACE;
-    if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return CVAE_E_LAUNCH;
     GEOM_INIT();
-    int rc;
-    if (dtype == CVAE_BF16) rc = nd == 3 ? launch_wgrad<bf16, 3>(S, L, (float*)workspace, g, st) : launch_wgrad<bf16, 2>(S, L, (float*)workspace, g, st);
-    else rc = nd == 3 ? launch_wgrad<float, 3>(S, L, (float*)workspace, g, st) : launch_wgrad<float, 2>(S, L, (float*)workspace, g, st);
-    if (rc != CVAE_OK) return rc;
-    const int64_t n = Cs * Cl * taps;
-    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, st, (const float*)workspace, dW, (int)Cs, (int)Cl, taps);
-    CVAE_CHECK_LAUNCH();
-    return CVAE_OK;
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_wgrad<bf16, 3>(S, L, (float*)workspace, dW, g, st) : launch_wgrad<bf16, 2>(S, L, (float*)workspace, dW, g, st);
+    return nd == 3 ? launch_wgrad<float, 3>(S, L, (float*)workspace, dW, g, st) : launch_wgrad<float, 2>(S, L, (float*)workspace, dW, g, st);
 }

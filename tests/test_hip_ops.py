@@ -63,6 +63,9 @@ CONV_CASES = [
     (3, 1, 128, 256, (4, 4, 4)),
     (3, 1, 32, 64, (10, 12, 18)),   # ragged tiles
     (3, 1, 1, 32, (6, 20, 10)),
+    (3, 2, 64, 128, (16, 16, 16)),  # several tiles per workgroup in the weight-gradient slabs
+    (3, 3, 32, 64, (16, 24, 16)),
+    (2, 5, 32, 64, (64, 48)),
 ]
 
 
