@@ -230,13 +230,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
             store_b(pb0, 0);
         }
         __syncthreads();
-#pragma unroll 1
-        for (int grp = 0; grp < NG; ++grp) {
-            const int buf = grp & 1;
-            Piece<T> pbn[BP];
-            const bool more = grp + 1 < NG;
-            if (more) load_b(pbn, chunk, grp + 1);         // issue next panel's loads; they land while the MFMAs run
-            const char* btb = bt + buf * BT_BYTES;
+        // Weight panels ride a 2-deep ring: the panel of group g+2 is loaded into registers at the start of group g and
+        // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
+        // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
+        auto taps = [&](int grp, const char* btb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int toff = tap_halo_off(grp, j);
@@ -250,8 +247,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], a[mi], bf[ni]);
             }
-            if (more) store_b(pbn, buf ^ 1);               // the other buffer was last read before the previous barrier
+        };
+        Piece<T> pbA[BP], pbB[BP];
+        if (NG > 1) load_b(pbA, chunk, 1);
+#pragma unroll 1
+        for (int grp = 0; grp < NG; grp += 2) {
+            if (grp + 2 < NG) load_b(pbB, chunk, grp + 2);
+            taps(grp, bt);
+            if (grp + 1 < NG) store_b(pbA, 1);
             __syncthreads();
+            if (grp + 1 < NG) {
+                if (grp + 3 < NG) load_b(pbA, chunk, grp + 3);
+                taps(grp + 1, bt + BT_BYTES);
+                if (grp + 2 < NG) store_b(pbB, 0);
+                __syncthreads();
+            }
         }
     }
 
