@@ -11,6 +11,44 @@ from . import _lib as L
 from ._lib import lib, check, ptr, stream
 
 
+_SIDE = {}
+FORK_BACKWARD = True       # weight-gradient kernels run on a side stream next to the data-gradient kernels
+
+
+class _Fork:
+    """`with _Fork() as f:` runs its body on a side HIP stream that first waits for the current stream; f.join() makes
+    the current stream wait for the side work.  The weight gradient of a layer and the data gradient of the same layer
+    only share inputs, so the two kernels (often too small to fill 256 CUs each) overlap.  Captured graphs record the
+    fork/join as dependencies."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        key = (device.index if device.index is not None else torch.cuda.current_device())
+        if key not in _SIDE:
+            _SIDE[key] = torch.cuda.Stream(device=device)
+        self.side = _SIDE[key] if FORK_BACKWARD else None
+        self.ctx = None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+
+
 def _cl_dims(t):
     assert t.dim() == 5 and t.is_contiguous(), "channels-last [B, D, H, W, C] contiguous tensor expected"
     return t.shape
@@ -231,17 +269,20 @@ class ConvDown(torch.autograd.Function):
         if act not in (None, "none") and not (premasked and act == "relu"):
             g = _act_bwd(g, y, act)
         dx = dw = db = None
+        want_db = has_bias and ctx.needs_input_grad[2]
+        fork = _Fork(g.device)
+        with fork:
+            if ctx.needs_input_grad[1]:
+                if want_db:
+                    dw, db = _conv_wgrad(g, x, nd, weight.shape, want_sbias=True)
+                else:
+                    dw = _conv_wgrad(g, x, nd, weight.shape)
+            elif want_db:
+                db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
             wp_up = pack_weight(weight, nd, True, g.dtype)
             dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None)
-        want_db = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            if want_db:
-                dw, db = _conv_wgrad(g, x, nd, weight.shape, want_sbias=True)
-            else:
-                dw = _conv_wgrad(g, x, nd, weight.shape)
-        elif want_db:
-            db = _channel_sum(g)
+        fork.join(dw, db)
         return dx, dw, db, None, None, None, None
 
 
@@ -266,13 +307,16 @@ class ConvUp(torch.autograd.Function):
         if act not in (None, "none") and not (premasked and act == "relu"):
             g = _act_bwd(g, y, act)
         dx = dw = db = None
+        fork = _Fork(g.device)
+        with fork:
+            if ctx.needs_input_grad[1]:
+                dw = _conv_wgrad(x, g, nd, weight.shape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
             wp_dn = pack_weight(weight, nd, False, g.dtype)
             dx = _conv_down(g, wp_dn, None, x if in_relu else None, weight.shape[0], nd, None)
-        if ctx.needs_input_grad[1]:
-            dw = _conv_wgrad(x, g, nd, weight.shape)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = _channel_sum(g)
+        fork.join(dw, db)
         return dx, dw, db, None, None, None, None
 
 
@@ -375,16 +419,19 @@ class Linear(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         dx = dw = db = None
+        fork = _Fork(g.device)
+        with fork:
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                if has_bias and ctx.needs_input_grad[2]:
+                    db = _empty((N,), torch.float32, g)
+                check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, stream()), "linear_bwd_weight")
+            elif has_bias and ctx.needs_input_grad[2]:
+                db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), torch.float32, g)
             check(lib.cvae_linear_bwd_data(ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, stream()), "linear_bwd_data")
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            if has_bias and ctx.needs_input_grad[2]:
-                db = _empty((N,), torch.float32, g)
-            check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, stream()), "linear_bwd_weight")
-        elif has_bias and ctx.needs_input_grad[2]:
-            db = _channel_sum(g)
+        fork.join(dw, db)
         return dx, dw, db, None
 
 
