@@ -343,6 +343,34 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// All conv weights of a model packed in ONE launch (the table rides in the kernel arguments): the per-step re-pack of the
+// fp32 masters is ~12 tiny tensors, i.e. pure launch latency when issued one by one.
+#define PACK_MAX 24
+struct PackTable {
+    const float* w[PACK_MAX];
+    void* out[PACK_MAX];
+    int Cs[PACK_MAX], Cl[PACK_MAX], for_up[PACK_MAX], blk_start[PACK_MAX + 1];
+    int count, taps;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackTable tb) {
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    const int Cs = tb.Cs[ti], Cl = tb.Cl[ti], taps = tb.taps, for_up = tb.for_up[ti];
+    const float* w = tb.w[ti];
+    T* out = (T*)tb.out[ti];
+    const int64_t n = (int64_t)Cs * Cl * taps;
+    const int nb = tb.blk_start[ti + 1] - tb.blk_start[ti];
+    for (int64_t i = ((int64_t)blockIdx.x - tb.blk_start[ti]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+        const int e = (int)(i & 15);
+        int64_t rr = i >> 4;
+        int cs, cl, tap;
+        if (!for_up) { cs = (int)(rr % Cs); rr /= Cs; const int ch = (int)(rr % (Cl / 16)); tap = (int)(rr / (Cl / 16)); cl = ch * 16 + e; }
+        else { cl = (int)(rr % Cl); rr /= Cl; const int ch = (int)(rr % (Cs / 16)); tap = (int)(rr / (Cs / 16)); cs = ch * 16 + e; }
+        out[i] = from_f32<T>(w[((int64_t)cs * Cl + cl) * taps + tap]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- wgrad
 // Workgroup: 4 waves; block of 64 cs x 32 cl; one depth tap kd (3D) / all taps (2D); wave w owns kh = w, kw = 0..3.
 template <typename T, int ND>
@@ -576,6 +604,38 @@ extern "C" int cvae_conv_pack_weight(const float* w, void* packed, int64_t Cs, i
     else if (dtype == CVAE_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, (int)Cs, (int)Cl, taps, for_up);
     else return CVAE_E_DTYPE;
     CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+extern "C" int cvae_conv_pack_weights(const float* const* w, void* const* packed, const int64_t* Cs, const int64_t* Cl, const int* for_up,
+                                       int count, int nd, int dtype, void* stream) {
+    if ((nd != 2 && nd != 3) || count < 0) return CVAE_E_BADSHAPE;
+    if (count == 0) return CVAE_OK;
+    if (!w || !packed || !Cs || !Cl || !for_up) return CVAE_E_NULLPTR;
+    if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
+    for (int c0 = 0; c0 < count; c0 += PACK_MAX) {
+        PackTable tb;
+        const int cnt = (count - c0 < PACK_MAX) ? count - c0 : PACK_MAX;
+        tb.taps = (nd == 3) ? 64 : 16;
+        int blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t cs = Cs[c0 + i], cl = Cl[c0 + i];
+            if (cs <= 0 || cl <= 0) return CVAE_E_BADSHAPE;
+            if ((!for_up[c0 + i] && cl % 16) || (for_up[c0 + i] && cs % 16)) return CVAE_E_UNSUPPORTED;
+            if (!w[c0 + i] || !packed[c0 + i]) return CVAE_E_NULLPTR;
+            tb.w[i] = w[c0 + i]; tb.out[i] = packed[c0 + i]; tb.Cs[i] = (int)cs; tb.Cl[i] = (int)cl; tb.for_up[i] = for_up[c0 + i];
+            tb.blk_start[i] = blocks;
+            int64_t nb = (cs * cl * tb.taps + 256 * 8 - 1) / (256 * 8);
+            if (nb > 1024) nb = 1024;
+            if (nb < 1) nb = 1;
+            blocks += (int)nb;
+        }
+        tb.blk_start[cnt] = blocks;
+        tb.count = cnt;
+        if (dtype == CVAE_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb);
+        else hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb);
+        CVAE_CHECK_LAUNCH();
+    }
     return CVAE_OK;
 }
 

@@ -157,9 +157,53 @@ extern "C" int cvae_act_fwd(const void* x, void* y, int64_t n, int act, int dtyp
 }
 
 // ------------------------------------------------------------------------------------- channel sum
-// x [P, C] channels-last.  Block = 256 threads = (256 / CL) rows x CL channel-lanes (CL = min(C, 256)); lanes run along C
-// so loads are contiguous; blockIdx.y walks channel chunks of CL, blockIdx.x strides the rows; partials meet in LDS, one
-// atomic per (block, channel).
+// x [P, C] channels-last -> out[c] = sum_p x[p, c].  Each thread owns one 16-byte group of channels (8 bf16 / 4 fp32) and
+// strides the rows, so every load is a full 16 B per lane and a block row covers whole 128-byte lines; block partials
+// meet in LDS.  A single-block-per-chunk launch (small inputs) writes the result directly — no memset, no atomics;
+// larger inputs spread rows over blockIdx.x and finish with one atomic per (block, channel) into a zeroed `out`.
+// C == 1 is the plain sum of all elements (rows of VEC "pseudo-channels" folded into out[0]).
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_vec_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t P, int64_t C, int fold, int direct) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float red[256 * VEC];
+    const int groups = (int)(C / VEC);                      // 16-byte groups per row (C % VEC == 0)
+    const int gpb = groups < 256 ? groups : 256;            // groups handled per block row
+    const int rows = 256 / gpb;
+    const int gi = threadIdx.x % gpb, ri = threadIdx.x / gpb;
+    const int64_t grp = (int64_t)blockIdx.y * gpb + gi;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    if (ri < rows && grp < groups) {
+        for (int64_t p = (int64_t)blockIdx.x * rows + ri; p < P; p += (int64_t)gridDim.x * rows) {
+            const uint4 v = *(const uint4*)(x + p * C + grp * VEC);
+            const T* pv = (const T*)&v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += to_f32(pv[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = acc[e];
+    __syncthreads();
+    if (ri == 0 && grp < groups) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float s = 0.f;
+            for (int r2 = 0; r2 < rows; ++r2) s += red[(r2 * gpb + gi) * VEC + e];
+            acc[e] = s;
+        }
+        if (fold) {                                         // C == 1 viewed as [P / VEC, VEC]
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s += acc[e];
+            if (direct) out[0] = s; else atomicAdd(&out[0], s);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { if (direct) out[grp * VEC + e] = acc[e]; else atomicAdd(&out[grp * VEC + e], acc[e]); }
+        }
+    }
+}
+// scalar fallback (C not a multiple of the vector width)
 template <typename T>
 __global__ void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t P, int64_t C) {
     __shared__ float red[256];
@@ -178,24 +222,45 @@ __global__ void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ 
         atomicAdd(&out[c], s);
     }
 }
-extern "C" int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* stream) {
-    if (P < 0 || C <= 0) return CVAE_E_BADSHAPE;
-    if (!out) return CVAE_E_NULLPTR;
-    if (hipMemsetAsync(out, 0, C * sizeof(float), (hipStream_t)stream) != hipSuccess) return CVAE_E_LAUNCH;
-    if (P == 0) return CVAE_OK;
-    if (!x) return CVAE_E_NULLPTR;
+template <typename T>
+static int channel_sum_launch(const T* x, float* out, int64_t P, int64_t C, hipStream_t st) {
+    constexpr int VEC = 16 / sizeof(T);
+    int64_t Pv = P, Cv = C;
+    int fold = 0;
+    if (C == 1 && P % VEC == 0 && P >= VEC) { Pv = P / VEC; Cv = VEC; fold = 1; }
+    if (Cv % VEC == 0 && (((uintptr_t)x) & 15) == 0) {
+        const int groups = (int)(Cv / VEC), gpb = groups < 256 ? groups : 256, rows = 256 / gpb;
+        const int64_t gy = (groups + gpb - 1) / gpb;
+        if (gy > 65535) return CVAE_E_BADSHAPE;
+        const int64_t passes = (Pv + rows - 1) / rows;       // row passes if one block did everything
+        int64_t gx = 1;
+        if (passes > 256) { gx = (passes + 63) / 64; const int64_t cap = (2048 + gy - 1) / gy; if (gx > cap) gx = cap; }
+        const int direct = gx == 1;
+        if (!direct && hipMemsetAsync(out, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
+        hipLaunchKernelGGL(channel_sum_vec_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, out, Pv, Cv, fold, direct);
+        return CVAE_OK;
+    }
+    if (hipMemsetAsync(out, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
     const int cl = (C >= 256) ? 256 : (int)C, rows = 256 / cl;
     const int64_t gy = (C + cl - 1) / cl;
     if (gy > 65535) return CVAE_E_BADSHAPE;
-    // every block ends with `cl` atomics onto the same words: give each block >= 64 row-passes of work
     int64_t gx = (P + (int64_t)rows * 64 - 1) / ((int64_t)rows * 64);
     const int64_t cap = (2048 + gy - 1) / gy;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-    dim3 grid((unsigned)gx, (unsigned)gy);
-    if (dtype == CVAE_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, P, C);
-    else if (dtype == CVAE_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, P, C);
+    hipLaunchKernelGGL(channel_sum_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, out, P, C);
+    return CVAE_OK;
+}
+extern "C" int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* stream) {
+    if (P < 0 || C <= 0) return CVAE_E_BADSHAPE;
+    if (!out) return CVAE_E_NULLPTR;
+    if (P == 0) return hipMemsetAsync(out, 0, C * sizeof(float), (hipStream_t)stream) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
+    if (!x) return CVAE_E_NULLPTR;
+    int rc;
+    if (dtype == CVAE_F32) rc = channel_sum_launch<float>((const float*)x, out, P, C, (hipStream_t)stream);
+    else if (dtype == CVAE_BF16) rc = channel_sum_launch<bf16>((const bf16*)x, out, P, C, (hipStream_t)stream);
     else return CVAE_E_DTYPE;
+    if (rc != CVAE_OK) return rc;
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

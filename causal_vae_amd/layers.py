@@ -29,8 +29,8 @@ class _ConvBase:
     _nd = 2
     _fn = ops.ConvDown
 
-    def forward_cl(self, x_cl, act=None, in_is_relu_out=False, grad_premasked=False):
-        return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked)
+    def forward_cl(self, x_cl, act=None, in_is_relu_out=False, grad_premasked=False, packed=None):
+        return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked, packed)
 
     def forward(self, x):                                   # NC(D)HW fp32 in / out, like the stock layer
         require_gpu(x)
@@ -118,11 +118,12 @@ class ConvStack(nn.Sequential):
         if not convs or x.shape[1] != convs[0].in_channels:
             raise RuntimeError(f"expected input with {convs[0].in_channels if convs else '?'} channels, got {tuple(x.shape)}")
         h = ops.ToChannelsLast.apply(x, self.compute_dtype)
+        packed = iter(ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))   # one launch for the stack
         i, prev_act = 0, None
         while i < len(mods) and isinstance(mods[i], _ConvBase):
             act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
             # every consumer of a ReLU output inside this stack (next conv, final pool) folds that ReLU's mask
-            h = mods[i].forward_cl(h, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu"))
+            h = mods[i].forward_cl(h, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu"), packed=next(packed))
             prev_act = act
             i += 2 if act else 1
         return h, mods[i:], prev_act
@@ -148,13 +149,15 @@ class DeconvStack(nn.Sequential):
     def forward_cl(self, h):
         mods = list(self)
         x = ops.ToChannelsLast.apply(h, self.compute_dtype)
+        convs = [m for m in mods if isinstance(m, _ConvBase)]
+        packed = iter(ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))   # one launch for the stack
         i, prev_act = 0, None
         while i < len(mods):
             if not isinstance(mods[i], _ConvBase):
                 raise CvaeError(f"DeconvStack: unexpected layer {type(mods[i]).__name__} at index {i}")
             act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
             nxt = i + (2 if act else 1)
-            x = mods[i].forward_cl(x, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu" and nxt < len(mods)))
+            x = mods[i].forward_cl(x, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu" and nxt < len(mods)), packed=next(packed))
             prev_act = act
             i = nxt
         return x

@@ -198,6 +198,30 @@ def pack_weight(w, nd, for_up, dtype):
     return out
 
 
+def pack_weights(weights, nd, dtype):
+    """Pack the weights of several conv layers for BOTH directions in one launch.
+    Returns [(packed_down, packed_up)] per weight; a Cl == 1 layer gets its fp32 weight back for both (not packed)."""
+    import ctypes as C
+    outs, ws, ps, cs, cl, fu = [], [], [], [], [], []
+    for w in weights:
+        w = w.contiguous()
+        Cs, Cl = w.shape[0], w.shape[1]
+        if Cl == 1:
+            outs.append((w, w))
+            continue
+        n = Cs * Cl * _taps(nd)
+        both = torch.empty(2 * n, dtype=dtype, device=w.device)
+        d, u = both[:n], both[n:]
+        outs.append((d, u))
+        for for_up, buf in ((0, d), (1, u)):
+            ws.append(w.data_ptr()); ps.append(buf.data_ptr()); cs.append(Cs); cl.append(Cl); fu.append(for_up)
+    k = len(ws)
+    if k:
+        check(lib.cvae_conv_pack_weights((C.c_void_p * k)(*ws), (C.c_void_p * k)(*ps), (C.c_int64 * k)(*cs), (C.c_int64 * k)(*cl),
+                                         (C.c_int * k)(*fu), k, nd, L.dtype_code(dtype), stream()), "conv_pack_weights")
+    return outs
+
+
 def _conv_down(Lt, wp, bias, mask, Cs, nd, act):
     B, ld, lh, lw, Cl = _cl_dims(Lt)
     sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
@@ -252,12 +276,13 @@ class ConvDown(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked):
+    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None):
         L.require_gpu(x, weight, bias)
         Cs = weight.shape[0]
-        wp = pack_weight(weight, nd, False, x.dtype)
+        wp = packed[0] if packed is not None else pack_weight(weight, nd, False, x.dtype)
         y = _conv_down(x, wp, bias, None, Cs, nd, act)
         ctx.save_for_backward(x, weight, y)
+        ctx.packed_bwd = packed[1] if packed is not None else None
         ctx.cfg = (nd, act, in_is_relu_out, grad_premasked, bias is not None)
         return y
 
@@ -280,22 +305,23 @@ class ConvDown(torch.autograd.Function):
             elif want_db:
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
-            wp_up = pack_weight(weight, nd, True, g.dtype)
+            wp_up = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, True, g.dtype)
             dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None)
         fork.join(dw, db)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class ConvUp(torch.autograd.Function):
     """nn.ConvTranspose{2,3}d(k=4, s=2, p=1) + bias + activation on channels-last tensors (flags as ConvDown)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked):
+    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None):
         L.require_gpu(x, weight, bias)
         Cl = weight.shape[1]
-        wp = pack_weight(weight, nd, True, x.dtype)
+        wp = packed[1] if packed is not None else pack_weight(weight, nd, True, x.dtype)
         y = _conv_up(x, wp, bias, None, Cl, nd, act)
         ctx.save_for_backward(x, weight, y)
+        ctx.packed_bwd = packed[0] if packed is not None else None
         ctx.cfg = (nd, act, in_is_relu_out, grad_premasked, bias is not None)
         return y
 
@@ -314,10 +340,10 @@ class ConvUp(torch.autograd.Function):
             if has_bias and ctx.needs_input_grad[2]:
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
-            wp_dn = pack_weight(weight, nd, False, g.dtype)
+            wp_dn = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, False, g.dtype)
             dx = _conv_down(g, wp_dn, None, x if in_relu else None, weight.shape[0], nd, None)
         fork.join(dw, db)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class Activation(torch.autograd.Function):

@@ -78,6 +78,10 @@ int cvae_onehot_panel(const int64_t* t, float* dst, int64_t B, int64_t n_classes
 size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, int dtype);
 int cvae_conv_pack_weight(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, int dtype, void* stream);
 
+/* The same packing for a LIST of weights in one launch (host arrays of `count` entries; all tensors share nd and dtype). */
+int cvae_conv_pack_weights(const float* const* w, void* const* packed, const int64_t* Cs, const int64_t* Cl, const int* for_up,
+                           int count, int nd, int dtype, void* stream);
+
 /* S = act(gather(L, w) + bias) [then * (mask > 0) if mask != NULL].  bias fp32 [Cs] or NULL; mask has S's shape/dtype. */
 int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
                    int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,

@@ -255,6 +255,16 @@ def test_batchnorm1d_train_and_eval(B):
     close(ye.cpu(), F.batch_norm(x.detach(), rm_ref, rv_ref, w, b, False, 0.1, 1e-5), torch.float32, "bn eval")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("P,C", [(1, 64), (4, 512), (4, 16384), (300000, 32), (1 << 20, 1), (1000, 19), (4097, 256), (77, 8)])
+def test_channel_sum(P, C, dtype):
+    g = torch.Generator().manual_seed(13)
+    x = rnd(torch.randn(P, C, generator=g), dtype)
+    out = ops._channel_sum(x.to(DEV).to(dtype))
+    ref = x.double().sum(0).float()
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4 * float(x.abs().sum(0).max()))
+
+
 def test_activation_standalone():
     x = torch.randn(1000)
     for act, f in (("relu", F.relu), ("sigmoid", torch.sigmoid), ("leaky02", lambda v: F.leaky_relu(v, 0.2))):
