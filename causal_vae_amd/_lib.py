@@ -52,16 +52,17 @@ SIGNATURES = {
     "cvae_upsample_linear_fwd": [_p, _p] + [_i64] * 8 + [_i, _p],
     "cvae_upsample_linear_bwd": [_p, _p] + [_i64] * 8 + [_i, _p],
     "cvae_linear_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p],
-    "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
-    "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p],
+    "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p],
     "cvae_bn1d_train_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _p],
     "cvae_bn1d_train_bwd": [_p] * 8 + [_i64, _i64, _p],
     "cvae_bn1d_eval_fwd": [_p] * 6 + [_i64, _i64, _f, _p],
     "cvae_philox_normal": [_p, _i64, _u64, _u64, _p, _p],
     "cvae_reparam_kld_fwd": [_p, _p, _p, _p, _p, _i64, _p],
-    "cvae_reparam_kld_bwd": [_p] * 7 + [_i64, _p],
+    "cvae_reparam_kld_bwd": [_p, _p, _f] + [_p] * 5 + [_i64, _p],
     "cvae_sse_fwd": [_p, _p, _p, _i64, _p],
-    "cvae_sse_bwd": [_p, _p, _p, _p, _i64, _p],
+    "cvae_sse_bwd": [_p, _p, _p, _f, _p, _i64, _p],
+    "cvae_combine3": [_p, _f, _f, _p],
     "cvae_bce_fwd": [_p, _p, _p, _i64, _p],
     "cvae_bce_bwd": [_p, _p, _p, _p, _i64, _p],
     "cvae_sum_fwd": [_p, _p, _i64, _p],

@@ -11,10 +11,8 @@ from .. import ops
 
 
 def loss_function(recon_x, x, m_hat, m, mu, logvar, gamma=2000.0):
-    recon_loss = ops.sse(recon_x, x)            # F.mse_loss(..., reduction='sum')
-    m_loss = ops.sse(m_hat, m)
-    kld = ops.KLD.apply(mu, logvar)
-    loss = recon_loss + (gamma * m_loss) + kld
+    # recon = MSE-sum(recon_x, x); m_loss = MSE-sum(m_hat, m); kld = -0.5*sum(1 + logvar - mu^2 - e^logvar); loss = recon + gamma*m_loss + kld
+    loss, recon_loss, m_loss, _kld = ops.Elbo.apply(recon_x, x, m_hat, m, mu, logvar, gamma)
     return loss, recon_loss, m_loss
 
 

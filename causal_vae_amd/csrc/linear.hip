@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void linear_fwd_skinny_kernel(const float* __r
 }
 // dx[m][k] += sum_{n in chunk} dy[m][n] W[n][k].  One thread per k (coalesced W rows), blockIdx.y walks n-chunks.
 __global__ __launch_bounds__(256) void linear_bwd_data_skinny_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
-                                                                     int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx, int64_t nchunk) {
+                                                                     int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx, int64_t nchunk,
+                                                                     const float* __restrict__ yact, int act) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.y * nchunk, n1 = min(N, n0 + nchunk);
     float acc[SK_M];
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256) void linear_bwd_data_skinny_kernel(const float
         for (int64_t n = n0; n < n1; ++n) {
             const float w = W[n * K + k];
 #pragma unroll
-            for (int m = 0; m < SK_M; ++m) if (m < M) acc[m] += w * dy[m * ldy + n];     // uniform address: scalar loads
+            for (int m = 0; m < SK_M; ++m)
+                if (m < M) acc[m] += w * dy[m * ldy + n] * (yact ? act_grad_from_out(yact[m * ldy + n], act) : 1.f);   // uniform address: scalar loads
         }
 #pragma unroll
         for (int m = 0; m < SK_M; ++m) if (m < M) atomicAdd(&dx[m * ldx + k], acc[m]);
@@ -172,14 +174,21 @@ __global__ __launch_bounds__(256) void linear_bwd_data_skinny_kernel(const float
 }
 // dW[n][k] = sum_m dy[m][n] x[m][k]: one thread per element of the flattened [N*K] weight (coalesced stores).
 __global__ __launch_bounds__(256) void linear_bwd_weight_skinny_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dW,
-                                                                       int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx) {
+                                                                       float* __restrict__ db, int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx,
+                                                                       const float* __restrict__ yact, int act) {
     const int64_t total = N * K;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t n = i / K, k = i - n * K;
-        float acc = 0.f;
+        float acc = 0.f, bsum = 0.f;
 #pragma unroll
-        for (int m = 0; m < SK_M; ++m) if (m < M) acc += dy[m * ldy + n] * x[m * ldx + k];
+        for (int m = 0; m < SK_M; ++m)
+            if (m < M) {
+                const float g = dy[m * ldy + n] * (yact ? act_grad_from_out(yact[m * ldy + n], act) : 1.f);
+                acc += g * x[m * ldx + k];
+                bsum += g;
+            }
         dW[i] = acc;
+        if (db && k == 0) db[n] = bsum;                       // the bias gradient rides along (column sums of dy)
     }
 }
 
@@ -208,8 +217,10 @@ extern "C" int cvae_linear_fwd(const float* x, const float* W, const float* b, f
     return gemm_f32(x, W, y, b, M, N, K, x_stride, 1, 1, K, y_stride, act, (hipStream_t)stream);
 }
 extern "C" int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N,
-                                    int64_t dy_stride, int64_t dx_stride, void* stream) {
+                                    int64_t dy_stride, int64_t dx_stride, const float* y_act, int act, void* stream) {
     if (dy_stride < N) return CVAE_E_BADSHAPE;
+    if (act == CVAE_ACT_NONE) y_act = nullptr;
+    if (y_act && !(M > 0 && M <= SK_M)) return CVAE_E_UNSUPPORTED;      // fused activation gradient: skinny path only
     if (M > 0 && M <= SK_M && K >= 1024 && N > 0 && dx_stride >= K) {
         if (!dy || !W || !dx) return CVAE_E_NULLPTR;
         hipStream_t st = (hipStream_t)stream;
@@ -220,20 +231,35 @@ extern "C" int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, 
         if (chunks < 1) chunks = 1;
         const int64_t nchunk = (N + chunks - 1) / chunks;
         chunks = (N + nchunk - 1) / nchunk;
-        hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk);
+        hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk, y_act, act);
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
+    if (y_act) {                                            // M <= 16 but K < 1024: materialise-free path = one block row per k-chunk of the generic grid
+        if (!dy || !W || !dx) return CVAE_E_NULLPTR;
+        hipStream_t st = (hipStream_t)stream;
+        if (hipMemset2DAsync(dx, (size_t)dx_stride * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
+        const int64_t kb = (K + 255) / 256;
+        int64_t chunks = N / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+        const int64_t nchunk = (N + chunks - 1) / chunks;
+        chunks = (N + nchunk - 1) / nchunk;
+        hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk, y_act, act);
         CVAE_CHECK_LAUNCH();
         return CVAE_OK;
     }
     return gemm_f32(dy, W, dx, nullptr, M, K, N, dy_stride, 1, K, 1, dx_stride, CVAE_ACT_NONE, (hipStream_t)stream);
 }
 extern "C" int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N,
-                                      int64_t dy_stride, int64_t x_stride, void* stream) {
+                                      int64_t dy_stride, int64_t x_stride, const float* y_act, int act, void* stream) {
     if (dy_stride < N || x_stride < K || M <= 0) return CVAE_E_BADSHAPE;
+    if (act == CVAE_ACT_NONE) y_act = nullptr;
+    if (y_act && M > SK_M) return CVAE_E_UNSUPPORTED;
     int rc = CVAE_OK;
     if (M <= SK_M && N > 0 && K > 0) {
         if (!dy || !x || !dW) return CVAE_E_NULLPTR;
-        hipLaunchKernelGGL(linear_bwd_weight_skinny_kernel, dim3(cvae_grid_1d(N * K, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, x, dW, (int)M, K, N, dy_stride, x_stride);
+        hipLaunchKernelGGL(linear_bwd_weight_skinny_kernel, dim3(cvae_grid_1d(N * K, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db, (int)M, K, N, dy_stride, x_stride, y_act, act);
         CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
     } else {
         rc = gemm_f32(dy, x, dW, nullptr, N, K, M, 1, dy_stride, x_stride, 1, K, CVAE_ACT_NONE, (hipStream_t)stream);
     }

@@ -56,25 +56,25 @@ extern "C" int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t 
 
 // Elementwise two-input map with a device-scalar upstream gradient.
 template <typename F>
-__global__ void map2_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout, float* __restrict__ o, int64_t n, F f) {
-    const float g = gout ? *gout : 1.f;
+__global__ void map2_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout, float* __restrict__ o, int64_t n, F f, float scale) {
+    const float g = (gout ? *gout : 1.f) * scale;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = f(a[i], b[i]) * g;
 }
 struct SseB { __device__ float operator()(float a, float b) const { return 2.f * (a - b); } };
 struct BceB {   // d/dp of BceF; aten: (p - x) / max((1-p)*p, 1e-12)
     __device__ float operator()(float p, float x) const { return (p - x) / fmaxf((1.f - p) * p, 1e-12f); }
 };
-#define LAUNCH_MAP2(F, a, b, g, o, n, stream)                                                                        \
+#define LAUNCH_MAP2(F, a, b, g, o, n, scale, stream)                                                                        \
     do {                                                                                                              \
         if ((n) < 0) return CVAE_E_BADSHAPE;                                                                          \
         if ((n) == 0) return CVAE_OK;                                                                                 \
         if (!(a) || !(b) || !(o)) return CVAE_E_NULLPTR;                                                              \
-        hipLaunchKernelGGL((map2_kernel<F>), dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)(stream), a, b, g, o, n, F()); \
+        hipLaunchKernelGGL((map2_kernel<F>), dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)(stream), a, b, g, o, n, F(), scale); \
         CVAE_CHECK_LAUNCH();                                                                                          \
         return CVAE_OK;                                                                                               \
     } while (0)
-extern "C" int cvae_sse_bwd(const float* a, const float* b, const float* gout, float* da, int64_t n, void* stream) { LAUNCH_MAP2(SseB, a, b, gout, da, n, stream); }
-extern "C" int cvae_bce_bwd(const float* p, const float* x, const float* gout, float* dp, int64_t n, void* stream) { LAUNCH_MAP2(BceB, p, x, gout, dp, n, stream); }
+extern "C" int cvae_sse_bwd(const float* a, const float* b, const float* gout, float scale, float* da, int64_t n, void* stream) { LAUNCH_MAP2(SseB, a, b, gout, da, n, scale, stream); }
+extern "C" int cvae_bce_bwd(const float* p, const float* x, const float* gout, float* dp, int64_t n, void* stream) { LAUNCH_MAP2(BceB, p, x, gout, dp, n, 1.f, stream); }
 
 // ------------------------------------------------------------------------------------- vessel recon terms
 __device__ __forceinline__ float vessel_pos_weight(float sum_x, int64_t n) {
@@ -146,10 +146,10 @@ extern "C" int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const 
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
-__global__ void reparam_kld_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ gkld, const float* __restrict__ mu,
+__global__ void reparam_kld_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ gkld, float gk_scale, const float* __restrict__ mu,
                                        const float* __restrict__ logvar, const float* __restrict__ eps, float* __restrict__ dmu,
                                        float* __restrict__ dlogvar, int64_t n) {
-    const float gk = gkld ? *gkld : 0.f;
+    const float gk = gkld ? *gkld * gk_scale : 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float m = mu[i], lv = logvar[i];
         float gm = gk * m, gl = gk * 0.5f * (expf(lv) - 1.f);
@@ -158,12 +158,23 @@ __global__ void reparam_kld_bwd_kernel(const float* __restrict__ dz, const float
         dlogvar[i] = gl;
     }
 }
-extern "C" int cvae_reparam_kld_bwd(const float* dz, const float* gkld, const float* mu, const float* logvar, const float* eps,
+extern "C" int cvae_reparam_kld_bwd(const float* dz, const float* gkld, float gk_scale, const float* mu, const float* logvar, const float* eps,
                                     float* dmu, float* dlogvar, int64_t n, void* stream) {
     if (n < 0) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!mu || !logvar || !dmu || !dlogvar || (dz && !eps)) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(reparam_kld_bwd_kernel, dim3(cvae_grid_1d(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, dz, gkld, mu, logvar, eps, dmu, dlogvar, n);
+    hipLaunchKernelGGL(reparam_kld_bwd_kernel, dim3(cvae_grid_1d(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, dz, gkld, gk_scale, mu, logvar, eps, dmu, dlogvar, n);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// out4 = {total, a, b, c} with total = a + wb * b + wc * c  (the ELBO of causal_cascade/train.py:16 from its three terms)
+__global__ void combine3_kernel(float* __restrict__ out4, float wb, float wc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out4[0] = out4[1] + wb * out4[2] + wc * out4[3];
+}
+extern "C" int cvae_combine3(float* out4, float wb, float wc, void* stream) {
+    if (!out4) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(combine3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out4, wb, wc);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

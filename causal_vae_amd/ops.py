@@ -440,10 +440,12 @@ class Linear(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         act, has_bias = ctx.cfg
         g = g.contiguous()
-        if act not in (None, "none"):
-            g = _act_bwd(g, y, act)
         M, K = x.shape
         N = weight.shape[0]
+        fused = act not in (None, "none") and M <= 16          # skinny kernels apply act'(y) on the fly
+        if act not in (None, "none") and not fused:
+            g = _act_bwd(g, y, act)
+        ya, ac = (ptr(y), L.act_code(act)) if fused else (None, L.ACT_NONE)
         dx = dw = db = None
         fork = _Fork(g.device)
         with fork:
@@ -451,12 +453,12 @@ class Linear(torch.autograd.Function):
                 dw = torch.empty_like(weight)
                 if has_bias and ctx.needs_input_grad[2]:
                     db = _empty((N,), torch.float32, g)
-                check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, stream()), "linear_bwd_weight")
+                check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, ya, ac, stream()), "linear_bwd_weight")
             elif has_bias and ctx.needs_input_grad[2]:
-                db = _channel_sum(g)
+                db = _channel_sum(_act_bwd(g, y, act) if fused else g)
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), torch.float32, g)
-            check(lib.cvae_linear_bwd_data(ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, stream()), "linear_bwd_data")
+            check(lib.cvae_linear_bwd_data(ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, stream()), "linear_bwd_data")
         fork.join(dw, db)
         return dx, dw, db, None
 
@@ -537,7 +539,7 @@ class Reparameterize(torch.autograd.Function):
         mu, logvar, eps = ctx.saved_tensors
         g = g.contiguous()
         dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
-        check(lib.cvae_reparam_kld_bwd(ptr(g), None, ptr(mu), ptr(logvar), ptr(eps), ptr(dmu), ptr(dlv), mu.numel(), stream()), "reparam_bwd")
+        check(lib.cvae_reparam_kld_bwd(ptr(g), None, 1.0, ptr(mu), ptr(logvar), ptr(eps), ptr(dmu), ptr(dlv), mu.numel(), stream()), "reparam_bwd")
         return dmu, dlv, None
 
 
@@ -558,7 +560,7 @@ class KLD(torch.autograd.Function):
         mu, logvar = ctx.saved_tensors
         g = g.contiguous()
         dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
-        check(lib.cvae_reparam_kld_bwd(None, ptr(g), ptr(mu), ptr(logvar), None, ptr(dmu), ptr(dlv), mu.numel(), stream()), "kld_bwd")
+        check(lib.cvae_reparam_kld_bwd(None, ptr(g), 1.0, ptr(mu), ptr(logvar), None, ptr(dmu), ptr(dlv), mu.numel(), stream()), "kld_bwd")
         return dmu, dlv
 
 
@@ -585,9 +587,65 @@ class _PairLoss(torch.autograd.Function):
         a, b = ctx.saved_tensors
         g = g.contiguous()
         da = torch.empty_like(a)
-        bwd = lib.cvae_sse_bwd if ctx.kind == "sse" else lib.cvae_bce_bwd
-        check(bwd(ptr(a), ptr(b), ptr(g), ptr(da), a.numel(), stream()), ctx.kind + "_bwd")
+        if ctx.kind == "sse":
+            check(lib.cvae_sse_bwd(ptr(a), ptr(b), ptr(g), 1.0, ptr(da), a.numel(), stream()), "sse_bwd")
+        else:
+            check(lib.cvae_bce_bwd(ptr(a), ptr(b), ptr(g), ptr(da), a.numel(), stream()), "bce_bwd")
         return da, None, None
+
+
+class Elbo(torch.autograd.Function):
+    """loss = SSE(recon_x, x) + gamma * SSE(m_hat, m) + KLD(mu, logvar)   (causal_cascade/train.py:5-17) in one node:
+    one zeroed 4-float buffer, three reductions, one combine; the backward scales each branch by the upstream gradient of
+    `loss` on the device (no host sync, no scalar torch kernels).  Returns (loss, recon, m_loss, kld)."""
+
+    @staticmethod
+    def forward(ctx, recon_x, x, m_hat, m, mu, logvar, gamma):
+        L.require_gpu(recon_x, x, m_hat, m, mu, logvar)
+        ts = [t.contiguous() for t in (recon_x, x, m_hat, m, mu, logvar)]
+        if any(t.dtype != torch.float32 for t in ts):
+            raise L.CvaeError("loss inputs must be float32")
+        recon_x, x, m_hat, m, mu, logvar = ts
+        if recon_x.shape != x.shape or m_hat.shape != m.shape:
+            raise RuntimeError(f"The size of tensor a {tuple(recon_x.shape)} must match the size of tensor b {tuple(x.shape)}")
+        buf = torch.zeros(4, dtype=torch.float32, device=x.device)
+        base = buf.data_ptr()
+        check(lib.cvae_sse_fwd(ptr(recon_x), ptr(x), base + 4, recon_x.numel(), stream()), "sse_fwd")
+        check(lib.cvae_sse_fwd(ptr(m_hat), ptr(m), base + 8, m.numel(), stream()), "sse_fwd")
+        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), None, None, base + 12, mu.numel(), stream()), "kld_fwd")
+        check(lib.cvae_combine3(base, float(gamma), 1.0, stream()), "combine3")
+        ctx.save_for_backward(*ts)
+        ctx.gamma = float(gamma)
+        ctx.set_materialize_grads(False)
+        return buf[0], buf[1], buf[2], buf[3]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_recon, g_m, g_kld):
+        recon_x, x, m_hat, m, mu, logvar = ctx.saved_tensors
+        gam = ctx.gamma
+        if g_recon is not None or g_m is not None or g_kld is not None:      # rare: someone back-propagates a single term too
+            z = torch.zeros((), dtype=torch.float32, device=x.device)
+            gl = g_loss if g_loss is not None else z
+            s_r = gl + (g_recon if g_recon is not None else z)
+            s_m = gam * gl + (g_m if g_m is not None else z)
+            s_k = gl + (g_kld if g_kld is not None else z)
+            scales = ((s_r.contiguous(), 1.0), (s_m.contiguous(), 1.0), (s_k.contiguous(), 1.0))
+        else:
+            if g_loss is None:
+                return None, None, None, None, None, None, None
+            gl = g_loss.contiguous()
+            scales = ((gl, 1.0), (gl, gam), (gl, 1.0))
+        d_recon = d_mhat = dmu = dlv = None
+        if ctx.needs_input_grad[0]:
+            d_recon = torch.empty_like(recon_x)
+            check(lib.cvae_sse_bwd(ptr(recon_x), ptr(x), ptr(scales[0][0]), scales[0][1], ptr(d_recon), x.numel(), stream()), "sse_bwd")
+        if ctx.needs_input_grad[2]:
+            d_mhat = torch.empty_like(m_hat)
+            check(lib.cvae_sse_bwd(ptr(m_hat), ptr(m), ptr(scales[1][0]), scales[1][1], ptr(d_mhat), m.numel(), stream()), "sse_bwd")
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+            check(lib.cvae_reparam_kld_bwd(None, ptr(scales[2][0]), scales[2][1], ptr(mu), ptr(logvar), None, ptr(dmu), ptr(dlv), mu.numel(), stream()), "kld_bwd")
+        return d_recon, None, d_mhat, None, dmu, dlv, None
 
 
 def sse(a, b):

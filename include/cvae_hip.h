@@ -123,12 +123,13 @@ int cvae_upsample_linear_bwd(const float* ddst, void* dsrc, int64_t B, int64_t d
 /* y[M, N] = act(x[M, K] @ W[N, K]^T + b).  workspace: 0 bytes needed; kept for ABI stability. */
 int cvae_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N,
                     int64_t x_stride, int64_t y_stride, int act, void* stream);
-/* dx[M, K] = dy[M, N] @ W[N, K] */
+/* dx[M, K] = g[M, N] @ W[N, K] with g = dy * act'(y_act) (y_act = the layer's saved OUTPUT, same shape/stride as dy; pass
+ * NULL / CVAE_ACT_NONE for g = dy).  The fused activation gradient is available for M <= 16 (the model's batch sizes). */
 int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N,
-                         int64_t dy_stride, int64_t dx_stride, void* stream);
-/* dW[N, K] = dy^T x ; db[N] = column sums of dy (db may be NULL).  Both overwritten. */
+                         int64_t dy_stride, int64_t dx_stride, const float* y_act, int act, void* stream);
+/* dW[N, K] = g^T x ; db[N] = column sums of g (db may be NULL).  Both overwritten.  g as above. */
 int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N,
-                           int64_t dy_stride, int64_t x_stride, void* stream);
+                           int64_t dy_stride, int64_t x_stride, const float* y_act, int act, void* stream);
 
 /* ---- BatchNorm1d --------------------------------------------------------------------------------------- */
 /* train: batch statistics (biased var) normalise; running stats updated with momentum (unbiased var). B >= 2. */
@@ -145,13 +146,16 @@ int cvae_bn1d_eval_fwd(const float* x, const float* w, const float* b, const flo
 int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const int* call_counter, void* stream);
 /* z = mu + eps*exp(logvar/2) (if z != NULL);  *kld += -0.5*sum(1 + logvar - mu^2 - exp(logvar)) (if kld != NULL). */
 int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* stream);
-/* dmu = dz + gk*mu ; dlogvar = dz*eps*0.5*exp(logvar/2) + gk*0.5*(exp(logvar) - 1); dz / gkld (device scalar) may be NULL. */
-int cvae_reparam_kld_bwd(const float* dz, const float* gkld, const float* mu, const float* logvar, const float* eps,
+/* dmu = dz + gk*mu ; dlogvar = dz*eps*0.5*exp(logvar/2) + gk*0.5*(exp(logvar) - 1), gk = *gkld * gk_scale;
+ * dz / gkld (device scalar) may be NULL. */
+int cvae_reparam_kld_bwd(const float* dz, const float* gkld, float gk_scale, const float* mu, const float* logvar, const float* eps,
                          float* dmu, float* dlogvar, int64_t n, void* stream);
 /* *out += sum (a - b)^2 */
 int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
-/* da = 2*(a - b) * (*gout)   (db = -da is formed by the caller when needed) */
-int cvae_sse_bwd(const float* a, const float* b, const float* gout, float* da, int64_t n, void* stream);
+/* da = 2*(a - b) * (*gout) * scale   (db = -da is formed by the caller when needed) */
+int cvae_sse_bwd(const float* a, const float* b, const float* gout, float scale, float* da, int64_t n, void* stream);
+/* out4[0] = out4[1] + wb*out4[2] + wc*out4[3]: total loss from its three terms, on the device */
+int cvae_combine3(float* out4, float wb, float wc, void* stream);
 /* F.binary_cross_entropy(p, x, reduction='sum') with torch's log clamp at -100 */
 int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* stream);
 int cvae_bce_bwd(const float* p, const float* x, const float* gout, float* dp, int64_t n, void* stream);
