@@ -185,13 +185,19 @@ __global__ __launch_bounds__(256) void channel_sum_vec_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = acc[e];
     __syncthreads();
+    // tree over the block's rows (all threads take part; rows need not be a power of two)
+    int span = 1;
+    while (span < rows) span <<= 1;
+    for (int sft = span >> 1; sft > 0; sft >>= 1) {
+        if (ri < sft && ri + sft < rows) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] += red[(threadIdx.x + sft * gpb) * VEC + e];
+        }
+        __syncthreads();
+    }
     if (ri == 0 && grp < groups) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float s = 0.f;
-            for (int r2 = 0; r2 < rows; ++r2) s += red[(r2 * gpb + gi) * VEC + e];
-            acc[e] = s;
-        }
+        for (int e = 0; e < VEC; ++e) acc[e] = red[threadIdx.x * VEC + e];
         if (fold) {                                         // C == 1 viewed as [P / VEC, VEC]
             float s = 0.f;
 #pragma unroll
@@ -234,7 +240,7 @@ static int channel_sum_launch(const T* x, float* out, int64_t P, int64_t C, hipS
         if (gy > 65535) return CVAE_E_BADSHAPE;
         const int64_t passes = (Pv + rows - 1) / rows;       // row passes if one block did everything
         int64_t gx = 1;
-        if (passes > 256) { gx = (passes + 63) / 64; const int64_t cap = (2048 + gy - 1) / gy; if (gx > cap) gx = cap; }
+        if (passes > 64) { gx = (passes + 7) / 8; const int64_t cap = (2048 + gy - 1) / gy; if (gx > cap) gx = cap; }   // >= 8 row passes per block
         const int direct = gx == 1;
         if (!direct && hipMemsetAsync(out, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
         hipLaunchKernelGGL(channel_sum_vec_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, out, Pv, Cv, fold, direct);

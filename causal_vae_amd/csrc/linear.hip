@@ -137,7 +137,17 @@ __global__ __launch_bounds__(256) void linear_fwd_skinny_kernel(const float* __r
 #pragma unroll
     for (int m = 0; m < SK_M; ++m) acc[m] = 0.f;
     const float* wr = W + n * K;
-    for (int64_t k = k0 + lane; k < k1; k += 64) {
+    int64_t k = k0 + lane;
+    for (; k + 192 < k1; k += 256) {                         // 4 independent 256-byte rows of W (and of each x row) in flight
+        const float w0 = wr[k], w1 = wr[k + 64], w2 = wr[k + 128], w3 = wr[k + 192];
+#pragma unroll
+        for (int m = 0; m < SK_M; ++m)
+            if (m < M) {
+                const float* xr = x + m * ldx + k;
+                acc[m] += w0 * xr[0] + w1 * xr[64] + w2 * xr[128] + w3 * xr[192];
+            }
+    }
+    for (; k < k1; k += 64) {
         const float w = wr[k];
 #pragma unroll
         for (int m = 0; m < SK_M; ++m) if (m < M) acc[m] += w * x[m * ldx + k];
@@ -158,16 +168,30 @@ __global__ __launch_bounds__(256) void linear_bwd_data_skinny_kernel(const float
                                                                      const float* __restrict__ yact, int act) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.y * nchunk, n1 = min(N, n0 + nchunk);
+    __shared__ float gs[SK_M][64];                          // g = dy * act'(y) of one 64-wide n sub-chunk
     float acc[SK_M];
 #pragma unroll
     for (int m = 0; m < SK_M; ++m) acc[m] = 0.f;
-    if (k < K) {
-        for (int64_t n = n0; n < n1; ++n) {
-            const float w = W[n * K + k];
-#pragma unroll
-            for (int m = 0; m < SK_M; ++m)
-                if (m < M) acc[m] += w * dy[m * ldy + n] * (yact ? act_grad_from_out(yact[m * ldy + n], act) : 1.f);   // uniform address: scalar loads
+    for (int64_t nb = n0; nb < n1; nb += 64) {
+        const int cnt = (int)min((int64_t)64, n1 - nb);
+        __syncthreads();
+        for (int i = threadIdx.x; i < M * 64; i += 256) {
+            const int m = i >> 6, j = i & 63;
+            float g = 0.f;
+            if (j < cnt) { g = dy[m * ldy + nb + j]; if (yact) g *= act_grad_from_out(yact[m * ldy + nb + j], act); }
+            gs[m][j] = g;
         }
+        __syncthreads();
+        if (k < K) {
+#pragma unroll 8
+            for (int j = 0; j < cnt; ++j) {
+                const float w = W[(nb + j) * K + k];
+#pragma unroll
+                for (int m = 0; m < SK_M; ++m) if (m < M) acc[m] += w * gs[m][j];      // LDS broadcast
+            }
+        }
+    }
+    if (k < K) {
 #pragma unroll
         for (int m = 0; m < SK_M; ++m) if (m < M) atomicAdd(&dx[m * ldx + k], acc[m]);
     }
@@ -190,6 +214,26 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_skinny_kernel(const flo
         dW[i] = acc;
         if (db && k == 0) db[n] = bsum;                       // the bias gradient rides along (column sums of dy)
     }
+}
+
+// Row-per-block form for wide layers (K >= 256): g[m] = dy[m][n] * act'(y[m][n]) is block-uniform, each thread owns k.
+__global__ __launch_bounds__(256) void linear_bwd_weight_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dW,
+                                                                     float* __restrict__ db, int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx,
+                                                                     const float* __restrict__ yact, int act) {
+    const int64_t n = blockIdx.y;
+    float g[SK_M], bsum = 0.f;
+#pragma unroll
+    for (int m = 0; m < SK_M; ++m) {
+        g[m] = 0.f;
+        if (m < M) { g[m] = dy[m * ldy + n]; if (yact) g[m] *= act_grad_from_out(yact[m * ldy + n], act); bsum += g[m]; }
+    }
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < K; k += (int64_t)gridDim.x * 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < SK_M; ++m) if (m < M) acc += g[m] * x[m * ldx + k];
+        dW[n * K + k] = acc;
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) db[n] = bsum;
 }
 
 extern "C" int cvae_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N,
@@ -226,7 +270,7 @@ extern "C" int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, 
         hipStream_t st = (hipStream_t)stream;
         if (hipMemset2DAsync(dx, (size_t)dx_stride * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
         const int64_t kb = (K + 255) / 256;
-        int64_t chunks = (1024 + kb - 1) / kb;
+        int64_t chunks = (2048 + kb - 1) / kb;                // >= 8 waves per SIMD worth of blocks: the W stream is latency-bound per wave
         if (chunks > N / 16) chunks = N / 16;
         if (chunks < 1) chunks = 1;
         const int64_t nchunk = (N + chunks - 1) / chunks;
@@ -257,7 +301,12 @@ extern "C" int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW
     int rc = CVAE_OK;
     if (M <= SK_M && N > 0 && K > 0) {
         if (!dy || !x || !dW) return CVAE_E_NULLPTR;
-        hipLaunchKernelGGL(linear_bwd_weight_skinny_kernel, dim3(cvae_grid_1d(N * K, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db, (int)M, K, N, dy_stride, x_stride, y_act, act);
+        if (K >= 256 && N <= 65535) {
+            int64_t gx = (K + 1023) / 1024;                  // each thread ~4 columns
+            hipLaunchKernelGGL(linear_bwd_weight_rows_kernel, dim3((unsigned)gx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db, (int)M, K, N, dy_stride, x_stride, y_act, act);
+        } else {
+            hipLaunchKernelGGL(linear_bwd_weight_skinny_kernel, dim3(cvae_grid_1d(N * K, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db, (int)M, K, N, dy_stride, x_stride, y_act, act);
+        }
         CVAE_CHECK_LAUNCH();
         return CVAE_OK;
     } else {

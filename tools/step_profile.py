@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Summarise one replayed train step from a rocprofv3 --kernel-trace CSV: kernel count, span, per-kernel totals."""
+import collections, csv, glob, os, sys
+d = sys.argv[1]
+f = max(glob.glob(os.path.join(d, "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "adam_multi" in r["Kernel_Name"]]
+step = rows[idx[-3] + 1: idx[-2] + 1]
+dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+print(f, "\nkernels in step", len(step), "span us", (int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])) / 1e3, "sum of durations", round(sum(map(dur, step)), 1))
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in step:
+    k = r["Kernel_Name"][:72]; agg[k][0] += 1; agg[k][1] += dur(r)
+for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[: int(sys.argv[2]) if len(sys.argv) > 2 else 20]:
+    print(f"{t:8.1f} us {n:3d}x  {k}")
