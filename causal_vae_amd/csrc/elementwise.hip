@@ -175,7 +175,20 @@ __global__ __launch_bounds__(256) void channel_sum_vec_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
     if (ri < rows && grp < groups) {
-        for (int64_t p = (int64_t)blockIdx.x * rows + ri; p < P; p += (int64_t)gridDim.x * rows) {
+        const int64_t stride = (int64_t)gridDim.x * rows;
+        int64_t p = (int64_t)blockIdx.x * rows + ri;
+        for (; p + 3 * stride < P; p += 4 * stride) {        // 4 independent 16-byte loads in flight per thread
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(x + (p + u * stride) * C + grp * VEC);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T* pv = (const T*)&v[u];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += to_f32(pv[e]);
+            }
+        }
+        for (; p < P; p += stride) {
             const uint4 v = *(const uint4*)(x + p * C + grp * VEC);
             const T* pv = (const T*)&v;
 #pragma unroll
@@ -240,7 +253,8 @@ static int channel_sum_launch(const T* x, float* out, int64_t P, int64_t C, hipS
         if (gy > 65535) return CVAE_E_BADSHAPE;
         const int64_t passes = (Pv + rows - 1) / rows;       // row passes if one block did everything
         int64_t gx = 1;
-        if (passes > 64) { gx = (passes + 7) / 8; const int64_t cap = (2048 + gy - 1) / gy; if (gx > cap) gx = cap; }   // >= 8 row passes per block
+        // every block ends with atomics onto the same C words: few blocks (<= 128 adders per word), 32+ row passes each
+        if (passes > 64) { gx = (passes + 31) / 32; const int64_t cap = (128 + gy - 1) / gy; if (gx > cap) gx = cap; }
         const int direct = gx == 1;
         if (!direct && hipMemsetAsync(out, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
         hipLaunchKernelGGL(channel_sum_vec_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, out, Pv, Cv, fold, direct);

@@ -284,7 +284,7 @@ extern "C" int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, 
         hipStream_t st = (hipStream_t)stream;
         if (hipMemset2DAsync(dx, (size_t)dx_stride * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
         const int64_t kb = (K + 255) / 256;
-        int64_t chunks = N / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+        int64_t chunks = N / 8; if (chunks < 1) chunks = 1; if (chunks > 256) chunks = 256;     // tiny W: spread the n reduction over many blocks
         const int64_t nchunk = (N + chunks - 1) / chunks;
         chunks = (N + nchunk - 1) / nchunk;
         hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk, y_act, act);
