@@ -54,10 +54,10 @@ def make_batch(B, size, seed, device):
     return tuple(v.to(device) for v in (x, m, t, eps))
 
 
-def cpu_baseline(B, size, budget_s, x, m, t, eps, lr=1e-3):
+def cpu_baseline(B, size, budget_s, x, m, t, eps, lr=1e-3, threads=16):
     """Oracle train steps on the host CPU: bounded sample (>= 2 timed steps, stops after ~budget_s seconds)."""
     import oracle
-    torch.set_num_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     sd = oracle.init_state_dict("bio3d", seed=42)
     state, losses, times = None, [], []
     t_all = time.time()
@@ -89,8 +89,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="samples per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = the box's CPU share: min(affinity, 16 per GPU))")
     ap.add_argument("--lr", type=float, default=1e-3, help="Adam learning rate (reference: 1e-3, causal_cascade/main.py:50)")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--fork", action="store_true", help="run weight-gradient kernels on a side stream (overlap with data-gradient kernels)")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--roofline-steps", type=int, default=5, help="eager steps with per-launch HIP events after the timed region")
     args = ap.parse_args()
@@ -100,6 +102,9 @@ def main():
     from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters, init_distributed
     import torch.distributed as dist
 
+    if args.fork:
+        from causal_vae_amd import ops as _ops0
+        _ops0.FORK_BACKWARD = True
     rank, world, local_rank = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -157,6 +162,8 @@ def main():
     # replayed graph); same process, same buffers, directly after the timed region ----
     timer = None
     if not args.no_kernel_timer and args.roofline_steps > 0:
+        from causal_vae_amd import ops as _ops
+        _ops.FORK_BACKWARD = False                                   # one stream: every launch is timed alone
         timer = _lib.KernelTimer()
         eager_step()
         torch.cuda.synchronize()
@@ -179,7 +186,7 @@ def main():
                                    f"Adam lr 1e-3, ELBO = MSE-sum + 2000*MSE-sum(m) + KLD", "global_batch": world * args.batch,
                        "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}",
                        "params": sum(p.numel() for p in model.parameters())},
-            "final_loss": final_loss, "loss_trajectory": traj[:4] + traj[-2:], "lr": args.lr, "hip_graph": use_graph,
+            "final_loss": final_loss, "loss_trajectory": traj[:4] + traj[-2:], "lr": args.lr, "hip_graph": use_graph, "side_stream_fork": args.fork,
         }
         if timer is not None:
             summ = timer.summary()
@@ -189,8 +196,12 @@ def main():
             fl = conv_flops(dom)
             peak = PEAK_BF16_FLOPS if args.dtype == "bf16" else PEAK_F32_FLOPS
             ach = fl / (ms * 1e-3)
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tfile):                                # HBM bytes per launch from the committed rocprofv3 --pmc passes
+                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None, "avg_ms": ms, "launches_per_step": n / args.roofline_steps,
+                               "frac": ach / peak, "traffic": traffic, "avg_ms": ms, "launches_per_step": n / args.roofline_steps,
                                "timing": f"HIP events around each launch over {args.roofline_steps} eager steps run right after the timed region",
                                "algorithmic_gflop_per_launch": fl / 1e9}
             conv_ms = sum(n_ * ms_ for n_, ms_ in summ.values()) / args.roofline_steps
@@ -198,7 +209,9 @@ def main():
             res["kernels"] = {k: {"per_step": v[0], "avg_ms": round(v[1], 4), "tflops": round(conv_flops(k) / (v[1] * 1e-3) / 1e12, 1)}
                               for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0] * kv[1][1])}
         if world == 1 and args.cpu_seconds > 0:
-            cb, elbo_ref = cpu_baseline(args.batch, args.size, args.cpu_seconds, x.cpu(), m.cpu(), t.cpu(), eps.cpu(), args.lr)
+            aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = args.cpu_threads if args.cpu_threads > 0 else min(aff, 16)
+            cb, elbo_ref = cpu_baseline(args.batch, args.size, args.cpu_seconds, x.cpu(), m.cpu(), t.cpu(), eps.cpu(), args.lr, threads)
             res["cpu_baseline"] = cb
             res["elbo_rel_err"] = abs(elbo0 - elbo_ref) / abs(elbo_ref)
             res["gpu_over_cpu"] = res["value"] / cb["value"]

@@ -12,7 +12,8 @@ from ._lib import lib, check, ptr, stream
 
 
 _SIDE = {}
-FORK_BACKWARD = True       # weight-gradient kernels run on a side stream next to the data-gradient kernels
+FORK_BACKWARD = False      # True: weight-gradient kernels run on a side stream next to the data-gradient kernels (A/B on MI355X:
+                           # -2 % at 128^3 once the kernels fill the chip; kept as an option for small volumes)
 
 
 class _Fork:
