@@ -76,6 +76,7 @@ SIGNATURES = {
     "cvae_uniform_kl_bwd": [_p, _p, _p, _i64, _i64, _p],
     "cvae_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
     "cvae_adam_multi": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p],
+    "cvae_multi_copy": [_p, _p, _p, _i, _p],
     "cvae_counter_add": [_p, _i, _p],
     "cvae_sqnorm": [_p, _p, _i64, _p],
     "cvae_scale": [_p, _i64, _p, _p],

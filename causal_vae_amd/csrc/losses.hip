@@ -477,6 +477,52 @@ extern "C" int cvae_adam_multi(float* const* p, const float* const* g, float* co
     }
     return CVAE_OK;
 }
+// Multi-tensor fp32 copy (pack gradients into the flat all-reduce bucket and back): one launch for the whole list.
+struct CopyTable {
+    const float* src[ADAM_MAX_TENSORS];
+    float* dst[ADAM_MAX_TENSORS];
+    long long n[ADAM_MAX_TENSORS];
+    int blk_start[ADAM_MAX_TENSORS + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(CopyTable tb) {
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    const float* s = tb.src[ti];
+    float* d = tb.dst[ti];
+    const long long base = (long long)((int)blockIdx.x - tb.blk_start[ti]) * ADAM_SPAN, end = min(tb.n[ti], base + ADAM_SPAN);
+    if (((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0 && end - base == ADAM_SPAN) {
+#pragma unroll
+        for (int k = 0; k < ADAM_SPAN / (256 * 4); ++k) ((float4*)d)[base / 4 + k * 256 + threadIdx.x] = ((const float4*)s)[base / 4 + k * 256 + threadIdx.x];
+    } else {
+        for (long long i = base + threadIdx.x; i < end; i += 256) d[i] = s[i];
+    }
+}
+extern "C" int cvae_multi_copy(const float* const* src, float* const* dst, const int64_t* n, int count, void* stream) {
+    if (count < 0) return CVAE_E_BADSHAPE;
+    if (count == 0) return CVAE_OK;
+    if (!src || !dst || !n) return CVAE_E_NULLPTR;
+    for (int c0 = 0; c0 < count; c0 += ADAM_MAX_TENSORS) {
+        CopyTable tb;
+        const int cnt = (count - c0 < ADAM_MAX_TENSORS) ? count - c0 : ADAM_MAX_TENSORS;
+        int blocks = 0, used = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t ni = n[c0 + i];
+            if (ni < 0) return CVAE_E_BADSHAPE;
+            if (ni == 0) continue;
+            if (!src[c0 + i] || !dst[c0 + i]) return CVAE_E_NULLPTR;
+            tb.src[used] = src[c0 + i]; tb.dst[used] = dst[c0 + i]; tb.n[used] = ni; tb.blk_start[used] = blocks;
+            blocks += (int)((ni + ADAM_SPAN - 1) / ADAM_SPAN);
+            ++used;
+        }
+        if (!used) continue;
+        tb.blk_start[used] = blocks;
+        tb.count = used;
+        hipLaunchKernelGGL(multi_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb);
+        CVAE_CHECK_LAUNCH();
+    }
+    return CVAE_OK;
+}
 __global__ void add_int_kernel(int* c, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta; }
 extern "C" int cvae_counter_add(int* counter, int delta, void* stream) {
     if (!counter) return CVAE_E_NULLPTR;

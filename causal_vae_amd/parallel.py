@@ -25,7 +25,8 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CVAE_DIST_BACKEND=gloo lets several ranks share ONE card (rehearsal of the N > 1 path on a 1-GPU box)
+            backend = os.environ.get("CVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -48,25 +49,42 @@ class GradAllReducer:
     def _grads(self):
         return [p.grad for p in self.params if p.grad is not None]
 
-    def pack(self):
-        """Copy every gradient into the flat fp32 bucket (capturable: fixed addresses once the bucket exists)."""
+    def _copy(self, to_flat):
+        """One multi-tensor launch (cvae_multi_copy) on GPU tensors; plain torch copies on CPU tensors (gloo tests)."""
         grads = self._grads()
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or (grads and self._flat.device != grads[0].device):
             self._flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
-        off = 0
+        offs, off = [], 0
         for g in grads:
-            self._flat[off:off + g.numel()].copy_(g.reshape(-1))
+            offs.append(off)
             off += g.numel()
+        if grads and grads[0].is_cuda and all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
+            import ctypes as C
+            from ._lib import lib, check, stream
+            k = len(grads)
+            gp = [g.data_ptr() for g in grads]
+            fp = [self._flat.data_ptr() + 4 * o for o in offs]
+            src, dst = (gp, fp) if to_flat else (fp, gp)
+            check(lib.cvae_multi_copy((C.c_void_p * k)(*src), (C.c_void_p * k)(*dst), (C.c_int64 * k)(*[g.numel() for g in grads]), k, stream()),
+                  "multi_copy")
+            return
+        for g, o in zip(grads, offs):
+            v = self._flat[o:o + g.numel()]
+            if to_flat:
+                v.copy_(g.reshape(-1))
+            else:
+                g.copy_(v.view_as(g))
+
+    def pack(self):
+        """Copy every gradient into the flat fp32 bucket (capturable: fixed addresses once the bucket exists)."""
+        self._copy(True)
 
     def all_reduce(self):
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def unpack(self):
-        off = 0
-        for g in self._grads():
-            g.copy_(self._flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        self._copy(False)
 
     def __call__(self):
         if self.world_size() == 1 or not self._grads():

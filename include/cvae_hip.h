@@ -185,6 +185,8 @@ int cvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int cvae_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, int count,
                     float lr, float beta1, float beta2, float eps, float bc1, float bc2, const int* step_dev,
                     const float* grad_scale, void* stream);
+/* dst[i][0..n[i]) = src[i][0..n[i]) for a LIST of fp32 tensors in one launch (gradient bucket pack / unpack). */
+int cvae_multi_copy(const float* const* src, float* const* dst, const int64_t* n, int count, void* stream);
 /* *counter += delta (device int; step counters that must advance inside a captured graph) */
 int cvae_counter_add(int* counter, int delta, void* stream);
 /* *out += sum g^2 */

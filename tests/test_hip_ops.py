@@ -386,3 +386,20 @@ def test_fused_adam_and_clip_match_torch():
         o_ref.step(); o_mine.step()
     for r, m in zip(ref, mine):
         torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_gradient_bucket_pack_unpack_roundtrip():
+    """GradAllReducer packs all .grad tensors into one flat fp32 bucket with ONE launch and unpacks them the same way."""
+    from causal_vae_amd.parallel import GradAllReducer
+    g = torch.Generator().manual_seed(21)
+    ps = [torch.nn.Parameter(torch.zeros(*s, device=DEV)) for s in [(512, 331), (64,), (32, 1, 4, 4, 4), (5,), (4097,)]]
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).to(DEV)
+    ref = [p.grad.clone() for p in ps]
+    red = GradAllReducer(ps)
+    red.pack()
+    assert torch.equal(red._flat, torch.cat([r.flatten() for r in ref]))
+    red._flat.mul_(2.0)
+    red.unpack()
+    for p, r in zip(ps, ref):
+        assert torch.equal(p.grad, 2.0 * r)
