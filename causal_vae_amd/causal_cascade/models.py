@@ -67,6 +67,19 @@ class CausalBioVAE(nn.Module):
         x_feat = self.dec_input(z_m_input).view(-1, 256, *([4] * self._ND))
         return self.dec_conv.forward_cl(x_feat)              # channels-last [B, D, H, W, C], compute dtype
 
+    def decode(self, z, m_hat, size=None):
+        """Decoder half only: [z, m_hat] -> dec_input -> dec_conv -> resize to `size` (default: the native 64^nd).
+        Rows are independent, so a whole counterfactual sweep (abduct z once, stack every intervened m') decodes in ONE call
+        instead of the reference's per-value loop (vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:77-99)."""
+        nd = self._ND
+        out_cl = self.decode_cl(ops.cat([z, m_hat]))
+        native = tuple(out_cl.shape[1:4])
+        size = native if size is None else (tuple(size) if nd == 3 else (1,) + tuple(size))
+        rec = ops.Cast.apply(out_cl, torch.float32) if size == native else ops.UpsampleLinear.apply(out_cl, size)
+        if out_cl.shape[-1] != 1:
+            return ops.FromChannelsLast.apply(rec, nd)
+        return rec.view(rec.shape[0], 1, *(size if nd == 3 else size[1:]))
+
     def forward(self, x, m, t, eps=None):
         nd = self._ND
         if x.dim() != nd + 2:

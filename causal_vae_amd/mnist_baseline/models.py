@@ -33,6 +33,10 @@ class CausalMorphVAE12(nn.Module):
             eps = self._eps.draw(mu)
         return ops.Reparameterize.apply(mu, logvar, eps)
 
+    def decode(self, m_hat, z):
+        """Decoder half: cat[m_hat, z] -> dec_fc -> dec_conv (check_mnist_counterfactual.py:72-74, any number of rows at once)."""
+        return self.dec_conv(self.dec_fc(ops.cat([m_hat, z])).view(-1, 64, 7, 7))
+
     def forward(self, x, m, t, eps=None):
         x_feat = self.enc_conv(x)
         mu, logvar = self.enc_fc(ops.cat([x_feat, m, t])).chunk(2, dim=1)

@@ -91,6 +91,25 @@ def bio_vae_forward(sd, x, m, t, eps, *, nd=None, training=True, update_running=
     return out
 
 
+def bio_decode(sd, z, m_hat, size=None, nd=2):
+    """Decoder half of CausalBioVAE.forward (causal_cascade/models.py:80-87): the per-row computation the reference's
+    counterfactual loops repeat (vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:97-99)."""
+    convT = _convT(nd)
+    d = _lin(sd, "dec_input", torch.cat([z, m_hat], dim=1)).view(-1, 256, *([4] * nd))
+    for i in range(4):
+        d = convT(d, sd[f"dec_conv.{2*i}.weight"], sd[f"dec_conv.{2*i}.bias"], stride=2, padding=1)
+        if i < 3:
+            d = F.relu(d)
+    if size is not None and tuple(size) != tuple(d.shape[2:]):
+        d = F.interpolate(d, size=tuple(size), mode="bilinear" if nd == 2 else "trilinear", align_corners=False)
+    return d
+
+
+def morph_decode(sd, m_hat, z):
+    """dec_fc -> view(-1, 64, 7, 7) -> dec_conv (mnist_test/01_baseline_causal_vae/check_mnist_counterfactual.py:72-74)."""
+    return _morph_decode(sd, m_hat, z)
+
+
 def _morph_encode(sd, x, m, t):
     h = F.relu(F.conv2d(x, sd["enc_conv.0.weight"], sd["enc_conv.0.bias"], stride=2, padding=1))
     h = F.relu(F.conv2d(h, sd["enc_conv.2.weight"], sd["enc_conv.2.bias"], stride=2, padding=1))

@@ -89,8 +89,10 @@ def cascade_train_step(sd, x, m, t, eps, adam_state=None, *, lr=1e-3, gamma=2000
 
 
 def mnist_adversarial_step(sd_vae, sd_d, x, m, t, eps_d, eps_vae, eps_adv, adam_vae=None, adam_d=None,
-                           *, lr=1e-3, beta=1.0, lambda_adv=10.0, apply_update=True):
+                           *, lr=1e-3, beta=1.0, lambda_adv=10.0, apply_update=True, gaussian=False):
     """One iteration of train_model's inner loop (mnist_test/01_baseline_causal_vae/train.py:34-93).
+    ``gaussian=True`` is the 06_model_experiment variant (mnist_test/06_model_experiment/train.py:40-97): 6-tuple forward with
+    the decoder on the real m, and the morph term is the Gaussian NLL (:79) instead of 100 * MSE-sum.
 
     The reference draws six eps per step; only three reach any result and
     are injected here: ``eps_d`` (:51, D's input), ``eps_vae`` (:67 forward, recon path) and
@@ -101,7 +103,8 @@ def mnist_adversarial_step(sd_vae, sd_d, x, m, t, eps_d, eps_vae, eps_adv, adam_
     t_idx = torch.argmax(t, dim=1)                                        # :36
     # ---- D step (:41-59) ----
     with torch.no_grad():
-        o = fn.morph_vae_forward(sd_vae, x, m, t, torch.zeros_like(eps_d))      # :49 (eps unused for mu/logvar)
+        fwd = fn.morph_vae6_forward if gaussian else fn.morph_vae_forward
+        o = fwd(sd_vae, x, m, t, torch.zeros_like(eps_d))                 # :49 (eps unused for mu/logvar)
         z_d = o["mu"] + eps_d * torch.exp(0.5 * o["logvar"])              # :50-52
     ld = _leaves(sd_d)
     loss_d = F.cross_entropy(fn.discriminator_forward(ld, z_d), t_idx)    # :55-56
@@ -112,11 +115,14 @@ def mnist_adversarial_step(sd_vae, sd_d, x, m, t, eps_d, eps_vae, eps_adv, adam_
         adam_update(sd_d, grads_d, adam_d, lr=lr)                         # :59
     # ---- VAE step (:65-89) — uses the *updated* discriminator ----
     lv = _leaves(sd_vae)
-    o = fn.morph_vae_forward(lv, x, m, t, eps_vae)                        # :67
+    o = fwd(lv, x, m, t, eps_vae)                                         # :67
     z_sample = fn.reparameterize(o["mu"], o["logvar"], eps_adv)           # :78
     d_fake = fn.discriminator_forward(sd_d, z_sample)                     # :79
     loss, recon, kld, morph, adv = fn.mnist_vae_losses(o["recon_x"], x, o["m_hat"], m, o["mu"], o["logvar"],
                                                        d_fake, beta=beta, lambda_adv=lambda_adv, t_dim=t_dim)
+    if gaussian:
+        morph = fn.gaussian_nll(m, o["m_mu"], o["m_logvar"])              # 06/train.py:79
+        loss = recon + kld + morph + adv
     kv = trainable_keys(sd_vae)
     grads_v = dict(zip(kv, torch.autograd.grad(loss, [lv[k] for k in kv])))
     if apply_update:

@@ -262,3 +262,73 @@ def test_graphed_step_matches_eager_steps():
     for (k, p), q in zip(m_e.named_parameters(), m_g.parameters()):
         if k != NOISE_KEY:
             assert float((p - q).abs().max()) < 5e-4, k
+
+
+def test_gaussian_head_variant_matches_reference_golden(golden):
+    """mnist_test/06_model_experiment CausalMorphVAE12 (6-tuple, decoder on the real m) vs tensors from the reference class."""
+    from causal_vae_amd.mnist_gaussian import CausalMorphVAE12 as GaussVAE
+    from causal_vae_amd import ops
+    g = golden("morph12g_b8")
+    torch.manual_seed(42)
+    vae = GaussVAE().to(DEV).train()
+    for k, v in vae.state_dict().items():
+        g.check("sd0", k, v, rtol=0, atol=0)
+    x, m, t = (g.t("in/" + k).to(DEV) for k in ("x", "m", "t"))
+    out = vae(x, m, t, eps=g.t("fwd/eps").to(DEV))
+    assert len(out) == 6
+    for k, v in zip(("recon_x", "m_hat", "mu", "logvar", "m_mu", "m_logvar"), out):
+        g.check("fwd", k, v, rtol=1e-4, atol=1e-5)
+    nll = ops.GaussNLL.apply(m, out[4], out[5])
+    assert rel(nll, g.t("fwd/nll")) < 1e-4
+    with torch.no_grad():
+        torch.testing.assert_close(vae.morph_predictor(t), out[4], rtol=1e-5, atol=1e-6)
+
+
+def test_batched_counterfactual_decode_equals_per_value_loop():
+    """One stacked decode == the reference's per-(feature, value) batch-1 decodes, checked against the oracle's decoder."""
+    from causal_vae_amd.counterfactual import batched_counterfactual, sweep_inputs
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).eval()
+    sd = oracle.init_state_dict("bio3d", seed=42)
+    g = torch.Generator().manual_seed(8)
+    z, m = torch.randn(2, 64, generator=g), torch.rand(2, 12, generator=g)
+    feats, vals = [0, 5, 11], [0.0, 0.25, 0.5, 0.75, 1.0]
+    out = batched_counterfactual(model, z.to(DEV), m.to(DEV), feats, vals)            # native 64^3 decode
+    assert out.shape == (2, 3, 5, 1, 64, 64, 64)
+    for b, fi, vi in ((0, 0, 0), (1, 2, 4), (0, 1, 3)):                             # spot-check three single decodes
+        m1 = m[b:b + 1].clone(); m1[0, feats[fi]] = vals[vi]
+        ref = ofn.bio_decode(sd, z[b:b + 1], m1, nd=3)
+        torch.testing.assert_close(out[b, fi, vi].cpu(), ref[0], rtol=1e-4, atol=1e-5)
+    up = batched_counterfactual(model, z.to(DEV), m.to(DEV), [3], [0.1, 0.9], size=(96, 80, 72))
+    ref = ofn.bio_decode(sd, z[1:2], torch.cat([m[1:2, :3], torch.tensor([[0.9]]), m[1:2, 4:]], 1), size=(96, 80, 72), nd=3)
+    torch.testing.assert_close(up[1, 0, 1].cpu(), ref[0], rtol=1e-4, atol=1e-5)
+    # MNIST: decode(m_hat, z)
+    torch.manual_seed(42)
+    vae = CausalMorphVAE12().to(DEV).eval()
+    sdm = oracle.init_state_dict("morph12", seed=42)
+    zz, mm = torch.randn(3, 10, generator=g), torch.rand(3, 12, generator=g)
+    outm = batched_counterfactual(vae, zz.to(DEV), mm.to(DEV), [1, 2], [0.0, 1.0])
+    z_rep, m_cf = sweep_inputs(zz, mm, [1, 2], [0.0, 1.0])
+    torch.testing.assert_close(outm.reshape(-1, 1, 28, 28).cpu(), ofn.morph_decode(sdm, m_cf, z_rep), rtol=1e-4, atol=1e-5)
+
+
+def test_gaussian_head_adversarial_step_matches_oracle():
+    """06_model_experiment train loop body (D step, then VAE step with the Gaussian-NLL morph term) vs the oracle's step."""
+    from causal_vae_amd.mnist_gaussian import CausalMorphVAE12 as GaussVAE, train_step as gauss_step
+    g = torch.Generator().manual_seed(3)
+    B = 16
+    x, m = torch.rand(B, 1, 28, 28, generator=g), torch.rand(B, 12, generator=g)
+    t = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float()
+    eps = tuple(torch.randn(B, 10, generator=g) for _ in range(3))
+    sd_v, sd_d = oracle.init_state_dict("morph12g", seed=42), oracle.init_state_dict("disc", seed=7)
+    vae, disc = GaussVAE().to(DEV).train(), LatentDiscriminator().to(DEV).train()
+    vae.load_state_dict(sd_v); disc.load_state_dict(sd_d)
+    ref = oracle.mnist_adversarial_step(sd_v, sd_d, x, m, t, *eps, gaussian=True)
+    opt_vae, opt_d = FusedAdam(vae.parameters(), lr=1e-3), FusedAdam(disc.parameters(), lr=1e-3)
+    r = gauss_step(vae, disc, opt_vae, opt_d, x.to(DEV), m.to(DEV), t.to(DEV), eps=tuple(e.to(DEV) for e in eps))
+    for k in ("loss_d", "loss", "recon", "kld", "morph", "adv"):
+        assert rel(r[k], ref[k]) < 1e-4, (k, float(r[k]), float(ref[k]))
+    for k, v in vae.state_dict().items():
+        adam_close(v, sd_v[k], k)
+    for k, v in disc.state_dict().items():
+        adam_close(v, sd_d[k], k)
