@@ -22,6 +22,20 @@
 #include "common.h"
 #include <cstdlib>
 
+// Development aid (make EXTRA=-DCVAE_STAMP, tools/stamp_probe.py): thread 0 of every workgroup of conv_data_kernel records the
+// shader clock at its phase boundaries into a device array that cvae_debug_stamps() copies out.  Not compiled by default.
+#ifdef CVAE_STAMP
+#define CVAE_STAMP_SLOTS 32
+#define CVAE_STAMP_WGS 8192
+__device__ unsigned long long g_stamp[(size_t)CVAE_STAMP_WGS * CVAE_STAMP_SLOTS];
+#define STAMP(i)                                                                                                         \
+    do {                                                                                                                 \
+        if (t == 0 && stamp_wg < CVAE_STAMP_WGS) g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 struct ConvGeom {
@@ -132,6 +146,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     char* bt = smem + HALO_BYTES;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef CVAE_STAMP
+    const unsigned stamp_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (t == 0 && stamp_wg < CVAE_STAMP_WGS) {
+        g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 30] = wall_clock64();
+        g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 29] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    }
+#endif
+    STAMP(0);
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z;
@@ -215,6 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
         }
     };
 
+    STAMP(1);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         {
             Piece<T> hp[HN], pb0[BP];
@@ -222,6 +245,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
             for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * 16, hoff[i] >= 0);
             load_b(pb0, chunk, 0);
             __syncthreads();                               // previous chunk's readers are done with halo + B buffers
+            if (chunk < 8) STAMP(2 + 3 * chunk);
 #pragma unroll
             for (int i = 0; i < HN; ++i) {
                 const int it = t + i * NT, pos = it >> 1;
@@ -230,6 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
             store_b(pb0, 0);
         }
         __syncthreads();
+        if (chunk < 8) STAMP(3 + 3 * chunk);
         // Weight panels ride a 2-deep ring: the panel of group g+2 is loaded into registers at the start of group g and
         // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
         // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
@@ -245,7 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], a[mi], bf[ni]);
+                    for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
             }
         };
         Piece<T> pbA[BP], pbB[BP];
@@ -263,34 +288,69 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
                 __syncthreads();
             }
         }
+        if (chunk < 8) STAMP(4 + 3 * chunk);
     }
+    STAMP(26);
 
-    // ---- epilogue.  32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
+    // ---- epilogue.  The MFMAs ran with the WEIGHT fragment as the A operand, so D rows are output channels and D columns are
+    // positions: lane (r, h) holds, for position r of each M sub-tile, channels (e & 3) + 8 (e >> 2) + 4 h of each 32-channel N
+    // sub-tile.  Two v_permlane32_swap per register pair regroup them so that the lane owns channels 8h..8h+7 and 16+8h..23+8h:
+    // two 8-channel pieces, each ONE 16-byte (bf16) store and ONE 16-byte mask load instead of eight 2-byte ones.
     const int out_d = UP ? g.ld : g.sd, out_h = UP ? g.lh : g.sh, out_w = UP ? g.lw : g.sw;
-    float bv[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bv[ni] = bias ? bias[n0 + (wn * NI + ni) * 32 + r] : 0.f;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int ms = wm * MI + mi;                                            // same lane -> position map as pbase
+        const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
+        int od, oh, ow;
+        if (UP) { od = (ND == 3) ? 2 * (o0d + d) + prd : 0; oh = 2 * (o0h + hh) + prh; ow = 2 * (o0w + w) + prw; }
+        else { od = o0d + d; oh = o0h + hh; ow = o0w + w; }
+        const bool ok = od < out_d && oh < out_h && ow < out_w;
+        const size_t pidx = ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int ni = 0; ni < NI; ++ni) {
+            float v[2][8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int ms = wm * MI + mi, rr = (e & 3) + 8 * (e >> 2) + 4 * h;      // MFMA row -> position, same map as pbase
-            const int w = ST::w_of(rr), hh = (ms % HB) * ST::SH + ST::h_of(rr), d = ms / HB;
-            int od, oh, ow;
-            if (UP) { od = (ND == 3) ? 2 * (o0d + d) + prd : 0; oh = 2 * (o0h + hh) + prh; ow = 2 * (o0w + w) + prw; }
-            else { od = o0d + d; oh = o0h + hh; ow = o0w + w; }
-            if (od >= out_d || oh >= out_h || ow >= out_w) continue;
-            const size_t pidx = ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout;
+            for (int i = 0; i < 4; ++i) {
+                const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][i]), __float_as_uint(acc[mi][ni][4 + i]), false, false);
+                const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 + i]), __float_as_uint(acc[mi][ni][12 + i]), false, false);
+                v[0][i] = __uint_as_float(lo[0]); v[0][4 + i] = __uint_as_float(lo[1]);
+                v[1][i] = __uint_as_float(hi[0]); v[1][4 + i] = __uint_as_float(hi[1]);
+            }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int c = n0 + (wn * NI + ni) * 32 + r;
-                float v = acc[mi][ni][e] + bv[ni];
-                if (EPI == 1) v = fmaxf(v, 0.f);
-                else if (EPI == 2) v = apply_act(v, act);
-                if (mask && !(to_f32(mask[pidx + c]) > 0.f)) v = 0.f;
-                out[pidx + c] = from_f32<T>(v);
+            for (int j = 0; j < 2; ++j) {
+                const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
+                if (bias) {
+                    const float4 b0 = *(const float4*)(bias + c), b1 = *(const float4*)(bias + c + 4);
+                    v[j][0] += b0.x; v[j][1] += b0.y; v[j][2] += b0.z; v[j][3] += b0.w;
+                    v[j][4] += b1.x; v[j][5] += b1.y; v[j][6] += b1.z; v[j][7] += b1.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (EPI == 1) v[j][q] = fmaxf(v[j][q], 0.f);
+                    else if (EPI == 2) v[j][q] = apply_act(v[j][q], act);
+                }
+                if (!ok) continue;
+                if (mask) {
+                    Piece<T> mp;
+                    piece_load<T>(mp, mask + pidx + c, true);
+                    const T* mv = (const T*)&mp;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
+                }
+                Piece<T> op;
+                T* ov = (T*)&op;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ov[q] = from_f32<T>(v[j][q]);
+                piece_store<T>(op, (char*)(out + pidx + c));
             }
         }
+    }
+#ifdef CVAE_STAMP
+    __builtin_amdgcn_s_waitcnt(0);                         // vmcnt(0): the stores have left the wave
+    STAMP(27);
+    if (t == 0 && stamp_wg < CVAE_STAMP_WGS) g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 31] = wall_clock64();
+#endif
 }
 
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI>
@@ -588,6 +648,13 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd);
 int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
                        int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
+
+#ifdef CVAE_STAMP
+extern "C" int cvae_debug_stamps(unsigned long long* host, size_t count) {
+    if (count > (size_t)CVAE_STAMP_WGS * CVAE_STAMP_SLOTS) return CVAE_E_BADSHAPE;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), count * sizeof(unsigned long long)) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
+}
+#endif
 
 extern "C" size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, int dtype) {
     const int64_t taps = (nd == 3) ? 64 : 16;

@@ -13,3 +13,8 @@ for r in step:
     k = r["Kernel_Name"][:72]; agg[k][0] += 1; agg[k][1] += dur(r)
 for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[: int(sys.argv[2]) if len(sys.argv) > 2 else 20]:
     print(f"{t:8.1f} us {n:3d}x  {k}")
+if "--seq" in sys.argv:
+    t0 = int(step[0]["Start_Timestamp"])
+    for r in step:
+        gap = (int(r["Start_Timestamp"]) - t0) / 1e3
+        print(f"{gap:9.1f} +{dur(r):7.1f} us  grid {r.get('Grid_Size_X','?'):>8s}x{r.get('Grid_Size_Y','?')}x{r.get('Grid_Size_Z','?')} wg {r.get('Workgroup_Size_X','?'):>4s} lds {r.get('LDS_Block_Size','?'):>6s} vgpr {r.get('VGPR_Count','?'):>3s}/{r.get('Accum_VGPR_Count','?'):>3s}  {r['Kernel_Name'][:90]}")
