@@ -101,7 +101,23 @@ template <typename T> struct Piece { uint4 v[(8 * sizeof(T)) / 16]; };
 template <typename T>
 __device__ __forceinline__ void piece_load(Piece<T>& p, const T* src, bool ok) {
 #pragma unroll
-    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) p.v[u] = ok ? ((const uint4*)src)[u] : make_uint4(0, 0, 0, 0);
+    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) {
+        // `src` is always a readable address (callers pass the tensor base when !ok): load unconditionally and select, so the
+        // compiler emits one straight-line global_load per piece instead of an exec-masked branch around each of them
+        const uint4 v = ((const uint4*)src)[u];
+        p.v[u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void piece_load_raw(Piece<T>& p, const T* src) {
+#pragma unroll
+    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) p.v[u] = ((const uint4*)src)[u];
+}
+template <typename T>
+__device__ __forceinline__ void piece_store_sel(const Piece<T>& p, bool ok, char* dst) {     // zero when !ok (decided at store time)
+#pragma unroll
+    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u)
+        ((uint4*)dst)[u] = make_uint4(ok ? p.v[u].x : 0u, ok ? p.v[u].y : 0u, ok ? p.v[u].z : 0u, ok ? p.v[u].w : 0u);
 }
 template <typename T>
 __device__ __forceinline__ void piece_store(const Piece<T>& p, char* dst) {
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
         const int it = t + i * NT, half = it & 1, pos = it >> 1;
         const int x = pos % IW, y = (pos / IW) % IH, z = pos / (IW * IH);
         const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
-        const bool ok = (it < NPOS * 2) && (gz >= 0) && (gz < in_d) && (gy >= 0) && (gy < in_h) && (gx >= 0) && (gx < in_w);
+        const bool ok = (it < NPOS * 2) & (gz >= 0) & (gz < in_d) & (gy >= 0) & (gy < in_h) & (gx >= 0) & (gx < in_w);
         hoff[i] = ok ? (((gz * in_h + gy) * in_w + gx) * Cin + 8 * half) : -1;
     }
     const T* in_b = in + (size_t)b * in_d * in_h * in_w * Cin;
@@ -432,14 +448,18 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackTable tb) {
 }
 
 // ---------------------------------------------------------------------------------------------- wgrad
-// Workgroup: 4 waves; block of 64 cs x 32 cl; one depth tap kd (3D) / all taps (2D); wave w owns kh = w, kw = 0..3.
+// Workgroup: 8 waves; block of 64 cs x 32 cl; one depth tap kd (3D) / all taps (2D); wave w owns kh = w & 3, kw = 0..3 and
+// the 32-row half sg = w >> 2 of the cs block: 4 accumulator tiles (64 VGPRs), so two workgroups (16 waves) fit a CU with the
+// next tile's global loads held in registers during the MFMA phase.
 template <typename T, int ND>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split) {
+__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split) {
     using TL = Tile<ND, 128>;
+    constexpr int NT = 512;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
     constexpr int IH = 2 * TH + 2, IW = 2 * TW + 2;          // L tile: TD planes (one kd) x IH x IW positions x 32 cl
     constexpr int SROW = 64 * sizeof(T), LROW = 32 * sizeof(T);
     constexpr int S_BYTES = 128 * SROW;
+    constexpr int FB = 8 * sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_lds = smem;
     char* l_lds = smem + S_BYTES;
@@ -447,89 +467,135 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv_wgrad_kernel
     const int cl_blocks = g.Cl / 32;
     const int cs0 = (blockIdx.y / cl_blocks) * 64, cl0 = (blockIdx.y % cl_blocks) * 32;
     const int kd = (ND == 3) ? blockIdx.z : 0;
-    const int kh = wave;
+    const int kh = wave & 3, sg = wave >> 2;
+    // Bank-conflict-free LDS images for the transposing reads.  One 32-lane group of ds_read_b64_tr_b16 reads 4 k-rows x 64
+    // bytes = the whole 256-byte bank row, provided the 4 rows sit in 4 different 64-byte quarters.  The k-rows of a group are 4
+    // consecutive output positions m .. m+3 along w.  S image (128-byte rows): the 64-byte halves of row m are swapped when bit 1
+    // of m is set.  L image (64-byte rows): the stride-2 input columns x = 2 w + kw are split into an even-x and an odd-x plane,
+    // so consecutive w are consecutive rows of plane kw & 1 and every tap is a constant row offset (kw >> 1).
+    constexpr int LHALF = IW / 2, LPLANE = TD * IH * LHALF;  // rows per line / per parity plane
+    auto s_byte = [](int m, int c) -> int { return m * SROW + ((((c >> 3) ^ (((m >> 1) & 1) << 2)) << 3) + (c & 7)) * (int)sizeof(T); };
+    auto l_row = [](int line, int x) -> int { return (x & 1) * LPLANE + line * LHALF + (x >> 1); };
     const int tiles_per_b = g.tiles_d * g.tiles_h * g.tiles_w, total_tiles = g.B * tiles_per_b;
+#ifdef CVAE_STAMP
+    const unsigned stamp_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (t == 0 && stamp_wg < CVAE_STAMP_WGS) {
+        g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 30] = wall_clock64();
+        g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 29] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    }
+    int stamp_it = 0;
+#endif
+    STAMP(0);
 
-    f32x16 acc[2][4];
+    f32x16 acc[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[s][k][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
-    for (int tile = blockIdx.x; tile < total_tiles; tile += n_split) {
+    // S tile: 128 positions x 64 channels; L tile: planes lz = 2 (o0d + d) - 1 + kd, rows 2 o0h - 1 + y, cols 2 o0w - 1 + x.
+    // Both LDS images are piece-linear (piece `it` at byte 16 it / 32 it).  The global loads of tile i+1 are issued right after
+    // tile i has been stored to LDS, so they are in flight during tile i's MFMA phase; out-of-range pieces are loaded from a
+    // clamped (valid) address and zeroed when they are stored, which keeps the loads unconditional and straight-line.
+    // Addresses are 32-bit offsets inside one sample (geom_ok bounds the sample size) on a wave-uniform 64-bit base.
+    constexpr int SN = (128 * 8) / NT, LNPOS = TD * IH * IW, LN = (LNPOS * 4 + NT - 1) / NT;
+    Piece<T> sp[SN], lp[LN];
+    unsigned okmask = 0;
+    const int s_sample = g.sd * g.sh * g.sw * g.Cs, l_sample = g.ld * g.lh * g.lw * g.Cl;
+    auto load_tile = [&](int tile) {
         int tt = tile;
         const int tw_i = tt % g.tiles_w; tt /= g.tiles_w;
         const int th_i = tt % g.tiles_h; tt /= g.tiles_h;
         const int td_i = tt % g.tiles_d;
         const int b = tt / g.tiles_d;
         const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
-        // S tile: 128 positions x 64 channels; L tile: planes lz = 2 (o0d + d) - 1 + kd, rows 2 o0h - 1 + y, cols 2 o0w - 1 + x.
-        // All loads are issued before the barrier that retires the previous tile's readers, then stored.
-        constexpr int SN = (128 * 8) / 256, LNPOS = TD * IH * IW, LN = (LNPOS * 4 + 255) / 256;
-        Piece<T> sp[SN], lp[LN];
+        const T* Sb = S + (size_t)b * s_sample + cs0;
+        const T* Lb = L + (size_t)b * l_sample + cl0;
+        okmask = 0;
+        int tz = t;
+        asm volatile("" : "+v"(tz));                         // opaque: keeps the per-piece index math inside the call (hoisted, it spills)
 #pragma unroll
         for (int i = 0; i < SN; ++i) {
-            const int it = t + i * 256, piece = it & 7, m = it >> 3;
+            const int it = tz + i * NT, piece = it & 7, m = it >> 3;
             const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
             const int od = o0d + d, oh = o0h + hh, ow = o0w + w;
-            const bool ok = od < g.sd && oh < g.sh && ow < g.sw;
-            piece_load<T>(sp[i], S + (ok ? ((((size_t)b * g.sd + od) * g.sh + oh) * g.sw + ow) * g.Cs + cs0 + piece * 8 : 0), ok);
+            const bool ok = (od < g.sd) & (oh < g.sh) & (ow < g.sw);
+            const unsigned off = ((min(od, g.sd - 1) * g.sh + min(oh, g.sh - 1)) * g.sw + min(ow, g.sw - 1)) * g.Cs + piece * 8;
+            piece_load_raw<T>(sp[i], Sb + off);
+            okmask |= (unsigned)ok << i;
         }
 #pragma unroll
         for (int i = 0; i < LN; ++i) {
-            const int it = t + i * 256, piece = it & 3, pos = it >> 2;
+            const int it = tz + i * NT, piece = it & 3, pos = min(it >> 2, LNPOS - 1);
             const int x = pos % IW, y = pos / IW % IH, d = pos / (IW * IH);
             const int lz = (ND == 3) ? 2 * (o0d + d) - 1 + kd : 0, ly = 2 * o0h - 1 + y, lx = 2 * o0w - 1 + x;
-            const bool ok = it < LNPOS * 4 && lz >= 0 && lz < g.ld && ly >= 0 && ly < g.lh && lx >= 0 && lx < g.lw;
-            piece_load<T>(lp[i], L + (ok ? ((((size_t)b * g.ld + lz) * g.lh + ly) * g.lw + lx) * g.Cl + cl0 + piece * 8 : 0), ok);
+            const bool ok = (lz >= 0) & (lz < g.ld) & (ly >= 0) & (ly < g.lh) & (lx >= 0) & (lx < g.lw);
+            const unsigned off = ((min(max(lz, 0), g.ld - 1) * g.lh + min(max(ly, 0), g.lh - 1)) * g.lw + min(max(lx, 0), g.lw - 1)) * g.Cl + piece * 8;
+            piece_load_raw<T>(lp[i], Lb + off);
+            okmask |= (unsigned)ok << (SN + i);
+        }
+    };
+    if ((int)blockIdx.x < total_tiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < total_tiles; tile += n_split) {
+        __syncthreads();                                     // the previous tile's readers are done with both images
+#ifdef CVAE_STAMP
+        if (stamp_it < 8) STAMP(2 + 3 * stamp_it);
+#endif
+        {
+            int tz = t;
+            asm volatile("" : "+v"(tz));                     // as in load_tile: recompute, do not keep 8 offsets live across the MFMA phase
+#pragma unroll
+            for (int i = 0; i < SN; ++i) {
+                const int it = tz + i * NT;
+                piece_store_sel<T>(sp[i], (okmask >> i) & 1, s_lds + s_byte(it >> 3, (it & 7) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < LN; ++i) {
+                const int it = tz + i * NT, pos = it >> 2;
+                if (it < LNPOS * 4) piece_store_sel<T>(lp[i], (okmask >> (SN + i)) & 1, l_lds + (l_row(pos / IW, pos % IW) * 4 + (it & 3)) * FB);
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < SN; ++i) {
-            const int it = t + i * 256;
-            piece_store<T>(sp[i], s_lds + (it >> 3) * SROW + (it & 7) * 8 * sizeof(T));
-        }
-#pragma unroll
-        for (int i = 0; i < LN; ++i) {
-            const int it = t + i * 256;
-            if (it < LNPOS * 4) piece_store<T>(lp[i], l_lds + (it >> 2) * LROW + (it & 3) * 8 * sizeof(T));
-        }
-        __syncthreads();
+#ifdef CVAE_STAMP
+        if (stamp_it < 8) STAMP(3 + 3 * stamp_it);
+#endif
+        if (tile + n_split < total_tiles) load_tile(tile + n_split);
         if constexpr (sizeof(T) == 2) {
             // bf16: transposing LDS reads.  Lane i of 16-lane group gq supplies the address of k-row q = i>>2,
             // 4 channels at 4*(i&3); it receives channel i of the 4 k-rows  (cdna_hip_programming.md T10).
             const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
             const int hk = gq >> 1, colblk = gq & 1;
             typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-#pragma unroll 1
+            // k-row of (c, jj): position m = 16 c + r0 with r0 = 8 hk + 4 jj + q.  The lane part (w, hh) = (r0 % TW, r0 / TW) and
+            // the c part (hh, d) = (16 c / TW % TH, 16 c / (TW TH)) add without carries, so with the loop fully unrolled every
+            // LDS address below is one per-lane base plus a compile-time offset.
+            const char* abase[2];
+            const char* bbase[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int r0 = 8 * hk + 4 * jj + q;
+                abase[jj] = s_lds + s_byte(r0, sg * 32 + 16 * colblk + 4 * p);
+                bbase[jj] = l_lds + l_row(2 * (r0 / TW) + kh, 2 * (r0 % TW)) * LROW + (16 * colblk + 4 * p) * 2;
+            }
+#pragma unroll
             for (int c = 0; c < 8; ++c) {
-                bf16x8 a[2];
-                int lpos[2];
+                const int hh_c = (16 * c / TW) % TH, d_c = (16 * c) / (TW * TH);
+                bf16x8 a;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    const int m = 16 * c + 8 * hk + 4 * jj + q;
-                    const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
-                    lpos[jj] = (d * IH + 2 * hh + kh) * IW + 2 * w;
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const char* ap = s_lds + m * SROW + (s * 32 + 16 * colblk + 4 * p) * 2;
-                        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)ap);
-                        a[s][4 * jj + 0] = v[0]; a[s][4 * jj + 1] = v[1]; a[s][4 * jj + 2] = v[2]; a[s][4 * jj + 3] = v[3];
-                    }
+                    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(abase[jj] + 16 * c * SROW));
+                    a[4 * jj + 0] = v[0]; a[4 * jj + 1] = v[1]; a[4 * jj + 2] = v[2]; a[4 * jj + 3] = v[3];
                 }
 #pragma unroll
                 for (int kw = 0; kw < 4; ++kw) {
                     bf16x8 bv;
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        const char* bp = l_lds + (lpos[jj] + kw) * LROW + (16 * colblk + 4 * p) * 2;
+                        const char* bp = bbase[jj] + (((kw & 1) * LPLANE + (d_c * IH + 2 * hh_c) * LHALF + (kw >> 1)) * LROW);
                         const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)bp);
                         bv[4 * jj + 0] = v[0]; bv[4 * jj + 1] = v[1]; bv[4 * jj + 2] = v[2]; bv[4 * jj + 3] = v[3];
                     }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) acc[s][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bv, acc[s][kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[kw], 0, 0, 0);
                 }
             }
         } else {
@@ -539,33 +605,38 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void conv_wgrad_kernel
             for (int mm = 0; mm < 128; mm += 2) {
                 const int m = mm + hk;
                 const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
-                const int lp = (d * IH + 2 * hh + kh) * IW + 2 * w;
-                float a[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) a[s] = *(const float*)(s_lds + m * SROW + (s * 32 + r) * 4);
+                const int line = d * IH + 2 * hh + kh;
+                const float a = *(const float*)(s_lds + s_byte(m, sg * 32 + r));
 #pragma unroll
                 for (int kw = 0; kw < 4; ++kw) {
-                    const float bv = *(const float*)(l_lds + (lp + kw) * LROW + r * 4);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) acc[s][kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv, acc[s][kw], 0, 0, 0);
+                    const float bv = *(const float*)(l_lds + l_row(line, 2 * w + kw) * LROW + r * 4);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[kw], 0, 0, 0);
                 }
             }
         }
+#ifdef CVAE_STAMP
+        if (stamp_it < 8) STAMP(4 + 3 * stamp_it);
+        ++stamp_it;
+#endif
     }
+    STAMP(26);
     // ---- write-out: this workgroup's partial sums leave as ONE slab [kh][kw][64 cs][32 cl] of plain 128-byte-row stores;
     // wgrad_reduce_kernel sums the slabs (fp32 atomics here cost more than the MFMA phase: 67 MB of adds at < 1 TB/s) ----
     if (!ws) return;                                          // tuning only: measure the accumulate phase alone
     const int col = lane & 31, hq = lane >> 5;
     float* slab = ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * n_split + blockIdx.x) * 32768;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = s * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
-                slab[((kh * 4 + kw) * 64 + row) * 32 + col] = acc[s][kw][e];
-            }
+        for (int e = 0; e < 16; ++e) {
+            const int row = sg * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
+            slab[((kh * 4 + kw) * 64 + row) * 32 + col] = acc[kw][e];
+        }
+#ifdef CVAE_STAMP
+    __builtin_amdgcn_s_waitcnt(0);
+    STAMP(27);
+    if (t == 0 && stamp_wg < CVAE_STAMP_WGS) g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 31] = wall_clock64();
+#endif
 }
 
 // dW[cs][cl][kd][kh][0..3] = sum over the n_split slabs of group (kd, channel block).  One thread per (kd, kh, cs, cl)
@@ -620,7 +691,7 @@ int launch_wgrad(const void* S, const void* L, float* ws, float* dW, ConvGeom g,
     if (n_split > total_tiles) n_split = total_tiles;
     if (cb > 65535) return CVAE_E_BADSHAPE;
     dim3 grid((unsigned)n_split, (unsigned)cb, (unsigned)tg);
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, (const T*)S, (const T*)L, getenv("CVAE_TUNE_WGRAD_NOREDUCE") ? nullptr : ws, g, (int)n_split);
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, (const T*)S, (const T*)L, getenv("CVAE_TUNE_WGRAD_NOREDUCE") ? nullptr : ws, g, (int)n_split);
     CVAE_CHECK_LAUNCH();
     if (getenv("CVAE_TUNE_WGRAD_NOREDUCE")) return CVAE_OK;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cb * tg * 4 * 32)), dim3(256), 0, stream, (const float*)ws, dW, g.Cs, g.Cl, (ND == 3) ? 64 : 16, (int)n_split, cb);
@@ -633,6 +704,7 @@ bool geom_ok(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t 
     if (B < 0 || sd <= 0 || sh <= 0 || sw <= 0 || Cs <= 0 || ld <= 0 || lh <= 0 || lw <= 0 || Cl <= 0) return false;
     if (B > 65535 || sd > 32767 || sh > 32767 || sw > 32767 || ld > 65535 || lh > 65535 || lw > 65535) return false;
     if (nd == 2 && (sd != 1 || ld != 1)) return false;
+    if (sd * sh * sw * Cs >= (int64_t(1) << 31) || ld * lh * lw * Cl >= (int64_t(1) << 31)) return false;   // 32-bit offsets inside a sample
     auto pair_ok = [](int64_t s, int64_t l) { return s == l / 2; };        // floor((l + 2 - 4) / 2) + 1 == l / 2
     if (nd == 3 && !pair_ok(sd, ld)) return false;
     return pair_ok(sh, lh) && pair_ok(sw, lw) && lh >= 2 && lw >= 2 && (nd == 2 || ld >= 2);

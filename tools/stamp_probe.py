@@ -22,8 +22,10 @@ Lt = (torch.randn(B, *lp, Cl, device="cuda") * 0.5).to(dt)
 w = torch.randn(Cs, Cl, 4, 4, 4, device="cuda") * 0.05
 if kind == "down":
     wp = ops.pack_weight(w, 3, False, dt); fn = lambda: ops._conv_down(Lt, wp, None, S, Cs, 3, None)
-else:
+elif kind == "up":
     wp = ops.pack_weight(w, 3, True, dt); fn = lambda: ops._conv_up(S, wp, None, Lt, Cl, 3, None)
+else:
+    fn = lambda: ops._conv_wgrad(S, Lt, 3, w.shape)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()
