@@ -40,8 +40,9 @@ SIGNATURES = {
     "cvae_conv_packed_weight_bytes": [_i64, _i64, _i, _i],
     "cvae_conv_pack_weight": [_p, _p, _i64, _i64, _i, _i, _i, _p],
     "cvae_conv_pack_weights": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "cvae_conv_down": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p],
-    "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p],
+    "cvae_conv_data_workspace_bytes": [_i64] * 9 + [_i, _i],
+    "cvae_conv_down": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
+    "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
     "cvae_conv_wgrad_workspace_bytes": [_i64, _i64, _i],
     "cvae_conv_wgrad": [_p, _p, _p, _p, _p, _sz] + [_i64] * 9 + [_i, _i, _p],
     "cvae_channel_sum": [_p, _p, _i64, _i64, _i, _p],
@@ -82,7 +83,8 @@ SIGNATURES = {
     "cvae_scale": [_p, _i64, _p, _p],
     "cvae_clip_coef": [_p, _p, _f, _p],
 }
-_RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz}
+_RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
+            "cvae_conv_data_workspace_bytes": _sz}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library disagree: fail at import

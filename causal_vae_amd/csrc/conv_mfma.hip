@@ -136,7 +136,8 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // EPI: 0 = bias only, 1 = bias + ReLU, 2 = generic activation code
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
-                                                                  const T* __restrict__ mask, T* __restrict__ out, ConvGeom g, int act) {
+                                                                  const T* __restrict__ mask, T* __restrict__ out, ConvGeom g, int act,
+                                                                  float* __restrict__ ws, int ksplit) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
@@ -175,7 +176,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     const int b = blockIdx.z;
     const int Cin = UP ? g.Cs : g.Cl, Cout = UP ? g.Cl : g.Cs;
     const int nblocks = Cout / BN;
-    const int nb = blockIdx.y % nblocks, par = blockIdx.y / nblocks;    // par: output parity class (UP only)
+    constexpr int NPAR = UP ? (ND == 3 ? 8 : 4) : 1;
+    // blockIdx.y = (ks * NPAR + par) * nblocks + nb; par: output parity class (UP only); ks: split-K slice of the channel chunks
+    const int nb = blockIdx.y % nblocks, par = (blockIdx.y / nblocks) % NPAR, ks = blockIdx.y / (nblocks * NPAR);
     const int prd = (UP && ND == 3) ? ((par >> 2) & 1) : 0, prh = UP ? ((par >> 1) & 1) : 0, prw = UP ? (par & 1) : 0;
     const int n0 = nb * BN;
     int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -254,14 +257,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     };
 
     STAMP(1);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int chunk_per = nchunks / ksplit;                 // host guarantees ksplit divides nchunks
+    for (int chunk = ks * chunk_per; chunk < (ks + 1) * chunk_per; ++chunk) {
         {
             Piece<T> hp[HN], pb0[BP];
 #pragma unroll
             for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * 16, hoff[i] >= 0);
             load_b(pb0, chunk, 0);
             __syncthreads();                               // previous chunk's readers are done with halo + B buffers
-            if (chunk < 8) STAMP(2 + 3 * chunk);
+            if (chunk - ks * chunk_per < 8) STAMP(2 + 3 * (chunk - ks * chunk_per));
 #pragma unroll
             for (int i = 0; i < HN; ++i) {
                 const int it = t + i * NT, pos = it >> 1;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
             store_b(pb0, 0);
         }
         __syncthreads();
-        if (chunk < 8) STAMP(3 + 3 * chunk);
+        if (chunk - ks * chunk_per < 8) STAMP(3 + 3 * (chunk - ks * chunk_per));
         // Weight panels ride a 2-deep ring: the panel of group g+2 is loaded into registers at the start of group g and
         // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
         // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
                 __syncthreads();
             }
         }
-        if (chunk < 8) STAMP(4 + 3 * chunk);
+        if (chunk - ks * chunk_per < 8) STAMP(4 + 3 * (chunk - ks * chunk_per));
     }
     STAMP(26);
 
@@ -331,6 +335,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
                 const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 + i]), __float_as_uint(acc[mi][ni][12 + i]), false, false);
                 v[0][i] = __uint_as_float(lo[0]); v[0][4 + i] = __uint_as_float(lo[1]);
                 v[1][i] = __uint_as_float(hi[0]); v[1][4 + i] = __uint_as_float(hi[1]);
+            }
+            if (ksplit > 1) {
+                // split-K: this workgroup saw only its slice of the input channels; leave the raw fp32 partial sums in slab ks of
+                // the workspace ([ks][B][positions][Cout]); conv_splitk_finish_kernel adds the slabs, bias, activation and mask.
+                if (ok) {
+                    float* wrow = ws + (size_t)ks * g.B * out_d * out_h * out_w * Cout + pidx;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
+                        *(float4*)(wrow + c) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                        *(float4*)(wrow + c + 4) = make_float4(v[j][4], v[j][5], v[j][6], v[j][7]);
+                    }
+                }
+                continue;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -369,8 +387,51 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #endif
 }
 
+// out[p][c] = act(sum_ks ws[ks][p][c] + bias[c]) (* mask > 0): 8 channels per thread, 16-byte bf16 stores.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, const T* __restrict__ mask,
+                                                                  T* __restrict__ out, int64_t total, int Cout, int ksplit, int act) {
+    const int64_t i8 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i8 >= total) return;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    for (int k = 0; k < ksplit; ++k) {
+        const float4 a = *(const float4*)(ws + (size_t)k * total + i8), b = *(const float4*)(ws + (size_t)k * total + i8 + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const int c = (int)(i8 % Cout);
+    Piece<T> mp, op;
+    if (mask) piece_load_raw<T>(mp, mask + i8);
+    const T* mv = (const T*)&mp;
+    T* ov = (T*)&op;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float x = v[q] + (bias ? bias[c + q] : 0.f);
+        x = apply_act(x, act);
+        if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
+        ov[q] = from_f32<T>(x);
+    }
+    piece_store<T>(op, (char*)(out + i8));
+}
+
+// Split-K factor for a launch of `nwg` workgroups over `nchunks` channel chunks: the layers with 8^3 / 4^3 grids fill a fraction
+// of the 256 CUs with one long serial K loop each; slicing K puts ~2 workgroups on every CU.  Largest divisor of nchunks <= target.
+// Only `down` splits: an `up` launch already has 8 (4) parity classes per tile and its output is 8x (4x) its input, so the fp32 slabs
+// cost more than the shorter K loop saves (measured: enc4 backward-data 23 -> 34 us, dec2 forward 12 -> 22 us with split-K).
+static int pick_ksplit(bool up, long long nwg, int nchunks) {
+    if (up || nwg >= 384 || nchunks < 2) return 1;
+    long long target = (512 + nwg - 1) / nwg;
+    if (target > 16) target = 16;
+    int best = 1;
+    for (int d = 1; d <= nchunks && d <= target; ++d)
+        if (nchunks % d == 0) best = d;
+    return best;
+}
+
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI>
-int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream) {
+int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
     constexpr int ID = (ND == 3) ? (UP ? TL::TD + 2 : 2 * TL::TD + 2) : 1;
@@ -387,21 +448,44 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     }
     const int md = UP ? ((ND == 3) ? (g.ld + 1) / 2 : 1) : g.sd, mh = UP ? (g.lh + 1) / 2 : g.sh, mw = UP ? (g.lw + 1) / 2 : g.sw;
     g.tiles_d = (md + TL::TD - 1) / TL::TD; g.tiles_h = (mh + TL::TH - 1) / TL::TH; g.tiles_w = (mw + TL::TW - 1) / TL::TW;
-    const int Cout = UP ? g.Cl : g.Cs;
+    const int Cout = UP ? g.Cl : g.Cs, Cin = UP ? g.Cs : g.Cl;
     const int npar = UP ? ((ND == 3) ? 8 : 4) : 1;
-    const long long gy = (long long)(Cout / BN) * npar;
+    const long long tiles = (long long)g.tiles_d * g.tiles_h * g.tiles_w;
+    long long gy = (long long)(Cout / BN) * npar;
+    const int64_t total = (int64_t)g.B * (UP ? (int64_t)g.ld * g.lh * g.lw : (int64_t)g.sd * g.sh * g.sw) * Cout;
+    int ksplit = pick_ksplit(UP, tiles * gy * g.B, Cin / 16);
+    if (!workspace || workspace_bytes < (size_t)ksplit * total * sizeof(float)) ksplit = 1;     // no (or too small a) workspace: unsplit
+    gy *= ksplit;
     if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
-    dim3 grid((unsigned)(g.tiles_d * g.tiles_h * g.tiles_w), (unsigned)gy, (unsigned)g.B);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const T*)mask, (T*)out, g, act);
+    dim3 grid((unsigned)tiles, (unsigned)gy, (unsigned)g.B);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const T*)mask, (T*)out, g, act, (float*)workspace, ksplit);
     CVAE_CHECK_LAUNCH();
+    if (ksplit > 1) {
+        hipLaunchKernelGGL(conv_splitk_finish_kernel<T>, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, bias,
+                           (const T*)mask, (T*)out, total, Cout, ksplit, act);
+        CVAE_CHECK_LAUNCH();
+    }
     return CVAE_OK;
 }
 
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
-int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream) {
-    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0>(in, wp, bias, mask, out, g, act, stream);
-    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1>(in, wp, bias, mask, out, g, act, stream);
-    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2>(in, wp, bias, mask, out, g, act, stream);
+int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* ws, size_t wsb, hipStream_t stream) {
+    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+}
+
+// Workspace the split-K path of launch_data would use for this geometry (0: the launch fills the chip without it).
+template <int ND, bool UP, int BM, int BN>
+size_t data_workspace_bytes(const ConvGeom& g) {
+    using TL = Tile<ND, BM>;
+    const int md = UP ? ((ND == 3) ? (g.ld + 1) / 2 : 1) : g.sd, mh = UP ? (g.lh + 1) / 2 : g.sh, mw = UP ? (g.lw + 1) / 2 : g.sw;
+    const long long tiles = (long long)((md + TL::TD - 1) / TL::TD) * ((mh + TL::TH - 1) / TL::TH) * ((mw + TL::TW - 1) / TL::TW);
+    const int Cout = UP ? g.Cl : g.Cs, Cin = UP ? g.Cs : g.Cl;
+    const int npar = UP ? ((ND == 3) ? 8 : 4) : 1;
+    const int ksplit = pick_ksplit(UP, tiles * (Cout / BN) * npar * g.B, Cin / 16);
+    if (ksplit <= 1) return 0;
+    return (size_t)ksplit * g.B * (UP ? (size_t)g.ld * g.lh * g.lw : (size_t)g.sd * g.sh * g.sw) * Cout * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -780,9 +864,23 @@ extern "C" int cvae_conv_pack_weights(const float* const* w, void* const* packed
 
 #define GEOM_INIT() ConvGeom g{(int)B, (int)sd, (int)sh, (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, (int)Cl, 0, 0, 0}
 
+extern "C" size_t cvae_conv_data_workspace_bytes(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                                                  int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int for_up) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || B == 0 || Cl == 1) return 0;
+    GEOM_INIT();
+    if (!for_up) {
+        if (Cl % 16 || Cs % 64) return 0;
+        return nd == 3 ? data_workspace_bytes<3, false, 128, 64>(g) : data_workspace_bytes<2, false, 128, 64>(g);
+    }
+    if (Cs % 16 || Cl % 32) return 0;
+    if (Cl % 64 == 0) return nd == 3 ? data_workspace_bytes<3, true, 128, 64>(g) : data_workspace_bytes<2, true, 128, 64>(g);
+    return nd == 3 ? data_workspace_bytes<3, true, 256, 32>(g) : data_workspace_bytes<2, true, 256, 32>(g);
+}
+
 extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
                               int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                              int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream) {
+                              int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (B == 0) return CVAE_OK;
@@ -791,15 +889,16 @@ extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, c
     if (Cl == 1) return cvae_conv_down_c1(L, (const float*)w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
     if (Cl % 16 || Cs % 64) return CVAE_E_UNSUPPORTED;
     GEOM_INIT();
-    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st)
-                                           : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st);
-    return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st)
-                   : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, st);
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
+                                           : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
+    return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
+                   : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
 }
 
 extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
                             int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                            int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream) {
+                            int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (B == 0) return CVAE_OK;
@@ -810,11 +909,11 @@ extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, con
     GEOM_INIT();
     const bool wide = (Cl % 64) == 0;     // N tile 64 (2x2 waves, 128 rows) else N tile 32 (4x1 waves, 256 rows)
     if (dtype == CVAE_BF16) {
-        if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
-        return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+        if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
+        return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
     }
-    if (nd == 3) return wide ? launch_data<float, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<float, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
-    return wide ? launch_data<float, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : launch_data<float, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+    if (nd == 3) return wide ? launch_data<float, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<float, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
+    return wide ? launch_data<float, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<float, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
 }
 
 extern "C" size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd) {

@@ -223,12 +223,24 @@ def pack_weights(weights, nd, dtype):
     return outs
 
 
+SPLIT_K = True      # hand the conv data kernels their split-K scratch (tests switch it off to cover the unsplit path)
+
+
+def _conv_data_workspace(device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, for_up):
+    """Split-K scratch for the small-grid layers (cvae_conv_data_workspace_bytes; 0 bytes for the large ones)."""
+    nbytes = lib.cvae_conv_data_workspace_bytes(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, for_up) if SPLIT_K else 0
+    if not nbytes:
+        return None, 0
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
 def _conv_down(Lt, wp, bias, mask, Cs, nd, act):
     B, ld, lh, lw, Cl = _cl_dims(Lt)
     sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
     S = _empty((B, sd, sh, sw, Cs), Lt.dtype, Lt)
+    ws, nbytes = _conv_data_workspace(Lt.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, 0)
     check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down, ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S),
-                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(Lt.dtype), L.act_code(act), stream()), "conv_down")
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(Lt.dtype), L.act_code(act), ptr(ws), nbytes, stream()), "conv_down")
     return S
 
 
@@ -236,8 +248,9 @@ def _conv_up(St, wp, bias, mask, Cl, nd, act):
     B, sd, sh, sw, Cs = _cl_dims(St)
     ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
     Lt = _empty((B, ld, lh, lw, Cl), St.dtype, St)
+    ws, nbytes = _conv_data_workspace(St.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, 1)
     check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up, ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt),
-                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), L.act_code(act), stream()), "conv_up")
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), L.act_code(act), ptr(ws), nbytes, stream()), "conv_up")
     return Lt
 
 

@@ -82,14 +82,21 @@ int cvae_conv_pack_weight(const float* w, void* packed, int64_t Cs, int64_t Cl, 
 int cvae_conv_pack_weights(const float* const* w, void* const* packed, const int64_t* Cs, const int64_t* Cl, const int* for_up,
                            int count, int nd, int dtype, void* stream);
 
+/* Optional scratch for cvae_conv_down (for_up = 0) / cvae_conv_up (for_up = 1): layers whose output grid is too small to fill
+ * the chip (8^3, 4^3 volumes) split the input-channel loop over workgroups and sum fp32 partial tiles from this buffer.
+ * Returns 0 when the launch needs none.  Passing NULL / a smaller buffer is always valid: the launch then runs unsplit. */
+size_t cvae_conv_data_workspace_bytes(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                                      int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int for_up);
 /* S = act(gather(L, w) + bias) [then * (mask > 0) if mask != NULL].  bias fp32 [Cs] or NULL; mask has S's shape/dtype. */
 int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
                    int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                   int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream);
+                   int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                   void* workspace, size_t workspace_bytes, void* stream);
 /* L = act(scatter(S, w) + bias) [then * (mask > 0) if mask != NULL].  bias fp32 [Cl] or NULL; mask has L's shape/dtype. */
 int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
                  int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                 int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act, void* stream);
+                 int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                 void* workspace, size_t workspace_bytes, void* stream);
 /* dW fp32 [Cs][Cl][taps] (overwritten) = sum over batch and positions.  workspace: cvae_conv_wgrad_workspace_bytes().
  * dbias (optional, fp32 [Cs], overwritten) = sum over batch and positions of S: the bias gradient of a Conv layer, whose
  * S is the output gradient (fused into the weight-gradient pass where S is read anyway). */

@@ -69,9 +69,17 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=[True, False], ids=["splitk", "unsplit"])
+def split_k(request):
+    """Small test volumes would all take the split-K path (few workgroups); run every conv case both ways."""
+    old, ops.SPLIT_K = ops.SPLIT_K, request.param
+    yield request.param
+    ops.SPLIT_K = old
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("nd,B,Cl,Cs,size", CONV_CASES)
-def test_conv_forward_backward(nd, B, Cl, Cs, size, dtype):
+def test_conv_forward_backward(nd, B, Cl, Cs, size, dtype, split_k):
     """nn.Conv{2,3}d(k4,s2,p1)+bias+ReLU: y, dx, dW, db (down / up / wgrad / channel_sum kernels)."""
     g = torch.Generator().manual_seed(1)
     conv = F.conv2d if nd == 2 else F.conv3d
@@ -97,7 +105,7 @@ def test_conv_forward_backward(nd, B, Cl, Cs, size, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("nd,B,Cl,Cs,size", CONV_CASES)
-def test_conv_transpose_forward_backward(nd, B, Cl, Cs, size, dtype):
+def test_conv_transpose_forward_backward(nd, B, Cl, Cs, size, dtype, split_k):
     """nn.ConvTranspose{2,3}d(k4,s2,p1)+bias (+ReLU): input is the SMALL tensor (Cs channels), output the large one."""
     g = torch.Generator().manual_seed(2)
     convT = F.conv_transpose2d if nd == 2 else F.conv_transpose3d
