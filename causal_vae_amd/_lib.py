@@ -82,6 +82,9 @@ SIGNATURES = {
     "cvae_sqnorm": [_p, _p, _i64, _p],
     "cvae_scale": [_p, _i64, _p, _p],
     "cvae_clip_coef": [_p, _p, _f, _p],
+    "cvae_bottleneck_sizes": [_p, _p, _p, _p, _p, _p],
+    "cvae_bottleneck_fwd": [_p] * 9 + [_f, _f, _i, _p, _p, _p, _p, _i, _p],
+    "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
             "cvae_conv_data_workspace_bytes": _sz}
@@ -90,6 +93,25 @@ for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library disagree: fail at import
     _fn.argtypes = _args
     _fn.restype = _RESTYPE.get(_name, _i)
+
+
+class BottleneckDims(C.Structure):
+    """cvae_bottleneck_dims"""
+    _fields_ = [(n, _i64) for n in ("M", "D", "H", "W", "C", "OD", "OH", "OW", "m_dim", "t_dim", "N1", "N2", "Z", "HM")]
+
+
+BOTTLENECK_PARAMS = ("W1", "b1", "W2", "b2", "Wmu", "bmu", "Wlv", "blv", "Wm0", "bm0", "gamma", "beta", "Wm3", "bm3", "Wm5", "bm5", "Wd", "bd")
+BOTTLENECK_SAVED = ("h1", "h2", "mu", "logvar", "xhat", "invstd", "a1n", "a2", "m_hat", "zm")
+
+
+class BottleneckPtrs18(C.Structure):
+    """cvae_bottleneck_params / cvae_bottleneck_grads: 18 device pointers in BOTTLENECK_PARAMS order"""
+    _fields_ = [(n, _p) for n in BOTTLENECK_PARAMS]
+
+
+class BottleneckSaved(C.Structure):
+    """cvae_bottleneck_saved"""
+    _fields_ = [(n, _p) for n in BOTTLENECK_SAVED]
 
 
 class KernelTimer:

@@ -80,15 +80,40 @@ class CausalBioVAE(nn.Module):
             return ops.FromChannelsLast.apply(rec, nd)
         return rec.view(rec.shape[0], 1, *(size if nd == 3 else size[1:]))
 
+    fuse_bottleneck = True     # training forward: run pool .. dec_input as ops.BioBottleneck (4 + 4 launches) when the shapes allow
+
+    def _fused_bottleneck(self, x, m, t_onehot, eps):
+        """The same computation as encode -> reparameterize -> mechanism_net -> dec_input, layer for layer, in csrc/bottleneck.hip.
+        Returns None (caller takes the layer-by-layer path) in eval mode, for B > 16 / B == 1, or pool windows that do not tile."""
+        h, rest, last_act = self.enc_conv.features_cl(x)
+        nd = self._ND
+        out_size = (4,) * 3 if nd == 3 else (1, 4, 4)
+        bn = self.mechanism_net[1]
+        if (not ops.BioBottleneck.supported(h, out_size, self.training) or last_act != "relu" or not bn.track_running_stats or bn.momentum is None
+                or not torch.is_grad_enabled()):
+            return None
+        if eps is None:
+            eps = self._eps.draw(torch.empty(x.shape[0], self.fc_mu.out_features, device=x.device))
+        lin = [self.enc_fc[0], self.enc_fc[2], self.fc_mu, self.fc_logvar, self.mechanism_net[0]]
+        params = [p for l in lin for p in (l.weight, l.bias)] + [bn.weight, bn.bias]
+        params += [p for l in (self.mechanism_net[3], self.mechanism_net[5], self.dec_input) for p in (l.weight, l.bias)]
+        mu, logvar, m_hat, dec_cl = ops.BioBottleneck.apply(h, m, t_onehot, eps, *params, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                            bn.momentum, bn.eps, out_size)
+        return mu, logvar, m_hat, self.dec_conv.forward_from_cl(dec_cl)
+
     def forward(self, x, m, t, eps=None):
         nd = self._ND
         if x.dim() != nd + 2:
             raise RuntimeError(f"{type(self).__name__} expects a {nd + 2}-D input [B, C, {'D, ' if nd == 3 else ''}H, W], got {tuple(x.shape)}")
         t_onehot = ops.one_hot(t, self.t_dim)
-        mu, logvar = self.encode(x, m, t_onehot)
-        z = self.reparameterize(mu, logvar, eps)
-        m_hat = self.mechanism_net(t_onehot)
-        out_cl = self.decode_cl(ops.cat([z, m_hat]))
+        fused = self._fused_bottleneck(x, m, t_onehot, eps) if self.fuse_bottleneck else None
+        if fused is not None:
+            mu, logvar, m_hat, out_cl = fused
+        else:
+            mu, logvar = self.encode(x, m, t_onehot)
+            z = self.reparameterize(mu, logvar, eps)
+            m_hat = self.mechanism_net(t_onehot)
+            out_cl = self.decode_cl(ops.cat([z, m_hat]))
         size = tuple(x.shape[2:]) if nd == 3 else (1,) + tuple(x.shape[2:])
         if tuple(out_cl.shape[1:4]) == size:
             recon_cl = ops.Cast.apply(out_cl, torch.float32)   # F.interpolate to the same size is the identity

@@ -1,0 +1,782 @@
+// bottleneck.hip — the dense middle of CausalBioVAE (causal_cascade/models.py:57-79 of the reference) for small batches.
+//
+// Between the last encoder conv and the first decoder conv the model is ~25 tiny fp32 ops on a batch of <= 16 rows
+// (pool, concat, enc_fc x2, fc_mu / fc_logvar, reparameterize, mechanism_net with BatchNorm1d, concat, dec_input) and as
+// many again in backward.  Only two of them move real data: enc_fc.0 (a 512 x 16415 weight, 33.6 MB) and dec_input
+// (16384 x 76, 5 MB).  As single launches each op pays ~5 us of launch / dependency latency for < 1 us of work, and the two big
+// ones ran at < 2 TB/s.  Here every dependency LEVEL of that graph is one wide launch (a single workgroup walking the whole chain
+// was tried first and is latency-bound: ~200 us), five forward and five backward:
+//
+//   forward   pool_cat_fwd        avg-pool + flatten + concat [feat, m, t]                                 -> xcat [M][K1]
+//             skinny_fwd_partial  enc_fc.0 as a split-K weight stream -> partial [KS][M][N1]; one extra block runs the whole
+//                                 mechanism_net (Linear, BatchNorm1d batch statistics + running stats, ReLU, Linear, ReLU, Linear)
+//             fc2_fwd             bias + ReLU of the partials, enc_fc.2 + ReLU (one wave per row)           -> h1, h2
+//             mulv_fwd            fc_mu, fc_logvar, reparameterize (one wave per latent)                    -> mu, logvar, zm = [z, m_hat]
+//             dec_input_fwd       dec_input + bias, written channels-last in the conv dtype                -> [M][S][C]
+//   backward  dec_input_bwd       dW, db of dec_input and per-cell partials of d(zm)
+//             mulv_bwd            reparameterize / fc_mu / fc_logvar backward by weight columns             -> dh2
+//             fc2_bwd             enc_fc.2 backward by weight columns                                       -> g1 = d(enc_fc.0 output), db1
+//             skinny_bwd_colwise  enc_fc.0: dW (33.6 MB written) and the partial d(xcat) in one pass over W; one extra block runs
+//                                 mechanism_net's backward (BatchNorm1d included)
+//             pool_bwd            sums the partials, spreads them over the pooling windows, applies the ReLU mask
+//
+// All arithmetic is fp32 (as in the unfused path); M <= 16.
+#include "common.h"
+
+#define BN_MAXM 16
+
+namespace {
+
+struct TailDims { int M, N1, N2, Z, T, HM, DM, KS, P; };     // N1 = 512, N2 = 256, Z = latent, T = t_dim, HM = 64, DM = m_dim
+struct TailParams {
+    const float *b1, *W2, *b2, *Wmu, *bmu, *Wlv, *blv, *Wm0, *bm0, *gamma, *beta, *Wm3, *bm3, *Wm5, *bm5;
+};
+struct TailGrads {
+    float *db1, *dW2, *db2, *dWmu, *dbmu, *dWlv, *dblv, *dWm0, *dbm0, *dgamma, *dbeta, *dWm3, *dbm3, *dWm5, *dbm5;
+};
+// saved activations (global), all [M][dim] row-major
+struct TailSaved { float *h1, *h2, *mu, *logvar, *xhat, *invstd, *a1n, *a2, *m_hat, *zm; };
+struct MechFwdArgs { const float* t_onehot; float *running_mean, *running_var; long long* num_batches_tracked; float momentum, bn_eps; int bn_training; };
+struct MechBwdArgs { const float *dzm_part, *g_mhat, *t_onehot; };
+
+__device__ __forceinline__ int pool_lo(int o, int in, int out) { return (o * in) / out; }
+__device__ __forceinline__ int pool_hi(int o, int in, int out) { return ((o + 1) * in + out - 1) / out; }
+
+// ------------------------------------------------------------------------------------------------ pool_cat_fwd
+// grid (S + 1, M): block (s, b) averages window s of sample b for all C channels (coalesced along c) and writes
+// xcat[b][c * S + s]; block (S, b) copies m and t behind the features.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_cat_fwd_kernel(const T* __restrict__ y, const float* __restrict__ m, const float* __restrict__ t,
+                                                           float* __restrict__ xcat, int D, int H, int W, int C, int OD, int OH, int OW,
+                                                           int m_dim, int t_dim, int K1) {
+    const int S = OD * OH * OW, b = blockIdx.y, s = blockIdx.x;
+    float* row = xcat + (size_t)b * K1;
+    if (s == S) {
+        for (int i = threadIdx.x; i < m_dim + t_dim; i += 256) row[C * S + i] = i < m_dim ? m[b * m_dim + i] : t[b * t_dim + i - m_dim];
+        return;
+    }
+    const int ow = s % OW, oh = (s / OW) % OH, od = s / (OW * OH);
+    const int d0 = pool_lo(od, D, OD), d1 = pool_hi(od, D, OD), h0 = pool_lo(oh, H, OH), h1 = pool_hi(oh, H, OH), w0 = pool_lo(ow, W, OW), w1 = pool_hi(ow, W, OW);
+    const float inv = 1.f / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int d = d0; d < d1; ++d)
+            for (int h = h0; h < h1; ++h)
+                for (int w = w0; w < w1; ++w) acc += to_f32(y[((((size_t)b * D + d) * H + h) * W + w) * C + c]);
+        row[c * S + s] = acc * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ skinny_fwd_partial
+// partial[ks][m][n] = sum_{k in slice ks} x[m][k] W[n][k].  grid (N / 4, KS), 256 threads: 4 weight rows per workgroup share one
+// pass over the x slice; rows are read with coalesced 4-byte loads (K is odd in the model: rows are not 16-byte aligned).
+__device__ void mech_fwd(const TailDims& d, const TailParams& p, const TailSaved& sv, const float* __restrict__ t_onehot, float* __restrict__ running_mean,
+                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked, float momentum, float bn_eps, int bn_training, float* lds);
+__device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads& gr, const TailSaved& sv, const float* __restrict__ dzm_part,
+                         const float* __restrict__ g_mhat, const float* __restrict__ t_onehot, float* lds);
+
+// The launch carries one extra block row (blockIdx.y == KS): its block 0 runs mechanism_net's forward, which depends only on t and
+// is hidden behind the weight stream.
+template <int MT>
+__global__ __launch_bounds__(256) void skinny_fwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ Wt, float* __restrict__ partial,
+                                                                 int M, int K, int N, int kslice, int KS, TailDims d, TailParams tp, TailSaved sv, MechFwdArgs ma) {
+    extern __shared__ float dyn_lds[];
+    if ((int)blockIdx.y == KS) {
+        if (blockIdx.x == 0) mech_fwd(d, tp, sv, ma.t_onehot, ma.running_mean, ma.running_var, ma.num_batches_tracked, ma.momentum, ma.bn_eps, ma.bn_training, dyn_lds);
+        return;
+    }
+    constexpr int R = 4;
+    const int n0 = blockIdx.x * R, ks = blockIdx.y;
+    const int k0 = ks * kslice, k1 = min(K, k0 + kslice);
+    float acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mm = 0; mm < MT; ++mm) acc[r][mm] = 0.f;
+    const float* wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = Wt + (size_t)min(n0 + r, N - 1) * K;
+#pragma unroll 4
+    for (int k = k0 + threadIdx.x; k < k1; k += 256) {
+        float xv[MT], wv[R];
+#pragma unroll
+        for (int mm = 0; mm < MT; ++mm) xv[mm] = mm < M ? x[(size_t)mm * K + k] : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[r] = wr[r][k];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int mm = 0; mm < MT; ++mm) acc[r][mm] += wv[r] * xv[mm];
+    }
+    __shared__ float red[4][R * MT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mm = 0; mm < MT; ++mm) {
+            const float sum = wave_sum(acc[r][mm]);
+            if (lane == 0) red[wave][r * MT + mm] = sum;
+        }
+    __syncthreads();
+    if (threadIdx.x < R * MT) {
+        const int r = threadIdx.x / MT, mm = threadIdx.x % MT;
+        if (mm < M && n0 + r < N)
+            partial[((size_t)ks * M + mm) * N + n0 + r] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ single-workgroup helpers
+// All take LDS operands laid out [M][dim] and are called by every thread of the (1024-thread) workgroup; the caller places
+// __syncthreads() between dependent stages.
+
+// ys[m][n] = act(sum_k xs[m][k] W[n][k] + b[n]); also stored to `yg` (global, row stride N) when non-null.  One wave per row.
+__device__ void wg_linear_fwd(const float* __restrict__ Wt, const float* __restrict__ bias, const float* xs, float* ys, float* __restrict__ yg,
+                              int M, int K, int N, int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int n = wave; n < N; n += nw) {
+        float acc[BN_MAXM];
+#pragma unroll
+        for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float w = Wt[(size_t)n * K + k];
+#pragma unroll
+            for (int m = 0; m < BN_MAXM; ++m)
+                if (m < M) acc[m] += w * xs[m * K + k];
+        }
+#pragma unroll
+        for (int m = 0; m < BN_MAXM; ++m) {
+            if (m >= M) break;
+            const float s = wave_sum(acc[m]);
+            if (lane == 0) {
+                const float v = apply_act(s + (bias ? bias[n] : 0.f), act);
+                ys[m * N + n] = v;
+                if (yg) yg[(size_t)m * N + n] = v;
+            }
+        }
+    }
+}
+
+// dW[n][k] = sum_m gs[m][n] xs[m][k];  db[n] = sum_m gs[m][n];  dxs[m][k] = sum_n gs[m][n] W[n][k]  (dxs may be null).
+__device__ void wg_linear_bwd(const float* __restrict__ Wt, float* __restrict__ dW, float* __restrict__ db, const float* gs, const float* xs, float* dxs,
+                              int M, int K, int N) {
+    const int T = blockDim.x;
+    for (int i = threadIdx.x; i < N * K; i += T) {
+        const int n = i / K, k = i - n * K;
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += gs[m * N + n] * xs[m * K + k];
+        dW[i] = acc;
+    }
+    if (db)
+        for (int n = threadIdx.x; n < N; n += T) {
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) acc += gs[m * N + n];
+            db[n] = acc;
+        }
+    if (dxs)
+        for (int i = threadIdx.x; i < M * K; i += T) {         // thread (m, k): consecutive threads walk k, so W rows are read coalesced
+            const int m = i / K, k = i - m * K;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int n = 0; n < N; ++n) acc += gs[m * N + n] * Wt[(size_t)n * K + k];
+            dxs[i] = acc;
+        }
+}
+
+
+// ------------------------------------------------------------------------------------------------ mechanism_net forward
+// One 256-thread workgroup (an extra block of the enc_fc.0 launch, which hides it): Linear(t) -> BatchNorm1d (batch statistics,
+// running-stat update) -> ReLU -> Linear -> ReLU -> Linear.  `lds` holds 4 * M * HM + M * T floats.
+__device__ void mech_fwd(const TailDims& d, const TailParams& p, const TailSaved& sv, const float* __restrict__ t_onehot, float* __restrict__ running_mean,
+                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked, float momentum, float bn_eps, int bn_training, float* lds) {
+    const int M = d.M, T = blockDim.x, tid = threadIdx.x, HM = d.HM;
+    float* ts = lds;                 // [M][T]
+    float* a1s = ts + M * d.T;       // [M][HM]
+    float* a2s = a1s + M * HM;       // [M][HM]
+    for (int i = tid; i < M * d.T; i += T) ts[i] = t_onehot[i];
+    __syncthreads();
+    for (int i = tid; i < M * HM; i += T) {                  // mechanism_net.0: thread (m, j)
+        const int m = i / HM, j = i - m * HM;
+        float acc = p.bm0[j];
+        for (int k = 0; k < d.T; ++k) acc += ts[m * d.T + k] * p.Wm0[j * d.T + k];
+        a1s[i] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < HM; j += T) {                      // BatchNorm1d + ReLU
+        float mean, var;
+        if (bn_training) {
+            mean = 0.f;
+            for (int m = 0; m < M; ++m) mean += a1s[m * HM + j];
+            mean /= (float)M;
+            var = 0.f;
+            for (int m = 0; m < M; ++m) { const float c = a1s[m * HM + j] - mean; var += c * c; }
+            var /= (float)M;
+            if (running_mean) {
+                running_mean[j] = (1.f - momentum) * running_mean[j] + momentum * mean;
+                running_var[j] = (1.f - momentum) * running_var[j] + momentum * var * ((float)M / (float)(M - 1));
+            }
+        } else {
+            mean = running_mean[j]; var = running_var[j];
+        }
+        const float is = 1.f / sqrtf(var + bn_eps);
+        sv.invstd[j] = is;
+        for (int m = 0; m < M; ++m) {
+            const float xh = (a1s[m * HM + j] - mean) * is;
+            sv.xhat[m * HM + j] = xh;
+            const float v = fmaxf(xh * p.gamma[j] + p.beta[j], 0.f);
+            a1s[m * HM + j] = v; sv.a1n[m * HM + j] = v;
+        }
+    }
+    if (tid == 0 && bn_training && num_batches_tracked) *num_batches_tracked += 1;
+    __syncthreads();
+    for (int i = tid; i < M * HM; i += T) {                  // mechanism_net.3 + ReLU
+        const int m = i / HM, j = i - m * HM;
+        float acc = p.bm3[j];
+#pragma unroll 8
+        for (int k = 0; k < HM; ++k) acc += a1s[m * HM + k] * p.Wm3[j * HM + k];
+        acc = fmaxf(acc, 0.f);
+        a2s[i] = acc; sv.a2[i] = acc;
+    }
+    __syncthreads();
+    const int K4 = d.Z + d.DM;
+    for (int i = tid; i < M * d.DM; i += T) {                // mechanism_net.5 -> m_hat, zm[:, Z:]
+        const int m = i / d.DM, j = i - m * d.DM;
+        float acc = p.bm5[j];
+#pragma unroll 8
+        for (int k = 0; k < HM; ++k) acc += a2s[m * HM + k] * p.Wm5[j * HM + k];
+        sv.m_hat[i] = acc;
+        sv.zm[m * K4 + d.Z + j] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fc2_fwd
+// h1 = relu(sum_ks partial + b1) (every workgroup rebuilds it in LDS from the L2-resident partials; block 0 also saves it),
+// then one wave per row of enc_fc.2: h2[m][n] = relu(W2[n] . h1[m] + b2[n]).  grid N2 / 4, 256 threads.
+__global__ __launch_bounds__(256) void fc2_fwd_kernel(TailDims d, TailParams p, TailSaved sv, const float* __restrict__ partial) {
+    extern __shared__ float lds[];
+    const int M = d.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* h1s = lds;                                        // [M][N1]
+    for (int i = tid; i < M * d.N1; i += 256) {
+        float acc = p.b1[i % d.N1];
+        for (int ks = 0; ks < d.KS; ++ks) acc += partial[(size_t)ks * M * d.N1 + i];
+        acc = fmaxf(acc, 0.f);
+        h1s[i] = acc;
+        if (blockIdx.x == 0) sv.h1[i] = acc;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= d.N2) return;
+    float acc[BN_MAXM];
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
+#pragma unroll 8
+    for (int k = lane; k < d.N1; k += 64) {
+        const float w = p.W2[(size_t)n * d.N1 + k];
+#pragma unroll
+        for (int m = 0; m < BN_MAXM; ++m)
+            if (m < M) acc[m] += w * h1s[m * d.N1 + k];
+    }
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m) {
+        if (m >= M) break;
+        const float sum = wave_sum(acc[m]);
+        if (lane == 0) sv.h2[m * d.N2 + n] = fmaxf(sum + p.b2[n], 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mulv_fwd
+// One wave per latent j: mu[:, j] = Wmu[j] . h2 + bmu[j], logvar likewise, z = mu + eps * exp(logvar / 2) -> zm[:, j].  grid Z / 4.
+__global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p, TailSaved sv, const float* __restrict__ eps) {
+    extern __shared__ float lds[];
+    const int M = d.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K4 = d.Z + d.DM;
+    float* h2s = lds;                                        // [M][N2]
+    for (int i = tid; i < M * d.N2; i += 256) h2s[i] = sv.h2[i];
+    __syncthreads();
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= d.Z) return;
+    float am[BN_MAXM], al[BN_MAXM];
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m) { am[m] = 0.f; al[m] = 0.f; }
+#pragma unroll 4
+    for (int k = lane; k < d.N2; k += 64) {
+        const float wm = p.Wmu[(size_t)j * d.N2 + k], wl = p.Wlv[(size_t)j * d.N2 + k];
+#pragma unroll
+        for (int m = 0; m < BN_MAXM; ++m)
+            if (m < M) { am[m] += wm * h2s[m * d.N2 + k]; al[m] += wl * h2s[m * d.N2 + k]; }
+    }
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m) {
+        if (m >= M) break;
+        const float smu = wave_sum(am[m]), slv = wave_sum(al[m]);
+        if (lane == 0) {
+            const float mu = smu + p.bmu[j], lv = slv + p.blv[j];
+            sv.mu[m * d.Z + j] = mu; sv.logvar[m * d.Z + j] = lv;
+            sv.zm[m * K4 + j] = mu + eps[m * d.Z + j] * __expf(0.5f * lv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dec_input_fwd
+// out[b][s][c] = sum_k zm[b][k] Wd[c * S + s][k] + bd[c * S + s].  grid (S, C / 64), 256 threads: the 64 weight rows of one
+// (cell, channel block) are staged in LDS with coalesced loads; thread (r, q) owns row r and a quarter of k.
+template <typename T>
+__global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restrict__ zm, const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                            T* __restrict__ out, int M, int K4, int S, int C) {
+    extern __shared__ float lds[];
+    const int KP = K4 | 1;                                   // odd row pitch: conflict-free column walks
+    float* ws = lds;                                         // [64][KP]
+    float* zs = ws + 64 * KP;                                // [M][K4]
+    float* part = zs + M * K4;                               // [4][M][64]
+    const int s = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int i = tid; i < 64 * K4; i += 256) {
+        const int r = i / K4, k = i - r * K4;
+        ws[r * KP + k] = Wd[((size_t)(c0 + r) * S + s) * K4 + k];
+    }
+    for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
+    __syncthreads();
+    const int r = tid & 63, q = tid >> 6;
+    const int kq = (K4 + 3) / 4, ka = q * kq, kb = min(K4, ka + kq);
+    float acc[BN_MAXM];
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
+    for (int k = ka; k < kb; ++k) {
+        const float w = ws[r * KP + k];
+#pragma unroll
+        for (int m = 0; m < BN_MAXM; ++m)
+            if (m < M) acc[m] += w * zs[m * K4 + k];
+    }
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m)
+        if (m < M) part[(q * M + m) * 64 + r] = acc[m];
+    __syncthreads();
+    for (int i = tid; i < M * 64; i += 256) {
+        const int m = i >> 6, rr = i & 63;
+        const float v = part[(0 * M + m) * 64 + rr] + part[(1 * M + m) * 64 + rr] + part[(2 * M + m) * 64 + rr] + part[(3 * M + m) * 64 + rr] +
+                        bd[(size_t)(c0 + rr) * S + s];
+        out[((size_t)m * S + s) * C + c0 + rr] = from_f32<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dec_input_bwd
+// g[b][n] = gcl[b][s][c] (n = c * S + s).  dWd[n][k] = sum_b g[b][n] zm[b][k]; dbd[n] = sum_b g[b][n];
+// dzm_part[s][b][k] = sum_c g[b][c * S + s] Wd[c * S + s][k].  grid S, 256 threads; the block walks the C / 64 channel blocks of its cell.
+template <typename T>
+__global__ __launch_bounds__(256) void dec_input_bwd_kernel(const T* __restrict__ gcl, const float* __restrict__ zm, const float* __restrict__ Wd,
+                                                            float* __restrict__ dWd, float* __restrict__ dbd, float* __restrict__ dzm_part,
+                                                            int M, int K4, int S, int C) {
+    extern __shared__ float lds[];
+    const int KP = K4 | 1;
+    float* ws = lds;                                         // [64][KP]
+    float* zs = ws + 64 * KP;                                // [M][K4]
+    float* gs = zs + M * K4;                                 // [M][64]
+    const int s = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
+    constexpr int EPT = (BN_MAXM * 128 + 255) / 256;         // d(zm) elements per thread (M * K4 <= 16 * 128)
+    float dz[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dz[e] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * K4; i += 256) {
+            const int r = i / K4, k = i - r * K4;
+            ws[r * KP + k] = Wd[((size_t)(c0 + r) * S + s) * K4 + k];
+        }
+        for (int i = tid; i < M * 64; i += 256) gs[i] = to_f32(gcl[((size_t)(i >> 6) * S + s) * C + c0 + (i & 63)]);
+        __syncthreads();
+        for (int i = tid; i < 64 * K4; i += 256) {
+            const int r = i / K4, k = i - r * K4;
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) acc += gs[m * 64 + r] * zs[m * K4 + k];
+            dWd[((size_t)(c0 + r) * S + s) * K4 + k] = acc;
+        }
+        if (tid < 64) {
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) acc += gs[m * 64 + tid];
+            dbd[(size_t)(c0 + tid) * S + s] = acc;
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * 256;
+            if (i < M * K4) {
+                const int m = i / K4, k = i - m * K4;
+                float acc = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < 64; ++r) acc += gs[m * 64 + r] * ws[r * KP + k];
+                dz[e] += acc;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * 256;
+        if (i < M * K4) dzm_part[(size_t)s * M * K4 + i] = dz[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ d(zm) from the partials
+// dzs[m][j] (LDS, [M][K4]) = sum over the P partial slabs written by dec_input_bwd.
+__device__ void sum_dzm(const float* __restrict__ dzm_part, float* dzs, int n, int P) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float acc = 0.f;
+#pragma unroll 16
+        for (int w = 0; w < P; ++w) acc += dzm_part[(size_t)w * n + i];
+        dzs[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mechanism_net backward
+// One 256-thread workgroup (an extra block of the enc_fc.0 backward launch, which hides it).  lds: M*K4 + 5*M*HM + M*T + M*DM.
+__device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads& gr, const TailSaved& sv, const float* __restrict__ dzm_part,
+                         const float* __restrict__ g_mhat, const float* __restrict__ t_onehot, float* lds) {
+    const int M = d.M, T = blockDim.x, tid = threadIdx.x, HM = d.HM, K4 = d.Z + d.DM;
+    float* dzs = lds;                    // [M][K4]
+    float* dmh = dzs + M * K4;           // [M][DM]
+    float* a2s = dmh + M * d.DM;         // [M][HM]
+    float* a1n = a2s + M * HM;           // [M][HM]
+    float* da2 = a1n + M * HM;           // [M][HM]
+    float* dy = da2 + M * HM;            // [M][HM]
+    float* xh = dy + M * HM;             // [M][HM]
+    float* ts = xh + M * HM;             // [M][T]
+    sum_dzm(dzm_part, dzs, M * K4, d.P);
+    for (int i = tid; i < M * HM; i += T) { a2s[i] = sv.a2[i]; a1n[i] = sv.a1n[i]; xh[i] = sv.xhat[i]; }
+    for (int i = tid; i < M * d.T; i += T) ts[i] = t_onehot[i];
+    __syncthreads();
+    for (int i = tid; i < M * d.DM; i += T) {
+        const int m = i / d.DM, j = i - m * d.DM;
+        dmh[i] = dzs[m * K4 + d.Z + j] + (g_mhat ? g_mhat[i] : 0.f);
+    }
+    __syncthreads();
+    wg_linear_bwd(p.Wm5, gr.dWm5, gr.dbm5, dmh, a2s, da2, M, HM, d.DM);
+    __syncthreads();
+    for (int i = tid; i < M * HM; i += T) da2[i] = a2s[i] > 0.f ? da2[i] : 0.f;
+    __syncthreads();
+    wg_linear_bwd(p.Wm3, gr.dWm3, gr.dbm3, da2, a1n, dy, M, HM, HM);
+    __syncthreads();
+    for (int j = tid; j < HM; j += T) {                      // ReLU mask, then BatchNorm1d backward (batch statistics)
+        float dgam = 0.f, dbet = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float g = a1n[m * HM + j] > 0.f ? dy[m * HM + j] : 0.f;
+            dy[m * HM + j] = g;
+            dgam += g * xh[m * HM + j];
+            dbet += g;
+        }
+        gr.dgamma[j] = dgam; gr.dbeta[j] = dbet;
+        const float k = p.gamma[j] * sv.invstd[j] / (float)M;
+        for (int m = 0; m < M; ++m) dy[m * HM + j] = k * ((float)M * dy[m * HM + j] - dbet - xh[m * HM + j] * dgam);
+    }
+    __syncthreads();
+    wg_linear_bwd(p.Wm0, gr.dWm0, gr.dbm0, dy, ts, nullptr, M, d.T, HM);
+}
+
+// ------------------------------------------------------------------------------------------------ mulv_bwd
+// fc_mu / fc_logvar backward.  grid N2 / 64: workgroup b owns columns k in [64 b, 64 b + 64) of both weights: dWmu[:, k], dWlv[:, k]
+// and dh2[:, k] = relu'(h2) (dmu . Wmu[:, k] + dlogvar . Wlv[:, k]); block 0 also writes the two bias gradients.
+// dmu = dz + g_mu, dlogvar = dz * eps * exp(logvar / 2) / 2 + g_logvar with dz = d(zm)[:, :Z] summed from the partials.
+__global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p, TailGrads gr, TailSaved sv, const float* __restrict__ dzm_part,
+                                                       const float* __restrict__ g_mu, const float* __restrict__ g_logvar, const float* __restrict__ eps,
+                                                       float* __restrict__ dh2) {
+    extern __shared__ float lds[];
+    const int M = d.M, tid = threadIdx.x, Z = d.Z, K4 = d.Z + d.DM;
+    float* dzs = lds;                    // [M][K4]
+    float* dmu = dzs + M * K4;           // [M][Z]
+    float* dlv = dmu + M * Z;            // [M][Z]
+    float* h2c = dlv + M * Z;            // [M][64]  this block's columns of h2
+    float* red = h2c + M * 64;           // [4][M][64]
+    sum_dzm(dzm_part, dzs, M * K4, d.P);
+    const int k0 = blockIdx.x * 64;
+    for (int i = tid; i < M * 64; i += 256) h2c[i] = (k0 + (i & 63) < d.N2) ? sv.h2[(i >> 6) * d.N2 + k0 + (i & 63)] : 0.f;
+    __syncthreads();
+    for (int i = tid; i < M * Z; i += 256) {
+        const int m = i / Z, j = i - m * Z;
+        const float dz = dzs[m * K4 + j];
+        dmu[i] = dz + (g_mu ? g_mu[i] : 0.f);
+        dlv[i] = dz * eps[i] * 0.5f * __expf(0.5f * sv.logvar[i]) + (g_logvar ? g_logvar[i] : 0.f);
+    }
+    __syncthreads();
+    const int kl = tid & 63, q = tid >> 6, k = k0 + kl;
+    float acc[BN_MAXM];
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
+    if (k < d.N2) {
+        for (int n = q; n < Z; n += 4) {                     // thread (k, q): rows n = q, q + 4, ..
+            const float wm = p.Wmu[(size_t)n * d.N2 + k], wl = p.Wlv[(size_t)n * d.N2 + k];
+            float gm = 0.f, gl = 0.f;
+#pragma unroll
+            for (int m = 0; m < BN_MAXM; ++m)
+                if (m < M) {
+                    acc[m] += dmu[m * Z + n] * wm + dlv[m * Z + n] * wl;
+                    gm += dmu[m * Z + n] * h2c[m * 64 + kl];
+                    gl += dlv[m * Z + n] * h2c[m * 64 + kl];
+                }
+            gr.dWmu[(size_t)n * d.N2 + k] = gm;
+            gr.dWlv[(size_t)n * d.N2 + k] = gl;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m)
+        if (m < M) red[(q * M + m) * 64 + kl] = acc[m];
+    __syncthreads();
+    for (int i = tid; i < M * 64; i += 256) {
+        const int m = i >> 6, c = i & 63;
+        if (k0 + c < d.N2) {
+            const float v = red[(0 * M + m) * 64 + c] + red[(1 * M + m) * 64 + c] + red[(2 * M + m) * 64 + c] + red[(3 * M + m) * 64 + c];
+            dh2[m * d.N2 + k0 + c] = h2c[i] > 0.f ? v : 0.f;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int n = tid; n < Z; n += 256) {
+            float bm = 0.f, bl = 0.f;
+            for (int m = 0; m < M; ++m) { bm += dmu[m * Z + n]; bl += dlv[m * Z + n]; }
+            gr.dbmu[n] = bm; gr.dblv[n] = bl;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ fc2_bwd
+// enc_fc.2 backward.  grid N1 / 32: workgroup b owns columns k in [32 b, 32 b + 32) of W2: dW2[:, k], g1[:, k] = relu'(h1) (dh2 . W2[:, k])
+// and db1[k] = sum_m g1[m][k]; block 0 also writes db2.  Thread (k, q) walks rows n = q, q + 8, .. (128-byte row segments).
+__global__ __launch_bounds__(256) void fc2_bwd_kernel(TailDims d, TailParams p, TailGrads gr, TailSaved sv, const float* __restrict__ dh2, float* __restrict__ g1) {
+    extern __shared__ float lds[];
+    const int M = d.M, tid = threadIdx.x, N = d.N2, K = d.N1;
+    float* dhs = lds;                    // [M][N2]
+    float* h1c = dhs + M * N;            // [M][32]
+    float* red = h1c + M * 32;           // [8][M][32]
+    const int k0 = blockIdx.x * 32;
+    for (int i = tid; i < M * N; i += 256) dhs[i] = dh2[i];
+    for (int i = tid; i < M * 32; i += 256) h1c[i] = (k0 + (i & 31) < K) ? sv.h1[(i >> 5) * K + k0 + (i & 31)] : 0.f;
+    __syncthreads();
+    const int kl = tid & 31, q = tid >> 5, k = k0 + kl;
+    float acc[BN_MAXM];
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
+    if (k < K) {
+#pragma unroll 4
+        for (int n = q; n < N; n += 8) {
+            const float w = p.W2[(size_t)n * K + k];
+            float dw = 0.f;
+#pragma unroll
+            for (int m = 0; m < BN_MAXM; ++m)
+                if (m < M) { acc[m] += dhs[m * N + n] * w; dw += dhs[m * N + n] * h1c[m * 32 + kl]; }
+            gr.dW2[(size_t)n * K + k] = dw;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < BN_MAXM; ++m)
+        if (m < M) red[(q * M + m) * 32 + kl] = acc[m];
+    __syncthreads();
+    if (tid < 32 && k0 + tid < K) {
+        float bsum = 0.f;
+        for (int m = 0; m < M; ++m) {
+            float v = 0.f;
+            for (int qq = 0; qq < 8; ++qq) v += red[(qq * M + m) * 32 + tid];
+            v = h1c[m * 32 + tid] > 0.f ? v : 0.f;
+            g1[m * K + k0 + tid] = v;
+            bsum += v;
+        }
+        gr.db1[k0 + tid] = bsum;
+    }
+    if (blockIdx.x == 0)
+        for (int n = tid; n < N; n += 256) {
+            float b = 0.f;
+            for (int m = 0; m < M; ++m) b += dhs[m * N + n];
+            gr.db2[n] = b;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ skinny_bwd_colwise
+// enc_fc.0 backward in one pass over W: thread owns column k; for its slice of rows n it writes dW[n][k] = sum_m g[m][n] x[m][k]
+// and accumulates dx[m][k] += g[m][n] W[n][k].  grid (ceil(K / 256), NS).  The partial dx of feature column f = c * S + s is
+// stored cell-major, dxp[ns][m][s][c], so pool_bwd reads it coalesced along c (columns >= F — m and t — need no gradient).
+template <int MT>
+__global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ Wt,
+                                                                 float* __restrict__ dW, float* __restrict__ dxp, int M, int K, int N, int nslice, int F, int S,
+                                                                 int NS, TailDims d, TailParams tp, TailGrads tg, TailSaved sv, MechBwdArgs mb) {
+    extern __shared__ float dyn_lds[];
+    if ((int)blockIdx.y == NS) {                             // extra block row: mechanism_net's backward, hidden behind the W stream
+        if (blockIdx.x == 0) mech_bwd(d, tp, tg, sv, mb.dzm_part, mb.g_mhat, mb.t_onehot, dyn_lds);
+        return;
+    }
+    __shared__ float gs[MT][64];
+    const int k = blockIdx.x * 256 + threadIdx.x, ns = blockIdx.y;
+    const int n0 = ns * nslice, n1 = min(N, n0 + nslice);
+    float xv[MT], acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { xv[m] = (m < M && k < K) ? x[(size_t)m * K + k] : 0.f; acc[m] = 0.f; }
+    for (int nb = n0; nb < n1; nb += 64) {
+        const int cnt = min(64, n1 - nb);
+        __syncthreads();
+        for (int i = threadIdx.x; i < MT * 64; i += 256) {
+            const int m = i >> 6, j = i & 63;
+            gs[m][j] = (m < M && j < cnt) ? g[(size_t)m * N + nb + j] : 0.f;
+        }
+        __syncthreads();
+        if (k < K) {
+#pragma unroll 8
+            for (int j = 0; j < cnt; ++j) {
+                const float w = Wt[(size_t)(nb + j) * K + k];
+                float dw = 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { dw += gs[m][j] * xv[m]; acc[m] += gs[m][j] * w; }
+                dW[(size_t)(nb + j) * K + k] = dw;
+            }
+        }
+    }
+    if (k < F) {
+        const int c = k / S, s = k - c * S, C = F / S;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (m < M) dxp[(((size_t)ns * M + m) * S + s) * C + c] = acc[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pool_bwd
+// grid (S, M): block (s, b) sums the NS partials of cell s for all channels and writes value / |window| to every voxel of the
+// window (windows must not overlap: D % OD == H % OH == W % OW == 0), zeroed where the pooled activation was not positive.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dxp, const T* __restrict__ y, T* __restrict__ dy, int NS, int M,
+                                                       int D, int H, int W, int C, int OD, int OH, int OW, int relu_mask) {
+    const int S = OD * OH * OW, b = blockIdx.y, s = blockIdx.x;
+    const int ow = s % OW, oh = (s / OW) % OH, od = s / (OW * OH);
+    const int d0 = pool_lo(od, D, OD), d1 = pool_hi(od, D, OD), h0 = pool_lo(oh, H, OH), h1 = pool_hi(oh, H, OH), w0 = pool_lo(ow, W, OW), w1 = pool_hi(ow, W, OW);
+    const float inv = 1.f / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int ns = 0; ns < NS; ++ns) acc += dxp[(((size_t)ns * M + b) * S + s) * C + c];
+        acc *= inv;
+        for (int dd = d0; dd < d1; ++dd)
+            for (int hh = h0; hh < h1; ++hh)
+                for (int ww = w0; ww < w1; ++ww) {
+                    const size_t idx = ((((size_t)b * D + dd) * H + hh) * W + ww) * C + c;
+                    dy[idx] = from_f32<T>((!relu_mask || to_f32(y[idx]) > 0.f) ? acc : 0.f);
+                }
+    }
+}
+
+size_t mech_fwd_lds(const TailDims& d) { return sizeof(float) * (size_t)d.M * (d.T + 2 * d.HM); }
+size_t mech_bwd_lds(const TailDims& d) { return sizeof(float) * (size_t)d.M * (d.Z + d.DM + d.DM + 5 * d.HM + d.T); }
+
+}  // namespace
+
+// Host-side description of the bottleneck (plain C struct of the C ABI, see include/cvae_hip.h).
+static bool dims_ok(const cvae_bottleneck_dims* q) {
+    if (!q) return false;
+    if (q->M < 1 || q->M > BN_MAXM) return false;
+    if (q->C < 64 || q->C % 64 || q->D < 1 || q->H < 1 || q->W < 1 || q->OD < 1 || q->OH < 1 || q->OW < 1) return false;
+    if (q->D % q->OD || q->H % q->OH || q->W % q->OW) return false;
+    if (q->m_dim < 1 || q->t_dim < 1 || q->N1 < 4 || q->N2 < 1 || q->Z < 1 || q->HM < 1 || q->HM > 1024) return false;
+    if (q->Z + q->m_dim > 128 || q->N1 > 4096 || q->N2 > 2048) return false;            // LDS / register budgets of the level kernels
+    return true;
+}
+static TailDims tail_dims(const cvae_bottleneck_dims* q, int KS, int P) {
+    return TailDims{(int)q->M, (int)q->N1, (int)q->N2, (int)q->Z, (int)q->t_dim, (int)q->HM, (int)q->m_dim, KS, P};
+}
+static int fwd_ksplit(int64_t K1) { int ks = (int)(K1 / 2048); return ks < 1 ? 1 : (ks > 16 ? 16 : ks); }
+static int bwd_nsplit(int64_t N1) { int ns = (int)(N1 / 32); return ns < 1 ? 1 : (ns > 16 ? 16 : ns); }
+
+extern "C" int cvae_bottleneck_sizes(const cvae_bottleneck_dims* q, int64_t* K1, int64_t* K4, int64_t* fwd_partial_floats, int64_t* dzm_partial_floats,
+                                     int64_t* dx_partial_floats) {
+    if (!dims_ok(q)) return CVAE_E_BADSHAPE;
+    const int64_t S = q->OD * q->OH * q->OW, F = q->C * S, k1 = F + q->m_dim + q->t_dim, k4 = q->Z + q->m_dim;
+    if (K1) *K1 = k1;
+    if (K4) *K4 = k4;
+    if (fwd_partial_floats) *fwd_partial_floats = (int64_t)fwd_ksplit(k1) * q->M * q->N1;
+    if (dzm_partial_floats) *dzm_partial_floats = S * q->M * k4;
+    if (dx_partial_floats) *dx_partial_floats = (int64_t)bwd_nsplit(q->N1) * q->M * F;
+    return CVAE_OK;
+}
+
+template <int MT>
+static void launch_fwd_partial(const float* x, const float* W1, float* partial, int M, int K, int N, int KS, const TailDims& d, const TailParams& p, const TailSaved& sv,
+                               const MechFwdArgs& ma, hipStream_t st) {
+    const int kslice = (K + KS - 1) / KS;
+    hipLaunchKernelGGL(skinny_fwd_partial_kernel<MT>, dim3((unsigned)((N + 3) / 4), (unsigned)(KS + 1)), dim3(256), mech_fwd_lds(d), st, x, W1, partial, M, K, N, kslice,
+                       KS, d, p, sv, ma);
+}
+template <int MT>
+static void launch_bwd_colwise(const float* g, const float* x, const float* W1, float* dW, float* dxp, int M, int K, int N, int NS, int F, int S, const TailDims& d,
+                               const TailParams& p, const TailGrads& tg, const TailSaved& sv, const MechBwdArgs& mb, hipStream_t st) {
+    const int nslice = (N + NS - 1) / NS;
+    hipLaunchKernelGGL(skinny_bwd_colwise_kernel<MT>, dim3((unsigned)((K + 255) / 256), (unsigned)(NS + 1)), dim3(256), mech_bwd_lds(d), st, g, x, W1, dW, dxp, M, K, N,
+                       nslice, F, S, NS, d, p, tg, sv, mb);
+}
+
+extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, const float* t_onehot,
+                                   const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
+                                   int bn_training, float* xcat, float* partial, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype, void* stream) {
+    if (!dims_ok(q)) return CVAE_E_BADSHAPE;
+    if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (!w || !sv || !y_cl || !m || !t_onehot || !eps || !xcat || !partial || !dec_cl) return CVAE_E_NULLPTR;
+    if (bn_training && q->M < 2) return CVAE_E_BADSHAPE;
+    if (!bn_training && (!running_mean || !running_var)) return CVAE_E_NULLPTR;
+    hipStream_t st = (hipStream_t)stream;
+    const int M = (int)q->M, S = (int)(q->OD * q->OH * q->OW), C = (int)q->C, F = C * S;
+    const int K1 = F + (int)q->m_dim + (int)q->t_dim, K4 = (int)(q->Z + q->m_dim), KS = fwd_ksplit(K1);
+    if (dtype == CVAE_BF16)
+        hipLaunchKernelGGL(pool_cat_fwd_kernel<bf16>, dim3(S + 1, M), dim3(256), 0, st, (const bf16*)y_cl, m, t_onehot, xcat, (int)q->D, (int)q->H, (int)q->W, C,
+                           (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1);
+    else
+        hipLaunchKernelGGL(pool_cat_fwd_kernel<float>, dim3(S + 1, M), dim3(256), 0, st, (const float*)y_cl, m, t_onehot, xcat, (int)q->D, (int)q->H, (int)q->W, C,
+                           (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1);
+    CVAE_CHECK_LAUNCH();
+    const TailDims d = tail_dims(q, KS, 0);
+    const TailParams p{w->b1, w->W2, w->b2, w->Wmu, w->bmu, w->Wlv, w->blv, w->Wm0, w->bm0, w->gamma, w->beta, w->Wm3, w->bm3, w->Wm5, w->bm5};
+    const TailSaved s{sv->h1, sv->h2, sv->mu, sv->logvar, sv->xhat, sv->invstd, sv->a1n, sv->a2, sv->m_hat, sv->zm};
+    const MechFwdArgs ma{t_onehot, running_mean, running_var, num_batches_tracked, momentum, bn_eps, bn_training};
+    if (M <= 4) launch_fwd_partial<4>(xcat, w->W1, partial, M, K1, (int)q->N1, KS, d, p, s, ma, st);
+    else if (M <= 8) launch_fwd_partial<8>(xcat, w->W1, partial, M, K1, (int)q->N1, KS, d, p, s, ma, st);
+    else launch_fwd_partial<16>(xcat, w->W1, partial, M, K1, (int)q->N1, KS, d, p, s, ma, st);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fc2_fwd_kernel, dim3((unsigned)((q->N2 + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N1, st, d, p, s, (const float*)partial);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mulv_fwd_kernel, dim3((unsigned)((q->Z + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N2, st, d, p, s, eps);
+    CVAE_CHECK_LAUNCH();
+    const size_t lds_d = sizeof(float) * ((size_t)64 * (K4 | 1) + (size_t)M * K4 + (size_t)4 * M * 64);
+    if (dtype == CVAE_BF16)
+        hipLaunchKernelGGL(dec_input_fwd_kernel<bf16>, dim3(S, C / 64), dim3(256), lds_d, st, (const float*)sv->zm, w->Wd, w->bd, (bf16*)dec_cl, M, K4, S, C);
+    else
+        hipLaunchKernelGGL(dec_input_fwd_kernel<float>, dim3(S, C / 64), dim3(256), lds_d, st, (const float*)sv->zm, w->Wd, w->bd, (float*)dec_cl, M, K4, S, C);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const cvae_bottleneck_grads* gr, const cvae_bottleneck_saved* sv,
+                                   const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat, const float* t_onehot, const float* eps,
+                                   const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1, float* dx_partial, void* dy_cl, int dtype,
+                                   void* stream) {
+    if (!dims_ok(q)) return CVAE_E_BADSHAPE;
+    if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (!w || !gr || !sv || !g_dec_cl || !t_onehot || !eps || !xcat || !y_cl || !dzm_partial || !g1 || !dx_partial || !dy_cl) return CVAE_E_NULLPTR;
+    hipStream_t st = (hipStream_t)stream;
+    const int M = (int)q->M, S = (int)(q->OD * q->OH * q->OW), C = (int)q->C, F = C * S;
+    const int K1 = F + (int)q->m_dim + (int)q->t_dim, K4 = (int)(q->Z + q->m_dim), NS = bwd_nsplit(q->N1), P = S;
+    const size_t lds_d = sizeof(float) * ((size_t)64 * (K4 | 1) + (size_t)M * K4 + (size_t)M * 64);
+    if (dtype == CVAE_BF16)
+        hipLaunchKernelGGL(dec_input_bwd_kernel<bf16>, dim3(S), dim3(256), lds_d, st, (const bf16*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
+                           dzm_partial, M, K4, S, C);
+    else
+        hipLaunchKernelGGL(dec_input_bwd_kernel<float>, dim3(S), dim3(256), lds_d, st, (const float*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
+                           dzm_partial, M, K4, S, C);
+    CVAE_CHECK_LAUNCH();
+    const TailDims d = tail_dims(q, 0, P);
+    const TailParams p{w->b1, w->W2, w->b2, w->Wmu, w->bmu, w->Wlv, w->blv, w->Wm0, w->bm0, w->gamma, w->beta, w->Wm3, w->bm3, w->Wm5, w->bm5};
+    const TailGrads g{gr->db1, gr->dW2, gr->db2, gr->dWmu, gr->dbmu, gr->dWlv, gr->dblv, gr->dWm0, gr->dbm0, gr->dgamma, gr->dbeta, gr->dWm3, gr->dbm3, gr->dWm5, gr->dbm5};
+    const TailSaved s{sv->h1, sv->h2, sv->mu, sv->logvar, sv->xhat, sv->invstd, sv->a1n, sv->a2, sv->m_hat, sv->zm};
+    float* dh2 = g1 + (size_t)M * q->N1;                     // second part of the g1 scratch
+    hipLaunchKernelGGL(mulv_bwd_kernel, dim3((unsigned)((q->N2 + 63) / 64)), dim3(256), sizeof(float) * ((size_t)M * K4 + 2 * (size_t)M * q->Z + 5 * (size_t)M * 64), st,
+                       d, p, g, s, (const float*)dzm_partial, g_mu, g_logvar, eps, dh2);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fc2_bwd_kernel, dim3((unsigned)((q->N1 + 31) / 32)), dim3(256), sizeof(float) * ((size_t)M * q->N2 + 9 * (size_t)M * 32), st, d, p, g, s,
+                       (const float*)dh2, g1);
+    CVAE_CHECK_LAUNCH();
+    const MechBwdArgs mb{dzm_partial, g_mhat, t_onehot};
+    if (M <= 4) launch_bwd_colwise<4>(g1, xcat, w->W1, gr->dW1, dx_partial, M, K1, (int)q->N1, NS, F, S, d, p, g, s, mb, st);
+    else if (M <= 8) launch_bwd_colwise<8>(g1, xcat, w->W1, gr->dW1, dx_partial, M, K1, (int)q->N1, NS, F, S, d, p, g, s, mb, st);
+    else launch_bwd_colwise<16>(g1, xcat, w->W1, gr->dW1, dx_partial, M, K1, (int)q->N1, NS, F, S, d, p, g, s, mb, st);
+    CVAE_CHECK_LAUNCH();
+    if (dtype == CVAE_BF16)
+        hipLaunchKernelGGL(pool_bwd_kernel<bf16>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const bf16*)y_cl, (bf16*)dy_cl, NS, M, (int)q->D, (int)q->H,
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask);
+    else
+        hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const float*)y_cl, (float*)dy_cl, NS, M, (int)q->D, (int)q->H,
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}

@@ -147,8 +147,11 @@ class DeconvStack(nn.Sequential):
     compute_dtype = torch.float32
 
     def forward_cl(self, h):
+        return self.forward_from_cl(ops.ToChannelsLast.apply(h, self.compute_dtype))
+
+    def forward_from_cl(self, x):
+        """The deconv chain on an input that is already channels-last in the compute dtype."""
         mods = list(self)
-        x = ops.ToChannelsLast.apply(h, self.compute_dtype)
         convs = [m for m in mods if isinstance(m, _ConvBase)]
         packed = iter(ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))   # one launch for the stack
         i, prev_act = 0, None

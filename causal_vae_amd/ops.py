@@ -5,6 +5,8 @@ in here: every Function.forward / backward enqueues HIP kernels on torch's curre
 activations are channels-last [B, D, H, W, C] (D = 1 for 2D) in the compute dtype (float32 or bfloat16); linear layers,
 losses, BN and sampling are fp32.
 """
+import ctypes as C_
+
 import torch
 
 from . import _lib as L
@@ -757,3 +759,72 @@ class UniformKL(torch.autograd.Function):
         dl = torch.empty_like(logits)
         check(lib.cvae_uniform_kl_bwd(ptr(logits), ptr(g), ptr(dl), logits.shape[0], logits.shape[1], stream()), "uniform_kl_bwd")
         return dl
+
+
+# ------------------------------------------------------------------------------------------------ fused bottleneck
+class BioBottleneck(torch.autograd.Function):
+    """Everything between CausalBioVAE's last encoder conv and first decoder conv as 5 + 5 launches (csrc/bottleneck.hip):
+    pool + flatten + cat, enc_fc, fc_mu / fc_logvar, reparameterize, mechanism_net (train-mode BatchNorm1d), cat, dec_input.
+
+    inputs : y_cl [B, D, H, W, C] (last encoder activation, a ReLU output), m [B, m_dim], t_onehot [B, t_dim], eps [B, Z],
+             the 18 parameters in _lib.BOTTLENECK_PARAMS order, then (running_mean, running_var, num_batches_tracked, momentum,
+             bn_eps, out_size).  returns (mu, logvar, m_hat, dec_cl [B, OD, OH, OW, C] in y_cl's dtype).
+    Same arithmetic (fp32) as the layer-by-layer path, which stays the general fallback (eval mode, B > 16, odd pool windows).
+    """
+
+    @staticmethod
+    def supported(y_cl, out_size, training):
+        B, D, H, W, C = y_cl.shape
+        OD, OH, OW = out_size
+        return training and 2 <= B <= 16 and C % 64 == 0 and D % OD == 0 and H % OH == 0 and W % OW == 0
+
+    @staticmethod
+    def forward(ctx, y_cl, m, t_onehot, eps, *rest):
+        params, (rm, rv, nbt, momentum, bn_eps, out_size) = rest[:18], rest[18:]
+        L.require_gpu(y_cl, m, t_onehot, eps, *params)
+        y_cl, m, t_onehot, eps = y_cl.contiguous(), m.contiguous().float(), t_onehot.contiguous().float(), eps.contiguous().float()
+        params = [p.contiguous() for p in params]
+        B, D, H, W, C = y_cl.shape
+        W1, W2, Wmu, Wm0 = params[0], params[2], params[4], params[8]
+        dims = L.BottleneckDims(B, D, H, W, C, *out_size, m.shape[1], t_onehot.shape[1], W1.shape[0], W2.shape[0], Wmu.shape[0], Wm0.shape[0])
+        sizes = [C_.c_int64() for _ in range(5)]
+        check(lib.cvae_bottleneck_sizes(C_.byref(dims), *[C_.byref(v) for v in sizes]), "bottleneck_sizes")
+        K1, K4, n_fwd, n_dzm, n_dx = (v.value for v in sizes)
+        if W1.shape[1] != K1 or params[16].shape != (C * out_size[0] * out_size[1] * out_size[2], K4):
+            raise L.CvaeError(f"BioBottleneck: enc_fc.0 expects {W1.shape[1]} inputs, the pooled features + m + t give {K1}")
+        dev, f32 = y_cl.device, torch.float32
+        new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
+        xcat, partial = new(B, K1), new(n_fwd)
+        N1, N2, Z, HM, DM = dims.N1, dims.N2, dims.Z, dims.HM, dims.m_dim
+        saved = dict(h1=new(B, N1), h2=new(B, N2), mu=new(B, Z), logvar=new(B, Z), xhat=new(B, HM), invstd=new(HM), a1n=new(B, HM), a2=new(B, HM),
+                     m_hat=new(B, DM), zm=new(B, K4))
+        dec_cl = torch.empty(B, *out_size, C, dtype=y_cl.dtype, device=dev)
+        pstruct = L.BottleneckPtrs18(*[ptr(p) for p in params])
+        sstruct = L.BottleneckSaved(*[ptr(saved[k]) for k in L.BOTTLENECK_SAVED])
+        check(lib.cvae_bottleneck_fwd(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
+                                      float(bn_eps), 1, ptr(xcat), ptr(partial), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), stream()), "bottleneck_fwd")
+        ctx.dims, ctx.scratch = dims, (n_dzm, n_dx)
+        ctx.save_for_backward(y_cl, t_onehot, eps, xcat, *params, *[saved[k] for k in L.BOTTLENECK_SAVED])
+        ctx.mark_non_differentiable(*[t for t in (rm, rv, nbt) if t is not None])
+        return saved["mu"], saved["logvar"], saved["m_hat"], dec_cl
+
+    @staticmethod
+    def backward(ctx, g_mu, g_logvar, g_mhat, g_dec):
+        y_cl, t_onehot, eps, xcat = ctx.saved_tensors[:4]
+        params, saved = ctx.saved_tensors[4:22], ctx.saved_tensors[22:]
+        dims, (n_dzm, n_dx) = ctx.dims, ctx.scratch
+        dev, f32 = y_cl.device, torch.float32
+        if g_dec is None:
+            g_dec = torch.zeros(dims.M, dims.OD, dims.OH, dims.OW, dims.C, dtype=y_cl.dtype, device=dev)
+        fix = lambda g: None if g is None else g.contiguous().float()
+        g_mu, g_logvar, g_mhat, g_dec = fix(g_mu), fix(g_logvar), fix(g_mhat), g_dec.contiguous()
+        grads = [torch.empty_like(p) for p in params]
+        dzm_part, g1, dx_part = (torch.empty(n, dtype=f32, device=dev) for n in (n_dzm, dims.M * (dims.N1 + dims.N2), n_dx))
+        dy_cl = torch.empty_like(y_cl)
+        pstruct = L.BottleneckPtrs18(*[ptr(p) for p in params])
+        gstruct = L.BottleneckPtrs18(*[ptr(g) for g in grads])
+        sstruct = L.BottleneckSaved(*[ptr(t) for t in saved])
+        check(lib.cvae_bottleneck_bwd(C_.byref(dims), C_.byref(pstruct), C_.byref(gstruct), C_.byref(sstruct), ptr(g_dec), ptr(g_mu), ptr(g_logvar), ptr(g_mhat),
+                                      ptr(t_onehot), ptr(eps), ptr(xcat), ptr(y_cl), 1, ptr(dzm_part), ptr(g1), ptr(dx_part), ptr(dy_cl),
+                                      L.dtype_code(y_cl.dtype), stream()), "bottleneck_bwd")
+        return (dy_cl, None, None, None, *grads, None, None, None, None, None, None)

@@ -97,6 +97,41 @@ int cvae_conv_up(const void* S, const void* w, const float* bias, const void* ma
                  int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                  int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* ---- The dense bottleneck of CausalBioVAE in 5 + 5 launches (batch M <= 16, fp32 arithmetic) --------------------------------
+ * Replaces, between the last encoder conv and the first decoder conv (causal_cascade/models.py:57-79):
+ *   AdaptiveAvgPool + Flatten, cat([x_feat, m, t]), enc_fc (Linear-ReLU-Linear-ReLU), fc_mu, fc_logvar, reparameterize,
+ *   mechanism_net (Linear, BatchNorm1d, ReLU, Linear, ReLU, Linear), cat([z, m_hat]), dec_input (+ the NC(D)HW -> channels-last
+ *   move into the decoder).  All pointers are device pointers; weights are the nn.Linear / BatchNorm1d tensors as they are.
+ * y_cl: last encoder activation [M][D][H][W][C] (conv dtype), pooled to OD x OH x OW windows (D % OD == 0 etc.).
+ * N1 / N2: widths of enc_fc.0 / enc_fc.2; Z: latent; HM: mechanism_net width; K1 = C*OD*OH*OW + m_dim + t_dim; K4 = Z + m_dim. */
+typedef struct { int64_t M, D, H, W, C, OD, OH, OW, m_dim, t_dim, N1, N2, Z, HM; } cvae_bottleneck_dims;
+typedef struct {                 /* parameters (fp32, torch layouts [out][in]) */
+    const float *W1, *b1, *W2, *b2, *Wmu, *bmu, *Wlv, *blv, *Wm0, *bm0, *gamma, *beta, *Wm3, *bm3, *Wm5, *bm5, *Wd, *bd;
+} cvae_bottleneck_params;
+typedef struct {                 /* their gradients (overwritten), same order and shapes */
+    float *dW1, *db1, *dW2, *db2, *dWmu, *dbmu, *dWlv, *dblv, *dWm0, *dbm0, *dgamma, *dbeta, *dWm3, *dbm3, *dWm5, *dbm5, *dWd, *dbd;
+} cvae_bottleneck_grads;
+typedef struct {                 /* activations kept for backward, all [M][dim] fp32: h1 [N1], h2 [N2], mu / logvar [Z],
+                                    xhat / a1n / a2 [HM], invstd [HM] (one row), m_hat [m_dim], zm [K4] = cat(z, m_hat) */
+    float *h1, *h2, *mu, *logvar, *xhat, *invstd, *a1n, *a2, *m_hat, *zm;
+} cvae_bottleneck_saved;
+/* Scratch sizes (in floats) for the given dims: xcat needs M*K1; the three partial buffers as returned. */
+int cvae_bottleneck_sizes(const cvae_bottleneck_dims* dims, int64_t* K1, int64_t* K4, int64_t* fwd_partial_floats, int64_t* dzm_partial_floats,
+                          int64_t* dx_partial_floats);
+/* Forward.  t_onehot [M][t_dim], eps [M][Z] (the reparameterisation noise).  bn_training: batch statistics + running-stat /
+ * num_batches_tracked update (running_* may be NULL), else running statistics.  Outputs: saved->mu / logvar / m_hat (the
+ * model's outputs) and dec_cl [M][OD][OH][OW][C] (conv dtype) = dec_input(cat(z, m_hat)) viewed [M, C, 4..] channels-last. */
+int cvae_bottleneck_fwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, const float* t_onehot,
+                        const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
+                        int bn_training, float* xcat, float* fwd_partial, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype, void* stream);
+/* Backward (training-mode BatchNorm only).  g_dec_cl: gradient of dec_cl; g_mu / g_logvar / g_mhat: gradients arriving at the
+ * three outputs (NULL = zero).  Writes every parameter gradient and dy_cl, the gradient of y_cl (zeroed where y_cl <= 0 when
+ * relu_mask).  g1 is scratch of M*(N1+N2) floats. */
+int cvae_bottleneck_bwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const cvae_bottleneck_grads* grads,
+                        const cvae_bottleneck_saved* saved, const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat,
+                        const float* t_onehot, const float* eps, const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1,
+                        float* dx_partial, void* dy_cl, int dtype, void* stream);
+
 /* dW fp32 [Cs][Cl][taps] (overwritten) = sum over batch and positions.  workspace: cvae_conv_wgrad_workspace_bytes().
  * dbias (optional, fp32 [Cs], overwritten) = sum over batch and positions of S: the bias gradient of a Conv layer, whose
  * S is the output gradient (fused into the weight-gradient pass where S is read anyway). */

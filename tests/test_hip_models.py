@@ -332,3 +332,40 @@ def test_gaussian_head_adversarial_step_matches_oracle():
         adam_close(v, sd_v[k], k)
     for k, v in disc.state_dict().items():
         adam_close(v, sd_d[k], k)
+
+
+@pytest.mark.parametrize("cls,shape,dtype", [("3d", (3, 1, 32, 32, 32), torch.float32), ("3d", (4, 1, 64, 64, 64), torch.bfloat16),
+                                             ("2d", (5, 1, 64, 96), torch.float32), ("3d", (16, 1, 32, 32, 32), torch.float32)])
+def test_fused_bottleneck_equals_layer_by_layer_path(cls, shape, dtype):
+    """ops.BioBottleneck (4 + 4 launches) against the same model run layer by layer: outputs, every gradient, BN buffers."""
+    Model = CausalBioVAE3D if cls == "3d" else CausalBioVAE
+    g = torch.Generator().manual_seed(11)
+    B = shape[0]
+    x, m = torch.randn(*shape, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (B,), generator=g).to(DEV)
+    eps = torch.randn(B, 64, generator=g).to(DEV)
+    runs = {}
+    for fused in (False, True):
+        torch.manual_seed(42)
+        model = Model().to(DEV).train().set_compute_dtype(dtype)
+        model.fuse_bottleneck = fused
+        recon, m_hat, mu, logvar = model(x, m, t, eps=eps)
+        loss = ((recon - x) ** 2).sum() + 3.0 * ((m_hat - m) ** 2).sum() - 0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
+        loss.backward()
+        bn = model.mechanism_net[1]
+        runs[fused] = dict(out=(recon, m_hat, mu, logvar), grads={k: p.grad.clone() for k, p in model.named_parameters()},
+                           bn=(bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    a, b = runs[False], runs[True]
+    tight = dtype == torch.float32
+    for u, v, name in zip(a["out"], b["out"], ("recon", "m_hat", "mu", "logvar")):
+        torch.testing.assert_close(v, u, rtol=1e-4 if tight else 2e-2, atol=1e-5 if tight else 2e-2, msg=lambda s: f"{name}: {s}")
+    assert a["bn"][2] == b["bn"][2] == 1
+    torch.testing.assert_close(b["bn"][0], a["bn"][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(b["bn"][1], a["bn"][1], rtol=1e-5, atol=1e-7)
+    for k in a["grads"]:
+        if k == NOISE_KEY:
+            continue
+        if tight:
+            grad_close(b["grads"][k], a["grads"][k].cpu(), k, l2=2e-4, linf=2e-3)
+        else:       # bf16 convs: a flipped bf16 rounding in dec_input's output / the pooled gradient moves conv gradients by ~1 bf16 ulp
+            grad_close(b["grads"][k], a["grads"][k].cpu(), k, l2=2e-2, linf=5e-2)
