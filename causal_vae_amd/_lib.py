@@ -83,7 +83,7 @@ SIGNATURES = {
     "cvae_scale": [_p, _i64, _p, _p],
     "cvae_clip_coef": [_p, _p, _f, _p],
     "cvae_bottleneck_sizes": [_p, _p, _p, _p, _p, _p],
-    "cvae_bottleneck_fwd": [_p] * 9 + [_f, _f, _i, _p, _p, _p, _p, _i, _p],
+    "cvae_bottleneck_fwd": [_p] * 9 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p],
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,

@@ -256,8 +256,12 @@ __global__ __launch_bounds__(256) void fc2_fwd_kernel(TailDims d, TailParams p, 
     const int M = d.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* h1s = lds;                                        // [M][N1]
     for (int i = tid; i < M * d.N1; i += 256) {
+        float v[8];                                          // KS <= 8: all slab loads of an element are issued together
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) v[ks] = ks < d.KS ? partial[(size_t)ks * M * d.N1 + i] : 0.f;
         float acc = p.b1[i % d.N1];
-        for (int ks = 0; ks < d.KS; ++ks) acc += partial[(size_t)ks * M * d.N1 + i];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc += v[ks];
         acc = fmaxf(acc, 0.f);
         h1s[i] = acc;
         if (blockIdx.x == 0) sv.h1[i] = acc;
@@ -285,9 +289,11 @@ __global__ __launch_bounds__(256) void fc2_fwd_kernel(TailDims d, TailParams p, 
 
 // ------------------------------------------------------------------------------------------------ mulv_fwd
 // One wave per latent j: mu[:, j] = Wmu[j] . h2 + bmu[j], logvar likewise, z = mu + eps * exp(logvar / 2) -> zm[:, j].  grid Z / 4.
-__global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p, TailSaved sv, const float* __restrict__ eps) {
+__global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p, TailSaved sv, const float* __restrict__ eps, float* __restrict__ dzm_acc) {
     extern __shared__ float lds[];
     const int M = d.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K4 = d.Z + d.DM;
+    if (blockIdx.x == 0 && dzm_acc)                          // the backward accumulates d(zm) here with atomics: leave it zeroed
+        for (int i = tid; i < M * K4; i += 256) dzm_acc[i] = 0.f;
     float* h2s = lds;                                        // [M][N2]
     for (int i = tid; i < M * d.N2; i += 256) h2s[i] = sv.h2[i];
     __syncthreads();
@@ -358,69 +364,48 @@ __global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------ dec_input_bwd
 // g[b][n] = gcl[b][s][c] (n = c * S + s).  dWd[n][k] = sum_b g[b][n] zm[b][k]; dbd[n] = sum_b g[b][n];
-// dzm_part[s][b][k] = sum_c g[b][c * S + s] Wd[c * S + s][k].  grid S, 256 threads; the block walks the C / 64 channel blocks of its cell.
+// dzm[b][k] += sum_{n in block} g[b][n] Wd[n][k]  (fp32 atomics onto the M x K4 accumulator, which the forward left zeroed and
+// pool_bwd zeroes again: a tree over the 256 blocks would cost an extra dependent launch).  grid (S, C / 64) as the forward.
 template <typename T>
 __global__ __launch_bounds__(256) void dec_input_bwd_kernel(const T* __restrict__ gcl, const float* __restrict__ zm, const float* __restrict__ Wd,
-                                                            float* __restrict__ dWd, float* __restrict__ dbd, float* __restrict__ dzm_part,
+                                                            float* __restrict__ dWd, float* __restrict__ dbd, float* __restrict__ dzm_acc,
                                                             int M, int K4, int S, int C) {
     extern __shared__ float lds[];
     const int KP = K4 | 1;
     float* ws = lds;                                         // [64][KP]
     float* zs = ws + 64 * KP;                                // [M][K4]
     float* gs = zs + M * K4;                                 // [M][64]
-    const int s = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
-    constexpr int EPT = (BN_MAXM * 128 + 255) / 256;         // d(zm) elements per thread (M * K4 <= 16 * 128)
-    float dz[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) dz[e] = 0.f;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        __syncthreads();
-        for (int i = tid; i < 64 * K4; i += 256) {
-            const int r = i / K4, k = i - r * K4;
-            ws[r * KP + k] = Wd[((size_t)(c0 + r) * S + s) * K4 + k];
-        }
-        for (int i = tid; i < M * 64; i += 256) gs[i] = to_f32(gcl[((size_t)(i >> 6) * S + s) * C + c0 + (i & 63)]);
-        __syncthreads();
-        for (int i = tid; i < 64 * K4; i += 256) {
-            const int r = i / K4, k = i - r * K4;
-            float acc = 0.f;
-            for (int m = 0; m < M; ++m) acc += gs[m * 64 + r] * zs[m * K4 + k];
-            dWd[((size_t)(c0 + r) * S + s) * K4 + k] = acc;
-        }
-        if (tid < 64) {
-            float acc = 0.f;
-            for (int m = 0; m < M; ++m) acc += gs[m * 64 + tid];
-            dbd[(size_t)(c0 + tid) * S + s] = acc;
-        }
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int i = tid + e * 256;
-            if (i < M * K4) {
-                const int m = i / K4, k = i - m * K4;
-                float acc = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < 64; ++r) acc += gs[m * 64 + r] * ws[r * KP + k];
-                dz[e] += acc;
-            }
-        }
+    const int s = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int i = tid; i < 64 * K4; i += 256) {
+        const int r = i / K4, k = i - r * K4;
+        ws[r * KP + k] = Wd[((size_t)(c0 + r) * S + s) * K4 + k];
     }
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * 256;
-        if (i < M * K4) dzm_part[(size_t)s * M * K4 + i] = dz[e];
+    for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
+    for (int i = tid; i < M * 64; i += 256) gs[i] = to_f32(gcl[((size_t)(i >> 6) * S + s) * C + c0 + (i & 63)]);
+    __syncthreads();
+    for (int i = tid; i < 64 * K4; i += 256) {
+        const int r = i / K4, k = i - r * K4;
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += gs[m * 64 + r] * zs[m * K4 + k];
+        dWd[((size_t)(c0 + r) * S + s) * K4 + k] = acc;
+    }
+    if (tid < 64) {
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += gs[m * 64 + tid];
+        dbd[(size_t)(c0 + tid) * S + s] = acc;
+    }
+    for (int i = tid; i < M * K4; i += 256) {
+        const int m = i / K4, k = i - m * K4;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) acc += gs[m * 64 + r] * ws[r * KP + k];
+        atomicAdd(&dzm_acc[i], acc);
     }
 }
 
-// ------------------------------------------------------------------------------------------------ d(zm) from the partials
-// dzs[m][j] (LDS, [M][K4]) = sum over the P partial slabs written by dec_input_bwd.
-__device__ void sum_dzm(const float* __restrict__ dzm_part, float* dzs, int n, int P) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float acc = 0.f;
-#pragma unroll 16
-        for (int w = 0; w < P; ++w) acc += dzm_part[(size_t)w * n + i];
-        dzs[i] = acc;
-    }
+// ------------------------------------------------------------------------------------------------ d(zm) -> LDS
+__device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dzs[i] = dzm_acc[i];
 }
 
 // ------------------------------------------------------------------------------------------------ mechanism_net backward
@@ -436,7 +421,7 @@ __device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads
     float* dy = da2 + M * HM;            // [M][HM]
     float* xh = dy + M * HM;             // [M][HM]
     float* ts = xh + M * HM;             // [M][T]
-    sum_dzm(dzm_part, dzs, M * K4, d.P);
+    load_dzm(dzm_part, dzs, M * K4);
     for (int i = tid; i < M * HM; i += T) { a2s[i] = sv.a2[i]; a1n[i] = sv.a1n[i]; xh[i] = sv.xhat[i]; }
     for (int i = tid; i < M * d.T; i += T) ts[i] = t_onehot[i];
     __syncthreads();
@@ -481,7 +466,7 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
     float* dlv = dmu + M * Z;            // [M][Z]
     float* h2c = dlv + M * Z;            // [M][64]  this block's columns of h2
     float* red = h2c + M * 64;           // [4][M][64]
-    sum_dzm(dzm_part, dzs, M * K4, d.P);
+    load_dzm(dzm_part, dzs, M * K4);
     const int k0 = blockIdx.x * 64;
     for (int i = tid; i < M * 64; i += 256) h2c[i] = (k0 + (i & 63) < d.N2) ? sv.h2[(i >> 6) * d.N2 + k0 + (i & 63)] : 0.f;
     __syncthreads();
@@ -531,43 +516,43 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
 }
 
 // ------------------------------------------------------------------------------------------------ fc2_bwd
-// enc_fc.2 backward.  grid N1 / 32: workgroup b owns columns k in [32 b, 32 b + 32) of W2: dW2[:, k], g1[:, k] = relu'(h1) (dh2 . W2[:, k])
-// and db1[k] = sum_m g1[m][k]; block 0 also writes db2.  Thread (k, q) walks rows n = q, q + 8, .. (128-byte row segments).
+// enc_fc.2 backward.  grid N1 / 16: workgroup b owns columns k in [16 b, 16 b + 16) of W2: dW2[:, k], g1[:, k] = relu'(h1) (dh2 . W2[:, k])
+// and db1[k] = sum_m g1[m][k]; block 0 also writes db2.  Thread (k, q) walks rows n = q, q + 16, .. (64-byte row segments).
 __global__ __launch_bounds__(256) void fc2_bwd_kernel(TailDims d, TailParams p, TailGrads gr, TailSaved sv, const float* __restrict__ dh2, float* __restrict__ g1) {
     extern __shared__ float lds[];
     const int M = d.M, tid = threadIdx.x, N = d.N2, K = d.N1;
     float* dhs = lds;                    // [M][N2]
-    float* h1c = dhs + M * N;            // [M][32]
-    float* red = h1c + M * 32;           // [8][M][32]
-    const int k0 = blockIdx.x * 32;
+    float* h1c = dhs + M * N;            // [M][16]
+    float* red = h1c + M * 16;           // [16][M][16]
+    const int k0 = blockIdx.x * 16;
     for (int i = tid; i < M * N; i += 256) dhs[i] = dh2[i];
-    for (int i = tid; i < M * 32; i += 256) h1c[i] = (k0 + (i & 31) < K) ? sv.h1[(i >> 5) * K + k0 + (i & 31)] : 0.f;
+    for (int i = tid; i < M * 16; i += 256) h1c[i] = (k0 + (i & 15) < K) ? sv.h1[(i >> 4) * K + k0 + (i & 15)] : 0.f;
     __syncthreads();
-    const int kl = tid & 31, q = tid >> 5, k = k0 + kl;
+    const int kl = tid & 15, q = tid >> 4, k = k0 + kl;
     float acc[BN_MAXM];
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
     if (k < K) {
-#pragma unroll 4
-        for (int n = q; n < N; n += 8) {
+#pragma unroll 8
+        for (int n = q; n < N; n += 16) {
             const float w = p.W2[(size_t)n * K + k];
             float dw = 0.f;
 #pragma unroll
             for (int m = 0; m < BN_MAXM; ++m)
-                if (m < M) { acc[m] += dhs[m * N + n] * w; dw += dhs[m * N + n] * h1c[m * 32 + kl]; }
+                if (m < M) { acc[m] += dhs[m * N + n] * w; dw += dhs[m * N + n] * h1c[m * 16 + kl]; }
             gr.dW2[(size_t)n * K + k] = dw;
         }
     }
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m)
-        if (m < M) red[(q * M + m) * 32 + kl] = acc[m];
+        if (m < M) red[(q * M + m) * 16 + kl] = acc[m];
     __syncthreads();
-    if (tid < 32 && k0 + tid < K) {
+    if (tid < 16 && k0 + tid < K) {
         float bsum = 0.f;
         for (int m = 0; m < M; ++m) {
             float v = 0.f;
-            for (int qq = 0; qq < 8; ++qq) v += red[(qq * M + m) * 32 + tid];
-            v = h1c[m * 32 + tid] > 0.f ? v : 0.f;
+            for (int qq = 0; qq < 16; ++qq) v += red[(qq * M + m) * 16 + tid];
+            v = h1c[m * 16 + tid] > 0.f ? v : 0.f;
             g1[m * K + k0 + tid] = v;
             bsum += v;
         }
@@ -609,7 +594,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
         }
         __syncthreads();
         if (k < K) {
-#pragma unroll 8
+#pragma unroll 16
             for (int j = 0; j < cnt; ++j) {
                 const float w = Wt[(size_t)(nb + j) * K + k];
                 float dw = 0.f;
@@ -632,8 +617,10 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
 // window (windows must not overlap: D % OD == H % OH == W % OW == 0), zeroed where the pooled activation was not positive.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dxp, const T* __restrict__ y, T* __restrict__ dy, int NS, int M,
-                                                       int D, int H, int W, int C, int OD, int OH, int OW, int relu_mask) {
+                                                       int D, int H, int W, int C, int OD, int OH, int OW, int relu_mask, float* __restrict__ dzm_acc, int n_dzm) {
     const int S = OD * OH * OW, b = blockIdx.y, s = blockIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0)                  // last launch of the backward: re-arm the d(zm) accumulator (all its readers are done)
+        for (int i = threadIdx.x; i < n_dzm; i += 256) dzm_acc[i] = 0.f;
     const int ow = s % OW, oh = (s / OW) % OH, od = s / (OW * OH);
     const int d0 = pool_lo(od, D, OD), d1 = pool_hi(od, D, OD), h0 = pool_lo(oh, H, OH), h1 = pool_hi(oh, H, OH), w0 = pool_lo(ow, W, OW), w1 = pool_hi(ow, W, OW);
     const float inv = 1.f / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
@@ -668,8 +655,8 @@ static bool dims_ok(const cvae_bottleneck_dims* q) {
 static TailDims tail_dims(const cvae_bottleneck_dims* q, int KS, int P) {
     return TailDims{(int)q->M, (int)q->N1, (int)q->N2, (int)q->Z, (int)q->t_dim, (int)q->HM, (int)q->m_dim, KS, P};
 }
-static int fwd_ksplit(int64_t K1) { int ks = (int)(K1 / 2048); return ks < 1 ? 1 : (ks > 16 ? 16 : ks); }
-static int bwd_nsplit(int64_t N1) { int ns = (int)(N1 / 32); return ns < 1 ? 1 : (ns > 16 ? 16 : ns); }
+static int fwd_ksplit(int64_t K1) { int ks = (int)(K1 / 4096); return ks < 1 ? 1 : (ks > 8 ? 8 : ks); }
+static int bwd_nsplit(int64_t N1) { int ns = (int)(N1 / 16); return ns < 1 ? 1 : (ns > 32 ? 32 : ns); }
 
 extern "C" int cvae_bottleneck_sizes(const cvae_bottleneck_dims* q, int64_t* K1, int64_t* K4, int64_t* fwd_partial_floats, int64_t* dzm_partial_floats,
                                      int64_t* dx_partial_floats) {
@@ -678,7 +665,7 @@ extern "C" int cvae_bottleneck_sizes(const cvae_bottleneck_dims* q, int64_t* K1,
     if (K1) *K1 = k1;
     if (K4) *K4 = k4;
     if (fwd_partial_floats) *fwd_partial_floats = (int64_t)fwd_ksplit(k1) * q->M * q->N1;
-    if (dzm_partial_floats) *dzm_partial_floats = S * q->M * k4;
+    if (dzm_partial_floats) *dzm_partial_floats = q->M * k4;
     if (dx_partial_floats) *dx_partial_floats = (int64_t)bwd_nsplit(q->N1) * q->M * F;
     return CVAE_OK;
 }
@@ -700,7 +687,8 @@ static void launch_bwd_colwise(const float* g, const float* x, const float* W1, 
 
 extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, const float* t_onehot,
                                    const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
-                                   int bn_training, float* xcat, float* partial, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype, void* stream) {
+                                   int bn_training, float* xcat, float* partial, float* dzm_acc, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype,
+                                   void* stream) {
     if (!dims_ok(q)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (!w || !sv || !y_cl || !m || !t_onehot || !eps || !xcat || !partial || !dec_cl) return CVAE_E_NULLPTR;
@@ -726,7 +714,7 @@ extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bot
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(fc2_fwd_kernel, dim3((unsigned)((q->N2 + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N1, st, d, p, s, (const float*)partial);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mulv_fwd_kernel, dim3((unsigned)((q->Z + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N2, st, d, p, s, eps);
+    hipLaunchKernelGGL(mulv_fwd_kernel, dim3((unsigned)((q->Z + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N2, st, d, p, s, eps, dzm_acc);
     CVAE_CHECK_LAUNCH();
     const size_t lds_d = sizeof(float) * ((size_t)64 * (K4 | 1) + (size_t)M * K4 + (size_t)4 * M * 64);
     if (dtype == CVAE_BF16)
@@ -749,10 +737,10 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     const int K1 = F + (int)q->m_dim + (int)q->t_dim, K4 = (int)(q->Z + q->m_dim), NS = bwd_nsplit(q->N1), P = S;
     const size_t lds_d = sizeof(float) * ((size_t)64 * (K4 | 1) + (size_t)M * K4 + (size_t)M * 64);
     if (dtype == CVAE_BF16)
-        hipLaunchKernelGGL(dec_input_bwd_kernel<bf16>, dim3(S), dim3(256), lds_d, st, (const bf16*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
+        hipLaunchKernelGGL(dec_input_bwd_kernel<bf16>, dim3(S, C / 64), dim3(256), lds_d, st, (const bf16*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
                            dzm_partial, M, K4, S, C);
     else
-        hipLaunchKernelGGL(dec_input_bwd_kernel<float>, dim3(S), dim3(256), lds_d, st, (const float*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
+        hipLaunchKernelGGL(dec_input_bwd_kernel<float>, dim3(S, C / 64), dim3(256), lds_d, st, (const float*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
                            dzm_partial, M, K4, S, C);
     CVAE_CHECK_LAUNCH();
     const TailDims d = tail_dims(q, 0, P);
@@ -763,7 +751,7 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     hipLaunchKernelGGL(mulv_bwd_kernel, dim3((unsigned)((q->N2 + 63) / 64)), dim3(256), sizeof(float) * ((size_t)M * K4 + 2 * (size_t)M * q->Z + 5 * (size_t)M * 64), st,
                        d, p, g, s, (const float*)dzm_partial, g_mu, g_logvar, eps, dh2);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fc2_bwd_kernel, dim3((unsigned)((q->N1 + 31) / 32)), dim3(256), sizeof(float) * ((size_t)M * q->N2 + 9 * (size_t)M * 32), st, d, p, g, s,
+    hipLaunchKernelGGL(fc2_bwd_kernel, dim3((unsigned)((q->N1 + 15) / 16)), dim3(256), sizeof(float) * ((size_t)M * q->N2 + 17 * (size_t)M * 16), st, d, p, g, s,
                        (const float*)dh2, g1);
     CVAE_CHECK_LAUNCH();
     const MechBwdArgs mb{dzm_partial, g_mhat, t_onehot};
@@ -773,10 +761,10 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     CVAE_CHECK_LAUNCH();
     if (dtype == CVAE_BF16)
         hipLaunchKernelGGL(pool_bwd_kernel<bf16>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const bf16*)y_cl, (bf16*)dy_cl, NS, M, (int)q->D, (int)q->H,
-                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask);
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, M * K4);
     else
         hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const float*)y_cl, (float*)dy_cl, NS, M, (int)q->D, (int)q->H,
-                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask);
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, M * K4);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

@@ -794,7 +794,7 @@ class BioBottleneck(torch.autograd.Function):
             raise L.CvaeError(f"BioBottleneck: enc_fc.0 expects {W1.shape[1]} inputs, the pooled features + m + t give {K1}")
         dev, f32 = y_cl.device, torch.float32
         new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
-        xcat, partial = new(B, K1), new(n_fwd)
+        xcat, partial, dzm_acc = new(B, K1), new(n_fwd), new(n_dzm)
         N1, N2, Z, HM, DM = dims.N1, dims.N2, dims.Z, dims.HM, dims.m_dim
         saved = dict(h1=new(B, N1), h2=new(B, N2), mu=new(B, Z), logvar=new(B, Z), xhat=new(B, HM), invstd=new(HM), a1n=new(B, HM), a2=new(B, HM),
                      m_hat=new(B, DM), zm=new(B, K4))
@@ -802,24 +802,24 @@ class BioBottleneck(torch.autograd.Function):
         pstruct = L.BottleneckPtrs18(*[ptr(p) for p in params])
         sstruct = L.BottleneckSaved(*[ptr(saved[k]) for k in L.BOTTLENECK_SAVED])
         check(lib.cvae_bottleneck_fwd(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
-                                      float(bn_eps), 1, ptr(xcat), ptr(partial), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), stream()), "bottleneck_fwd")
-        ctx.dims, ctx.scratch = dims, (n_dzm, n_dx)
-        ctx.save_for_backward(y_cl, t_onehot, eps, xcat, *params, *[saved[k] for k in L.BOTTLENECK_SAVED])
+                                      float(bn_eps), 1, ptr(xcat), ptr(partial), ptr(dzm_acc), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), stream()), "bottleneck_fwd")
+        ctx.dims, ctx.scratch = dims, n_dx
+        ctx.save_for_backward(y_cl, t_onehot, eps, xcat, *params, *[saved[k] for k in L.BOTTLENECK_SAVED], dzm_acc)
         ctx.mark_non_differentiable(*[t for t in (rm, rv, nbt) if t is not None])
         return saved["mu"], saved["logvar"], saved["m_hat"], dec_cl
 
     @staticmethod
     def backward(ctx, g_mu, g_logvar, g_mhat, g_dec):
         y_cl, t_onehot, eps, xcat = ctx.saved_tensors[:4]
-        params, saved = ctx.saved_tensors[4:22], ctx.saved_tensors[22:]
-        dims, (n_dzm, n_dx) = ctx.dims, ctx.scratch
+        params, saved, dzm_part = ctx.saved_tensors[4:22], ctx.saved_tensors[22:-1], ctx.saved_tensors[-1]
+        dims, n_dx = ctx.dims, ctx.scratch
         dev, f32 = y_cl.device, torch.float32
         if g_dec is None:
             g_dec = torch.zeros(dims.M, dims.OD, dims.OH, dims.OW, dims.C, dtype=y_cl.dtype, device=dev)
         fix = lambda g: None if g is None else g.contiguous().float()
         g_mu, g_logvar, g_mhat, g_dec = fix(g_mu), fix(g_logvar), fix(g_mhat), g_dec.contiguous()
         grads = [torch.empty_like(p) for p in params]
-        dzm_part, g1, dx_part = (torch.empty(n, dtype=f32, device=dev) for n in (n_dzm, dims.M * (dims.N1 + dims.N2), n_dx))
+        g1, dx_part = (torch.empty(n, dtype=f32, device=dev) for n in (dims.M * (dims.N1 + dims.N2), n_dx))
         dy_cl = torch.empty_like(y_cl)
         pstruct = L.BottleneckPtrs18(*[ptr(p) for p in params])
         gstruct = L.BottleneckPtrs18(*[ptr(g) for g in grads])

@@ -120,13 +120,15 @@ int cvae_bottleneck_sizes(const cvae_bottleneck_dims* dims, int64_t* K1, int64_t
                           int64_t* dx_partial_floats);
 /* Forward.  t_onehot [M][t_dim], eps [M][Z] (the reparameterisation noise).  bn_training: batch statistics + running-stat /
  * num_batches_tracked update (running_* may be NULL), else running statistics.  Outputs: saved->mu / logvar / m_hat (the
- * model's outputs) and dec_cl [M][OD][OH][OW][C] (conv dtype) = dec_input(cat(z, m_hat)) viewed [M, C, 4..] channels-last. */
+ * model's outputs) and dec_cl [M][OD][OH][OW][C] (conv dtype) = dec_input(cat(z, m_hat)) viewed [M, C, 4..] channels-last.
+ * dzm_acc: the M*K4 accumulator the backward adds d(zm) into; the forward zeroes it (keep it until the backward has run). */
 int cvae_bottleneck_fwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, const float* t_onehot,
                         const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
-                        int bn_training, float* xcat, float* fwd_partial, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype, void* stream);
+                        int bn_training, float* xcat, float* fwd_partial, float* dzm_acc, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype,
+                        void* stream);
 /* Backward (training-mode BatchNorm only).  g_dec_cl: gradient of dec_cl; g_mu / g_logvar / g_mhat: gradients arriving at the
  * three outputs (NULL = zero).  Writes every parameter gradient and dy_cl, the gradient of y_cl (zeroed where y_cl <= 0 when
- * relu_mask).  g1 is scratch of M*(N1+N2) floats. */
+ * relu_mask).  g1 is scratch of M*(N1+N2) floats; dzm_partial is the forward's dzm_acc (zero on entry, zero again on exit). */
 int cvae_bottleneck_bwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const cvae_bottleneck_grads* grads,
                         const cvae_bottleneck_saved* saved, const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat,
                         const float* t_onehot, const float* eps, const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1,

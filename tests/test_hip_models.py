@@ -259,9 +259,14 @@ def test_graphed_step_matches_eager_steps():
     for a, b in zip(eager[3:], graphed):
         assert rel(b, a) < 2e-4, (eager, graphed)
     assert len(set(graphed)) == 3                                   # the replays really advance (weights + eps change)
+    # A few reductions use fp32 atomics (bias sums, d(zm) in csrc/bottleneck.hip), so two runs of the SAME eager loop already differ in
+    # the last bit of some gradients, and Adam's first steps (update = lr * g / |g|) amplify that where g ~ 0: two eager runs differ by
+    # up to ~6e-4 in isolated weights after 6 steps at lr = 1e-4 (tools measurement).  Bound: 2 * lr per step, and a small mean drift.
     for (k, p), q in zip(m_e.named_parameters(), m_g.parameters()):
         if k != NOISE_KEY:
-            assert float((p - q).abs().max()) < 5e-4, k
+            dlt = (p.detach() - q.detach()).abs()
+            assert float(dlt.max()) <= 2 * 1e-4 * 6 + 1e-6, k
+            assert float(dlt.mean()) <= 5e-5, k
 
 
 def test_gaussian_head_variant_matches_reference_golden(golden):
