@@ -536,7 +536,8 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackTable tb) {
 // the 32-row half sg = w >> 2 of the cs block: 4 accumulator tiles (64 VGPRs), so two workgroups (16 waves) fit a CU with the
 // next tile's global loads held in registers during the MFMA phase.
 template <typename T, int ND>
-__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split) {
+__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split,
+                                                                                          float* __restrict__ bias_ws, int bias_mode) {
     using TL = Tile<ND, 128>;
     constexpr int NT = 512;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
@@ -577,6 +578,13 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
+    // Bias gradients ride along (no separate channel-sum pass over the gradient tensor): bias_mode 1 = per-channel sum of S (Conv
+    // layers), done by the (cl block 0, kd 0) workgroups from their S tiles; bias_mode 2 = per-channel sum of L (ConvTranspose
+    // layers), done by the (cs block 0, kd 1 | 2) workgroups from the non-halo part of their L tiles (kd = 1 sees the even planes,
+    // kd = 2 the odd ones; in 2D the single tap group sees the one plane).  Partials go to bias_ws, wgrad_reduce_kernel sums them.
+    const bool bias_s = bias_mode == 1 && (blockIdx.y % cl_blocks) == 0 && kd == 0;
+    const bool bias_l = bias_mode == 2 && (blockIdx.y / cl_blocks) == 0 && (ND == 2 || kd == 1 || kd == 2);
+    float bacc = 0.f;
     // S tile: 128 positions x 64 channels; L tile: planes lz = 2 (o0d + d) - 1 + kd, rows 2 o0h - 1 + y, cols 2 o0w - 1 + x.
     // Both LDS images are piece-linear (piece `it` at byte 16 it / 32 it).  The global loads of tile i+1 are issued right after
     // tile i has been stored to LDS, so they are in flight during tile i's MFMA phase; out-of-range pieces are loaded from a
@@ -644,6 +652,19 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
         if (stamp_it < 8) STAMP(3 + 3 * stamp_it);
 #endif
         if (tile + n_split < total_tiles) load_tile(tile + n_split);
+        if (bias_s) {                                        // thread (c, pg): 16 of the tile's 128 positions of channel c
+            const int c = t & 63, pg = t >> 6;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) bacc += to_f32(*(const T*)(s_lds + s_byte(pg * 16 + j, c)));
+        } else if (bias_l) {                                 // thread (c, pg): 32 of the 512 owned (non-halo) positions of channel c
+            const int c = t & 31, pg = t >> 5;
+#pragma unroll 4
+            for (int j = 0; j < 32; ++j) {
+                const int pp = pg + 16 * j;
+                const int xx = pp % (2 * TW), yy = pp / (2 * TW) % (2 * TH), dd = pp / (4 * TW * TH);
+                bacc += to_f32(*(const T*)(l_lds + l_row(dd * IH + yy + 1, xx + 1) * LROW + c * (int)sizeof(T)));
+            }
+        }
         if constexpr (sizeof(T) == 2) {
             // bf16: transposing LDS reads.  Lane i of 16-lane group gq supplies the address of k-row q = i>>2,
             // 4 channels at 4*(i&3); it receives channel i of the 4 k-rows  (cdna_hip_programming.md T10).
@@ -706,6 +727,25 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     STAMP(26);
     // ---- write-out: this workgroup's partial sums leave as ONE slab [kh][kw][64 cs][32 cl] of plain 128-byte-row stores;
     // wgrad_reduce_kernel sums the slabs (fp32 atomics here cost more than the MFMA phase: 67 MB of adds at < 1 TB/s) ----
+    if (bias_s || bias_l) {                                   // block-uniform
+        __syncthreads();                                     // the last tile's readers are done with the S image: reuse it as scratch
+        float* red = (float*)s_lds;
+        red[t] = bacc;
+        __syncthreads();
+        if (bias_s && t < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += red[q * 64 + t];
+            bias_ws[((size_t)(blockIdx.y / cl_blocks) * n_split + blockIdx.x) * 64 + t] = v;
+        }
+        if (bias_l && t < 32) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += red[q * 32 + t];
+            const int half = (ND == 3) ? kd - 1 : 0, nhalf = (ND == 3) ? 2 : 1;
+            bias_ws[(((size_t)(blockIdx.y % cl_blocks) * nhalf + half) * n_split + blockIdx.x) * 32 + t] = v;
+        }
+    }
     if (!ws) return;                                          // tuning only: measure the accumulate phase alone
     const int col = lane & 31, hq = lane >> 5;
     float* slab = ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * n_split + blockIdx.x) * 32768;
@@ -725,8 +765,25 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
 
 // dW[cs][cl][kd][kh][0..3] = sum over the n_split slabs of group (kd, channel block).  One thread per (kd, kh, cs, cl)
 // sums the 4 kw values (a 16-byte store into the reference layout); 4 thread groups split the slab range, LDS combines.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Cs, int Cl, int taps, int n_split, int cb) {
+// Blocks past the dW range sum the bias partials: block j handles 64 channels, 4 thread groups split the partial rows.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Cs, int Cl, int taps, int n_split, int cb,
+                                                           int dw_blocks, const float* __restrict__ bias_ws, float* __restrict__ dbias, int bias_n, int bias_rows,
+                                                           int bias_width) {
     __shared__ float4 part[4][64];
+    if ((int)blockIdx.x >= dw_blocks) {
+        // bias_ws is [channel group][bias_rows][bias_width]; channel = group * bias_width + lane
+        __shared__ float bred[4][64];
+        const int ch = ((int)blockIdx.x - dw_blocks) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+        float v = 0.f;
+        if (ch < bias_n) {
+            const float* base = bias_ws + (size_t)(ch / bias_width) * bias_rows * bias_width + (ch % bias_width);
+            for (int r = q; r < bias_rows; r += 4) v += base[(size_t)r * bias_width];
+        }
+        bred[q][threadIdx.x & 63] = v;
+        __syncthreads();
+        if (q == 0 && ch < bias_n) dbias[ch] = bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x];
+        return;
+    }
     const int cl_blocks = Cl / 32;
     // blockIdx.x enumerates (group = kd * cb + block, kh, cs row pair) ; 64 threads = 2 cs rows x 32 cl
     int bi = blockIdx.x;
@@ -754,7 +811,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 #define WGRAD_MAX_WG 512
 template <typename T, int ND>
-int launch_wgrad(const void* S, const void* L, float* ws, float* dW, ConvGeom g, hipStream_t stream) {
+int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbias, int bias_mode, ConvGeom g, hipStream_t stream) {
     using TL = Tile<ND, 128>;
     constexpr size_t LDS = (size_t)128 * 64 * sizeof(T) + (size_t)TL::TD * (2 * TL::TH + 2) * (2 * TL::TW + 2) * 32 * sizeof(T);
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
@@ -775,10 +832,19 @@ int launch_wgrad(const void* S, const void* L, float* ws, float* dW, ConvGeom g,
     if (n_split > total_tiles) n_split = total_tiles;
     if (cb > 65535) return CVAE_E_BADSHAPE;
     dim3 grid((unsigned)n_split, (unsigned)cb, (unsigned)tg);
-    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, (const T*)S, (const T*)L, getenv("CVAE_TUNE_WGRAD_NOREDUCE") ? nullptr : ws, g, (int)n_split);
+    // bias partials live behind the slabs: [channel group][rows][width] with (mode 1) 64-wide groups of cs, n_split rows;
+    // (mode 2) 32-wide groups of cl, (2 plane parities in 3D) * n_split rows
+    const long long wgs = (long long)cb * tg * n_split;
+    float* bias_ws = ws + (size_t)(wgs > WGRAD_MAX_WG ? wgs : WGRAD_MAX_WG) * 32768;
+    if (!dbias) bias_mode = 0;
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, (const T*)S, (const T*)L, getenv("CVAE_TUNE_WGRAD_NOREDUCE") ? nullptr : ws, g, (int)n_split, bias_ws, bias_mode);
     CVAE_CHECK_LAUNCH();
     if (getenv("CVAE_TUNE_WGRAD_NOREDUCE")) return CVAE_OK;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cb * tg * 4 * 32)), dim3(256), 0, stream, (const float*)ws, dW, g.Cs, g.Cl, (ND == 3) ? 64 : 16, (int)n_split, cb);
+    const int dw_blocks = cb * tg * 4 * 32;
+    const int bias_n = bias_mode == 1 ? g.Cs : (bias_mode == 2 ? g.Cl : 0), bias_width = bias_mode == 1 ? 64 : 32;
+    const int bias_rows = (int)n_split * ((bias_mode == 2 && ND == 3) ? 2 : 1);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(dw_blocks + (bias_n + 63) / 64)), dim3(256), 0, stream, (const float*)ws, dW, g.Cs, g.Cl, (ND == 3) ? 64 : 16,
+                       (int)n_split, cb, dw_blocks, (const float*)bias_ws, dbias, bias_n, bias_rows, bias_width);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
@@ -920,32 +986,46 @@ extern "C" size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd
     if (Cl == 1) return cvae_conv_wgrad_c1_workspace_bytes(Cs, nd);
     const int64_t groups = (Cs / 64) * (Cl / 32) * ((nd == 3) ? 4 : 1);             // slab groups (kd, channel block)
     const int64_t wgs = groups > WGRAD_MAX_WG ? groups : WGRAD_MAX_WG;             // groups * n_split <= max(WGRAD_MAX_WG, groups)
-    return (size_t)wgs * 32768 * sizeof(float);
+    const int64_t bias_floats = 2 * wgs * 64;                                      // bias partials: < 2 rows of 64 floats per workgroup
+    return (size_t)(wgs * 32768 + bias_floats) * sizeof(float);
 }
 
-extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, int dbias_side, void* workspace, size_t workspace_bytes,
                                int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                                int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (!dW) return CVAE_E_NULLPTR;
+    if (dbias_side != 0 && dbias_side != 1) return CVAE_E_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int taps = (nd == 3) ? 64 : 16;
     if (B == 0) {
-        if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cs * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
+        if (dbias && hipMemsetAsync(dbias, 0, (size_t)(dbias_side ? Cl : Cs) * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
         return hipMemsetAsync(dW, 0, (size_t)Cs * Cl * taps * sizeof(float), st) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
     }
     if (!S || !L) return CVAE_E_NULLPTR;
-    if (Cl == 1) return cvae_conv_wgrad_c1(S, L, dW, dbias, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);   // bias sum fused (S^T . ones)
+    if (Cl == 1) {
+        if (dbias && dbias_side == 1) {                      // ConvTranspose to one channel: its bias gradient is the plain sum of L
+            const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, 1, dtype, stream);
+            if (rcb != CVAE_OK) return rcb;
+            dbias = nullptr;
+        }
+        return cvae_conv_wgrad_c1(S, L, dW, dbias, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);   // S-side bias sum fused (S^T . ones)
+    }
     if (Cs % 64 || Cl % 32) return CVAE_E_UNSUPPORTED;
-    if (dbias) {
-        const int rcb = cvae_channel_sum(S, dbias, B * sd * sh * sw, Cs, dtype, stream);
+    int bias_mode = dbias ? (dbias_side ? 2 : 1) : 0;
+    if (bias_mode == 2 && (lh != 2 * sh || lw != 2 * sw || (nd == 3 && ld != 2 * sd))) {
+        // an odd L extent leaves a plane / row outside every tile's non-halo part: sum L separately
+        const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, Cl, dtype, stream);
         if (rcb != CVAE_OK) return rcb;
+        bias_mode = 0;
     }
     const size_t need = cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd);
     if (!workspace) return CVAE_E_NULLPTR;
     if (workspace_bytes < need) return CVAE_E_WORKSPACE;
     GEOM_INIT();
-    if (dtype == CVAE_BF16) return nd == 3 ? launch_wgrad<bf16, 3>(S, L, (float*)workspace, dW, g, st) : launch_wgrad<bf16, 2>(S, L, (float*)workspace, dW, g, st);
-    return nd == 3 ? launch_wgrad<float, 3>(S, L, (float*)workspace, dW, g, st) : launch_wgrad<float, 2>(S, L, (float*)workspace, dW, g, st);
+    float* db = bias_mode ? dbias : nullptr;
+    if (dtype == CVAE_BF16)
+        return nd == 3 ? launch_wgrad<bf16, 3>(S, L, (float*)workspace, dW, db, bias_mode, g, st) : launch_wgrad<bf16, 2>(S, L, (float*)workspace, dW, db, bias_mode, g, st);
+    return nd == 3 ? launch_wgrad<float, 3>(S, L, (float*)workspace, dW, db, bias_mode, g, st) : launch_wgrad<float, 2>(S, L, (float*)workspace, dW, db, bias_mode, g, st);
 }

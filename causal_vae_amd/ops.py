@@ -256,17 +256,17 @@ def _conv_up(St, wp, bias, mask, Cl, nd, act):
     return Lt
 
 
-def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False):
-    """dW (and, when want_sbias, the per-channel sum of S = the bias gradient of a Conv layer)."""
+def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False):
+    """dW and, in the same pass, the bias gradient: want_sbias = per-channel sum of S (Conv layer), want_lbias = of L (ConvTranspose)."""
     B, sd, sh, sw, Cs = _cl_dims(St)
     _, ld, lh, lw, Cl = _cl_dims(Lt)
     dW = torch.empty(wshape, dtype=torch.float32, device=St.device)
-    db = torch.empty(Cs, dtype=torch.float32, device=St.device) if want_sbias else None
+    db = torch.empty(Cl if want_lbias else Cs, dtype=torch.float32, device=St.device) if (want_sbias or want_lbias) else None
     nbytes = lib.cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=St.device)
-    check(L.timed(f"conv_wgrad nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L{Cl}", lib.cvae_conv_wgrad, ptr(St), ptr(Lt), ptr(dW), ptr(db), ptr(ws), nbytes,
+    check(L.timed(f"conv_wgrad nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L{Cl}", lib.cvae_conv_wgrad, ptr(St), ptr(Lt), ptr(dW), ptr(db), 1 if want_lbias else 0, ptr(ws), nbytes,
                   B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), stream()), "conv_wgrad")
-    return (dW, db) if want_sbias else dW
+    return (dW, db) if (want_sbias or want_lbias) else dW
 
 
 def _channel_sum(x):
@@ -351,9 +351,13 @@ class ConvUp(torch.autograd.Function):
         dx = dw = db = None
         fork = _Fork(g.device)
         with fork:
+            want_db = has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                dw = _conv_wgrad(x, g, nd, weight.shape)
-            if has_bias and ctx.needs_input_grad[2]:
+                if want_db:
+                    dw, db = _conv_wgrad(x, g, nd, weight.shape, want_lbias=True)
+                else:
+                    dw = _conv_wgrad(x, g, nd, weight.shape)
+            elif want_db:
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
             wp_dn = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, False, g.dtype)

@@ -135,10 +135,11 @@ int cvae_bottleneck_bwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_
                         float* dx_partial, void* dy_cl, int dtype, void* stream);
 
 /* dW fp32 [Cs][Cl][taps] (overwritten) = sum over batch and positions.  workspace: cvae_conv_wgrad_workspace_bytes().
- * dbias (optional, fp32 [Cs], overwritten) = sum over batch and positions of S: the bias gradient of a Conv layer, whose
- * S is the output gradient (fused into the weight-gradient pass where S is read anyway). */
+ * dbias (optional, overwritten) rides along in the same pass, where both tensors are read anyway:
+ *   dbias_side 0: fp32 [Cs] = sum over batch and positions of S — the bias gradient of a Conv layer (S = output gradient);
+ *   dbias_side 1: fp32 [Cl] = the same sum of L — the bias gradient of a ConvTranspose layer (L = output gradient). */
 size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd);
-int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, int dbias_side, void* workspace, size_t workspace_bytes,
                     int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                     int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream);
 /* out[c] = sum_p x[p, c] over a channels-last [P, C] tensor (bias gradients). out is overwritten. */
