@@ -40,6 +40,7 @@ SIGNATURES = {
     "cvae_conv_packed_weight_bytes": [_i64, _i64, _i, _i],
     "cvae_conv_pack_weight": [_p, _p, _i64, _i64, _i, _i, _i, _p],
     "cvae_conv_pack_weights": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "cvae_conv_pack_weight_pairs": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "cvae_conv_data_workspace_bytes": [_i64] * 9 + [_i, _i],
     "cvae_conv_down": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
     "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],

@@ -85,13 +85,19 @@ class CausalBioVAE(nn.Module):
     def _fused_bottleneck(self, x, m, t_onehot, eps):
         """The same computation as encode -> reparameterize -> mechanism_net -> dec_input, layer for layer, in csrc/bottleneck.hip.
         Returns None (caller takes the layer-by-layer path) in eval mode, for B > 16 / B == 1, or pool windows that do not tile."""
-        h, rest, last_act = self.enc_conv.features_cl(x)
         nd = self._ND
         out_size = (4,) * 3 if nd == 3 else (1, 4, 4)
         bn = self.mechanism_net[1]
-        if (not ops.BioBottleneck.supported(h, out_size, self.training) or last_act != "relu" or not bn.track_running_stats or bn.momentum is None
-                or not torch.is_grad_enabled()):
+        # decide before any kernel runs: training-mode BN, 2 <= B <= 16, and the /16 encoder output must tile into 4^nd windows
+        sp = [s // 16 for s in x.shape[2:]]
+        if (not self.training or not torch.is_grad_enabled() or not (2 <= x.shape[0] <= 16) or any(s < 4 or s % 4 for s in sp)
+                or any(s % 16 for s in x.shape[2:]) or not bn.track_running_stats or bn.momentum is None):
             return None
+        we, wd = self.enc_conv.conv_weights(), self.dec_conv.conv_weights()
+        packed = ops.pack_weights(we + wd, nd, self.enc_conv.compute_dtype)          # every conv weight of the model, one launch
+        h, rest, last_act = self.enc_conv.features_cl(x, packed=packed[:len(we)])
+        if not ops.BioBottleneck.supported(h, out_size, True) or last_act != "relu":
+            raise ops.L.CvaeError("fused bottleneck: unexpected encoder output " + str(tuple(h.shape)))
         if eps is None:
             eps = self._eps.draw(torch.empty(x.shape[0], self.fc_mu.out_features, device=x.device))
         lin = [self.enc_fc[0], self.enc_fc[2], self.fc_mu, self.fc_logvar, self.mechanism_net[0]]
@@ -99,7 +105,7 @@ class CausalBioVAE(nn.Module):
         params += [p for l in (self.mechanism_net[3], self.mechanism_net[5], self.dec_input) for p in (l.weight, l.bias)]
         mu, logvar, m_hat, dec_cl = ops.BioBottleneck.apply(h, m, t_onehot, eps, *params, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                                             bn.momentum, bn.eps, out_size)
-        return mu, logvar, m_hat, self.dec_conv.forward_from_cl(dec_cl)
+        return mu, logvar, m_hat, self.dec_conv.forward_from_cl(dec_cl, packed=packed[len(we):])
 
     def forward(self, x, m, t, eps=None):
         nd = self._ND

@@ -531,6 +531,41 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackTable tb) {
     }
 }
 
+// Both directions of every weight in one launch, through an LDS transpose: a block takes a 16 cs x 16 cl x taps tile of one fp32
+// master (16 contiguous rows of 16 * taps floats), and writes the `down` panel ([tap][cl / 16][cs][16 cl]) and the `up` panel
+// ([tap][cs / 16][cl][16 cs]) in 512-byte (bf16) runs — the gather form above reads every source line 16 times.
+#define PAIR_MAX 16
+struct PairTable {
+    const float* w[PAIR_MAX];
+    void* down[PAIR_MAX];
+    void* up[PAIR_MAX];
+    int Cs[PAIR_MAX], Cl[PAIR_MAX], blk_start[PAIR_MAX + 1];
+    int count, taps;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_pairs_kernel(PairTable tb) {
+    extern __shared__ float tile[];                          // [(cs * 17 + cl)][taps + 1]
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    const int Cs = tb.Cs[ti], Cl = tb.Cl[ti], taps = tb.taps, TP = taps + 1;
+    const int blk = (int)blockIdx.x - tb.blk_start[ti], nclt = Cl / 16, ncst = Cs / 16;
+    const int cst = blk / nclt, clt = blk % nclt, cs0 = cst * 16, cl0 = clt * 16;
+    const float* w = tb.w[ti];
+    const int row = 16 * taps;                               // floats of one cs row of the tile (contiguous in w)
+    for (int i = threadIdx.x; i < 16 * row; i += 256) {
+        const int cs = i / row, rem = i - cs * row, cl = rem / taps, tap = rem - cl * taps;
+        tile[(cs * 17 + cl) * TP + tap] = w[((size_t)(cs0 + cs) * Cl + cl0) * taps + rem];
+    }
+    __syncthreads();
+    T* od = (T*)tb.down[ti];
+    T* ou = (T*)tb.up[ti];
+    const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+    for (int tap = 0; tap < taps; ++tap) {
+        od[((size_t)(tap * nclt + clt) * Cs + cs0 + a) * 16 + b] = from_f32<T>(tile[(a * 17 + b) * TP + tap]);      // (cs = a, cl = b)
+        ou[((size_t)(tap * ncst + cst) * Cl + cl0 + a) * 16 + b] = from_f32<T>(tile[(b * 17 + a) * TP + tap]);      // (cl = a, cs = b)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- wgrad
 // Workgroup: 8 waves; block of 64 cs x 32 cl; one depth tap kd (3D) / all taps (2D); wave w owns kh = w & 3, kw = 0..3 and
 // the 32-row half sg = w >> 2 of the cs block: 4 accumulator tiles (64 VGPRs), so two workgroups (16 waves) fit a CU with the
@@ -923,6 +958,45 @@ extern "C" int cvae_conv_pack_weights(const float* const* w, void* const* packed
         tb.count = cnt;
         if (dtype == CVAE_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb);
         else hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb);
+        CVAE_CHECK_LAUNCH();
+    }
+    return CVAE_OK;
+}
+
+extern "C" int cvae_conv_pack_weight_pairs(const float* const* w, void* const* packed_down, void* const* packed_up, const int64_t* Cs, const int64_t* Cl,
+                                           int count, int nd, int dtype, void* stream) {
+    if ((nd != 2 && nd != 3) || count < 0) return CVAE_E_BADSHAPE;
+    if (count == 0) return CVAE_OK;
+    if (!w || !packed_down || !packed_up || !Cs || !Cl) return CVAE_E_NULLPTR;
+    if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
+    const int taps = (nd == 3) ? 64 : 16;
+    const size_t lds = (size_t)16 * 17 * (taps + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)pack_weight_pairs_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 17 * 65 * 4) != hipSuccess ||
+            hipFuncSetAttribute((const void*)pack_weight_pairs_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 17 * 65 * 4) != hipSuccess)
+            return CVAE_E_LAUNCH;
+        attr_set = true;
+    }
+    for (int c0 = 0; c0 < count; c0 += PAIR_MAX) {
+        PairTable tb;
+        const int cnt = (count - c0 < PAIR_MAX) ? count - c0 : PAIR_MAX;
+        tb.taps = taps;
+        long long blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t cs = Cs[c0 + i], cl = Cl[c0 + i];
+            if (cs <= 0 || cl <= 0) return CVAE_E_BADSHAPE;
+            if (cs % 16 || cl % 16) return CVAE_E_UNSUPPORTED;
+            if (!w[c0 + i] || !packed_down[c0 + i] || !packed_up[c0 + i]) return CVAE_E_NULLPTR;
+            tb.w[i] = w[c0 + i]; tb.down[i] = packed_down[c0 + i]; tb.up[i] = packed_up[c0 + i]; tb.Cs[i] = (int)cs; tb.Cl[i] = (int)cl;
+            tb.blk_start[i] = (int)blocks;
+            blocks += (cs / 16) * (cl / 16);
+            if (blocks > (1 << 30)) return CVAE_E_BADSHAPE;
+        }
+        tb.blk_start[cnt] = (int)blocks;
+        tb.count = cnt;
+        if (dtype == CVAE_BF16) hipLaunchKernelGGL(pack_weight_pairs_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, tb);
+        else hipLaunchKernelGGL(pack_weight_pairs_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, tb);
         CVAE_CHECK_LAUNCH();
     }
     return CVAE_OK;

@@ -111,14 +111,18 @@ class ConvStack(nn.Sequential):
     """Encoder: [Conv, ReLU]* (+ AdaptiveAvgPool) + Flatten.  forward(x NC(D)HW fp32) -> [B, F] fp32."""
     compute_dtype = torch.float32
 
-    def features_cl(self, x):
-        """Run the conv chain; returns the last activation channels-last (compute dtype) and the layers left over."""
+    def conv_weights(self):
+        return [m.weight for m in self if isinstance(m, _ConvBase)]
+
+    def features_cl(self, x, packed=None):
+        """Run the conv chain; returns the last activation channels-last (compute dtype) and the layers left over.
+        `packed`: this stack's entries of an ops.pack_weights call made by the caller (one launch for the whole model)."""
         mods = list(self)
         convs = [m for m in mods if isinstance(m, _ConvBase)]
         if not convs or x.shape[1] != convs[0].in_channels:
             raise RuntimeError(f"expected input with {convs[0].in_channels if convs else '?'} channels, got {tuple(x.shape)}")
         h = ops.ToChannelsLast.apply(x, self.compute_dtype)
-        packed = iter(ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))   # one launch for the stack
+        packed = iter(packed if packed is not None else ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))
         i, prev_act = 0, None
         while i < len(mods) and isinstance(mods[i], _ConvBase):
             act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
@@ -149,11 +153,14 @@ class DeconvStack(nn.Sequential):
     def forward_cl(self, h):
         return self.forward_from_cl(ops.ToChannelsLast.apply(h, self.compute_dtype))
 
-    def forward_from_cl(self, x):
+    def conv_weights(self):
+        return [m.weight for m in self if isinstance(m, _ConvBase)]
+
+    def forward_from_cl(self, x, packed=None):
         """The deconv chain on an input that is already channels-last in the compute dtype."""
         mods = list(self)
         convs = [m for m in mods if isinstance(m, _ConvBase)]
-        packed = iter(ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))   # one launch for the stack
+        packed = iter(packed if packed is not None else ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))
         i, prev_act = 0, None
         while i < len(mods):
             if not isinstance(mods[i], _ConvBase):

@@ -202,10 +202,10 @@ def pack_weight(w, nd, for_up, dtype):
 
 
 def pack_weights(weights, nd, dtype):
-    """Pack the weights of several conv layers for BOTH directions in one launch.
+    """Pack the weights of several conv layers for BOTH directions in one launch (cvae_conv_pack_weight_pairs).
     Returns [(packed_down, packed_up)] per weight; a Cl == 1 layer gets its fp32 weight back for both (not packed)."""
     import ctypes as C
-    outs, ws, ps, cs, cl, fu = [], [], [], [], [], []
+    outs, ws, pd, pu, cs, cl = [], [], [], [], [], []
     for w in weights:
         w = w.contiguous()
         Cs, Cl = w.shape[0], w.shape[1]
@@ -216,12 +216,11 @@ def pack_weights(weights, nd, dtype):
         both = torch.empty(2 * n, dtype=dtype, device=w.device)
         d, u = both[:n], both[n:]
         outs.append((d, u))
-        for for_up, buf in ((0, d), (1, u)):
-            ws.append(w.data_ptr()); ps.append(buf.data_ptr()); cs.append(Cs); cl.append(Cl); fu.append(for_up)
+        ws.append(w.data_ptr()); pd.append(d.data_ptr()); pu.append(u.data_ptr()); cs.append(Cs); cl.append(Cl)
     k = len(ws)
     if k:
-        check(lib.cvae_conv_pack_weights((C.c_void_p * k)(*ws), (C.c_void_p * k)(*ps), (C.c_int64 * k)(*cs), (C.c_int64 * k)(*cl),
-                                         (C.c_int * k)(*fu), k, nd, L.dtype_code(dtype), stream()), "conv_pack_weights")
+        check(lib.cvae_conv_pack_weight_pairs((C.c_void_p * k)(*ws), (C.c_void_p * k)(*pd), (C.c_void_p * k)(*pu), (C.c_int64 * k)(*cs), (C.c_int64 * k)(*cl),
+                                              k, nd, L.dtype_code(dtype), stream()), "conv_pack_weight_pairs")
     return outs
 
 

@@ -82,6 +82,10 @@ int cvae_conv_pack_weight(const float* w, void* packed, int64_t Cs, int64_t Cl, 
 int cvae_conv_pack_weights(const float* const* w, void* const* packed, const int64_t* Cs, const int64_t* Cl, const int* for_up,
                            int count, int nd, int dtype, void* stream);
 
+/* Both packings (for_up = 0 and 1) of a LIST of weights in one launch through an LDS transpose (Cs and Cl multiples of 16). */
+int cvae_conv_pack_weight_pairs(const float* const* w, void* const* packed_down, void* const* packed_up, const int64_t* Cs, const int64_t* Cl,
+                                int count, int nd, int dtype, void* stream);
+
 /* Optional scratch for cvae_conv_down (for_up = 0) / cvae_conv_up (for_up = 1): layers whose output grid is too small to fill
  * the chip (8^3, 4^3 volumes) split the input-channel loop over workgroups and sum fp32 partial tiles from this buffer.
  * Returns 0 when the launch needs none.  Passing NULL / a smaller buffer is always valid: the launch then runs unsplit. */
