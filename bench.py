@@ -136,7 +136,7 @@ def main():
     n_pre = 0
     if use_graph:
         from causal_vae_amd.graph import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, (x, m, t), lambda o, xx, mm: loss_function(o[0], xx, o[1], mm, o[2], o[3]), reducer=reducer, warmup=3)
+        gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3)      # None: model.forward_elbo, as train_step
         n_pre = 3                                                    # the capture warm-up runs 3 real steps
         step = lambda: gstep()
     else:

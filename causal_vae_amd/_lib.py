@@ -83,6 +83,10 @@ SIGNATURES = {
     "cvae_sqnorm": [_p, _p, _i64, _p],
     "cvae_scale": [_p, _i64, _p, _p],
     "cvae_clip_coef": [_p, _p, _f, _p],
+    "cvae_up2x_supported": [_i64] * 7,
+    "cvae_up2x_fwd": [_p, _p] + [_i64] * 7 + [_i, _p],
+    "cvae_elbo_up2x_fwd": [_p] * 6 + [_f, _p] + [_i64] * 9 + [_i, _p],
+    "cvae_elbo_up2x_bwd": [_p] * 6 + [_f] + [_p] * 6 + [_i64] * 9 + [_i, _p],
     "cvae_bottleneck_sizes": [_p, _p, _p, _p, _p, _p],
     "cvae_bottleneck_fwd": [_p] * 9 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p],
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],

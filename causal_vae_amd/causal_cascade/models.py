@@ -107,7 +107,8 @@ class CausalBioVAE(nn.Module):
                                                             bn.momentum, bn.eps, out_size)
         return mu, logvar, m_hat, self.dec_conv.forward_from_cl(dec_cl, packed=packed[len(we):])
 
-    def forward(self, x, m, t, eps=None):
+    def _forward_cl(self, x, m, t, eps):
+        """Everything up to the decoder output, channels-last [B, d, h, w, C] in the conv dtype (before the resize to x's size)."""
         nd = self._ND
         if x.dim() != nd + 2:
             raise RuntimeError(f"{type(self).__name__} expects a {nd + 2}-D input [B, C, {'D, ' if nd == 3 else ''}H, W], got {tuple(x.shape)}")
@@ -120,6 +121,10 @@ class CausalBioVAE(nn.Module):
             z = self.reparameterize(mu, logvar, eps)
             m_hat = self.mechanism_net(t_onehot)
             out_cl = self.decode_cl(ops.cat([z, m_hat]))
+        return out_cl, m_hat, mu, logvar
+
+    def _resize_to(self, out_cl, x):
+        nd = self._ND
         size = tuple(x.shape[2:]) if nd == 3 else (1,) + tuple(x.shape[2:])
         if tuple(out_cl.shape[1:4]) == size:
             recon_cl = ops.Cast.apply(out_cl, torch.float32)   # F.interpolate to the same size is the identity
@@ -127,10 +132,25 @@ class CausalBioVAE(nn.Module):
             recon_cl = ops.UpsampleLinear.apply(out_cl, size)
         B, C = x.shape[0], out_cl.shape[-1]
         if C != 1:
-            recon_x = ops.FromChannelsLast.apply(recon_cl, nd)
+            return ops.FromChannelsLast.apply(recon_cl, nd)
+        return recon_cl.view(B, 1, *x.shape[2:])               # C == 1: channels-last and NC(D)HW coincide
+
+    def forward(self, x, m, t, eps=None):
+        out_cl, m_hat, mu, logvar = self._forward_cl(x, m, t, eps)
+        return self._resize_to(out_cl, x), m_hat, mu, logvar
+
+    def forward_elbo(self, x, m, t, eps=None, gamma=2000.0):
+        """forward + loss_function(recon_x, x, m_hat, m, mu, logvar, gamma) -> (loss, recon_loss, m_loss) in one call.  When the resize
+        is the exact 2x of the benchmark shape the reconstruction term is computed from the decoder output directly
+        (ops.ElboUp2x): the resized volume is never written; otherwise this is literally forward() followed by the ELBO node."""
+        out_cl, m_hat, mu, logvar = self._forward_cl(x, m, t, eps)
+        if self.fuse_recon_loss and ops.ElboUp2x.supported(out_cl, x):
+            loss, recon, m_loss, _ = ops.ElboUp2x.apply(out_cl, x, m_hat, m, mu, logvar, gamma)
         else:
-            recon_x = recon_cl.view(B, 1, *x.shape[2:])        # C == 1: channels-last and NC(D)HW coincide
-        return recon_x, m_hat, mu, logvar
+            loss, recon, m_loss, _ = ops.Elbo.apply(self._resize_to(out_cl, x), x, m_hat, m, mu, logvar, gamma)
+        return loss, recon, m_loss
+
+    fuse_recon_loss = True
 
 
 class CausalBioVAE3D(CausalBioVAE):

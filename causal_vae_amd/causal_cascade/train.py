@@ -20,8 +20,11 @@ def train_step(model, optimizer, x, m, t, eps=None, gamma=2000.0, grad_hook=None
     """zero_grad -> forward -> ELBO -> backward -> [grad_hook, e.g. the data-parallel all-reduce] -> optimizer.step.
     Returns (loss, recon_loss, m_loss) as 0-dim device tensors (no host sync)."""
     optimizer.zero_grad(set_to_none=True)
-    recon_x, m_hat, mu, logvar = model(x, m, t) if eps is None else model(x, m, t, eps=eps)
-    loss, l_recon, l_m = loss_function(recon_x, x, m_hat, m, mu, logvar, gamma)
+    if hasattr(model, "forward_elbo"):      # same numbers; skips materialising recon_x when the resize is an exact 2x (models.py)
+        loss, l_recon, l_m = model.forward_elbo(x, m, t, eps=eps, gamma=gamma)
+    else:
+        recon_x, m_hat, mu, logvar = model(x, m, t) if eps is None else model(x, m, t, eps=eps)
+        loss, l_recon, l_m = loss_function(recon_x, x, m_hat, m, mu, logvar, gamma)
     loss.backward()
     if grad_hook is not None:
         grad_hook()

@@ -1,0 +1,285 @@
+// recon_loss.hip — the reconstruction end of the training step for the exact-2x resize (64^3 decoder output -> 128^3 volume):
+// F.interpolate(x_dec, size, mode='trilinear', align_corners=False) followed by the sum-of-squares reconstruction term of
+// loss_function (causal_cascade/models.py:84-87, train.py:5-17 of the reference).
+//
+// The resized volume is 8x the decoder output (33.5 MB fp32 per batch of 4); written, re-read by the loss, re-read by the loss
+// backward, and its gradient written and re-read by the resize backward, it made ~240 MB of traffic around 2 MB of information.
+// Here the 2x resize is recomputed where it is needed from the small tensor:
+//   up2x_block_kernel<MODE 0>  recon = up(src)                     (model.forward: the volume a caller asked for)
+//   up2x_block_kernel<MODE 1>  sum (up(src) - x)^2                 (ELBO forward: reads x once, never writes the volume)
+//   up2x_block_kernel<MODE 2>  t1 = U_w^T [2 g (up(src) - x)]      (ELBO backward, stage a: reads x once)
+//   up2x_bwd_b_kernel          d src = U_d^T U_h^T t1              (stage b)
+// A thread owns 4 consecutive source voxels along w and their 2 x 2 x 8 block of outputs; the 3 x 3 x 6 source neighbourhood is
+// loaded once (1.7 loads per output instead of 8).  The tap weights are the values lin_tap() of the generic kernels produces and the
+// interpolation keeps aten's association (w, then h, then d), so MODE 0 returns the same numbers as cvae_upsample_linear_fwd.
+#include "common.h"
+
+namespace {
+
+struct LinTap { int i0, i1; float w0, w1; };
+// torch upsample_linear, align_corners=False: src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out (float)
+__device__ __forceinline__ LinTap lin_tap(int o, int in, float scale) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    LinTap t;
+    t.i0 = (int)s;
+    if (t.i0 > in - 1) t.i0 = in - 1;
+    t.i1 = t.i0 + ((t.i0 < in - 1) ? 1 : 0);
+    t.w1 = s - (float)t.i0;
+    t.w0 = 1.f - t.w1;
+    return t;
+}
+// weights with which outputs j0 .. j0 + 3 (j0 = 2 i - 1) of a 2x-resized axis read source index i
+struct Win4 { int j0; float w[4]; };
+__device__ __forceinline__ Win4 win4(int i, int in, int out, float scale, bool strided) {
+    Win4 r;
+    if (!strided) { r.j0 = i; r.w[0] = 1.f; r.w[1] = r.w[2] = r.w[3] = 0.f; return r; }
+    r.j0 = 2 * i - 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int j = r.j0 + c;
+        float wv = 0.f;
+        if (j >= 0 && j < out) {
+            const LinTap t = lin_tap(j, in, scale);
+            wv = (t.i0 == i ? t.w0 : 0.f) + (t.i1 == i ? t.w1 : 0.f);
+        }
+        r.w[c] = wv;
+    }
+    return r;
+}
+
+// Exact 2x taps.  lin_tap() gives, for an even output o = 2 i: (i - 1, i) with weights (0.25, 0.75) — except o = 0: (0, 1) with
+// weights (1, 0) — and for an odd output o = 2 i + 1: (i, i + 1) with weights (0.75, 0.25), the upper index clamped to in - 1.
+// With source indices clamped on load the same values come out of a FIXED pattern: even -> (v[i-1], v[i]) x (0.25, 0.75), or x (0, 1)
+// at o = 0 (0*v0 + 1*v0 == 1*v0 + 0*v1); odd -> (v[i], v[i+1]) x (0.75, 0.25).  No per-output index arithmetic is left.
+__device__ __forceinline__ float2 even_w(int o) { return o == 0 ? make_float2(0.f, 1.f) : make_float2(0.25f, 0.75f); }
+
+// MODE 0: dst = up(src).  MODE 1: *acc_out += sum (up(src) - xin)^2.  MODE 2: t1[b][od][oh][x] = sum_ow Ww(ow -> x) gs (up(src) - xin),
+// gs = 2 * (*gout) * gscale.  D == d (2D tensors) leaves the depth axis untouched.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ src, const float* __restrict__ xin, float* __restrict__ dst,
+                                                         float* __restrict__ acc_out, const float* __restrict__ gout, float gscale,
+                                                         int B, int d, int h, int w, int D, int H, int W) {
+    constexpr int J0 = (MODE == 2) ? -1 : 0, NJ = (MODE == 2) ? 10 : 8;     // outputs along w per row: local j <-> ow = ow0 + J0 + j
+    const bool sdz = D != d;
+    const float sw = (float)w / (float)W;
+    const int wg = w >> 2, n = B * d * h * wg;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float sse = 0.f;
+    if (i < n) {
+        int r = i;
+        const int xg = r % wg; r /= wg;
+        const int y = r % h; r /= h;
+        const int z = r % d;
+        const int b = r / d;
+        const int x0 = 4 * xg, ow0 = 8 * xg;
+        // w-interpolated rows P[zr][yr][j] of the 3 x 3 source rows around (z, y): zr <-> z - 1 + zr, yr <-> y - 1 + yr (clamped)
+        float P[3][3][NJ];
+        const float2 ew0 = even_w(ow0);
+#pragma unroll
+        for (int zr = 0; zr < 3; ++zr) {
+            const int zi = sdz ? min(max(z - 1 + zr, 0), d - 1) : z;
+#pragma unroll
+            for (int yr = 0; yr < 3; ++yr) {
+                const int yi = min(max(y - 1 + yr, 0), h - 1);
+                const T* row = src + ((size_t)(b * d + zi) * h + yi) * w;
+                float v[6];                                  // source x0 - 1 .. x0 + 4 (clamped)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[c] = to_f32(row[min(max(x0 - 1 + c, 0), w - 1)]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int jj = J0 + j;                   // ow = ow0 + jj, jj in [-1, 8]
+                    if (jj & 1) {                            // odd: i = x0 + (jj - 1) / 2 -> v[(jj - 1) / 2 + 1], v[.. + 2]
+                        const int c = (jj + 1) / 2;          // jj = -1 -> c = 0; jj = 7 -> c = 4
+                        P[zr][yr][j] = 0.75f * v[c] + 0.25f * v[c + 1];
+                    } else {                                 // even: i = x0 + jj / 2 -> v[jj / 2], v[jj / 2 + 1]
+                        const int c = jj / 2;
+                        const float2 ww = (jj == 0) ? ew0 : make_float2(0.25f, 0.75f);
+                        P[zr][yr][j] = ww.x * v[c] + ww.y * v[c + 1];
+                    }
+                }
+            }
+        }
+        Win4 wx[4];
+        if (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wx[q] = win4(x0 + q, w, W, sw, true);
+        }
+        const float gs = (MODE == 2) ? 2.f * (gout ? *gout : 1.f) * gscale : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (!sdz && a == 1) break;
+            const int od = sdz ? 2 * z + a : z;
+            // depth taps: rows (a, a + 1) with weights (dw.x, dw.y); on an unstrided depth axis all three rows hold plane z and dw = (1, 0)
+            const int zr0 = a;
+            const float2 dw = !sdz ? make_float2(1.f, 0.f) : (a == 0 ? even_w(od) : make_float2(0.75f, 0.25f));
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+                const int oh = 2 * y + bq;
+                const float2 hw = (bq == 0) ? even_w(oh) : make_float2(0.75f, 0.25f);
+                float o[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float lo = hw.x * P[zr0][bq][j] + hw.y * P[zr0][bq + 1][j];
+                    const float hi = hw.x * P[zr0 + 1][bq][j] + hw.y * P[zr0 + 1][bq + 1][j];
+                    o[j] = dw.x * lo + dw.y * hi;
+                }
+                const size_t rowoff = ((size_t)(b * D + od) * H + oh) * W;
+                if (MODE == 0) {
+                    *(float4*)(dst + rowoff + ow0) = make_float4(o[0], o[1], o[2], o[3]);
+                    *(float4*)(dst + rowoff + ow0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                } else {
+                    const float4 xa = *(const float4*)(xin + rowoff + ow0), xb = *(const float4*)(xin + rowoff + ow0 + 4);
+                    const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    if (MODE == 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float df = o[j] - xv[j]; sse += df * df; }
+                    } else {
+                        float g[10];
+                        g[0] = (ow0 > 0) ? gs * (o[0] - xin[rowoff + ow0 - 1]) : 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) g[1 + j] = gs * (o[1 + j] - xv[j]);
+                        g[9] = (ow0 + 8 < W) ? gs * (o[9] - xin[rowoff + ow0 + 8]) : 0.f;
+                        float t1v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {                // outputs 2 (x0 + q) - 1 + c  ->  local g index 2 q + c
+                            float rs = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (wx[q].w[c] != 0.f) rs += wx[q].w[c] * g[2 * q + c];
+                            t1v[q] = rs;
+                        }
+                        *(float4*)(dst + ((size_t)(b * D + od) * H + oh) * w + x0) = make_float4(t1v[0], t1v[1], t1v[2], t1v[3]);
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        __shared__ float red[4];
+        sse = wave_sum(sse);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sse;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(acc_out, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// d src[b][z][y][x .. x + 3] = sum_{od, oh} Wd(od -> z) Wh(oh -> y) t1[b][od][oh][x ..]
+template <typename T>
+__global__ __launch_bounds__(256) void up2x_bwd_b_kernel(const float* __restrict__ t1, T* __restrict__ dsrc, int B, int d, int h, int w, int D, int H) {
+    const float sd = (float)d / (float)D, sh = (float)h / (float)H;
+    const int wg = w >> 2, n = B * d * h * wg;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int r = i;
+    const int xg = r % wg; r /= wg;
+    const int y = r % h; r /= h;
+    const int z = r % d;
+    const int b = r / d;
+    const Win4 wz = win4(z, d, D, sd, D != d), wy = win4(y, h, H, sh, true);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (wz.w[a] == 0.f) continue;
+        float pl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            if (wy.w[bb] == 0.f) continue;
+            const float4 v = *(const float4*)(t1 + ((size_t)(b * D + wz.j0 + a) * H + (wy.j0 + bb)) * w + 4 * xg);
+            pl[0] += wy.w[bb] * v.x; pl[1] += wy.w[bb] * v.y; pl[2] += wy.w[bb] * v.z; pl[3] += wy.w[bb] * v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += wz.w[a] * pl[q];
+    }
+    T* o = dsrc + ((size_t)(b * d + z) * h + y) * w + 4 * xg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(acc[q]);
+}
+
+// out4 = {0, 0, sum (m_hat - m)^2, -0.5 sum (1 + logvar - mu^2 - exp(logvar))}: the small terms of the ELBO in one block, which
+// also zeroes the accumulator of the reconstruction term (out4[1]).
+__global__ __launch_bounds__(256) void elbo_small_fwd_kernel(const float* __restrict__ m_hat, const float* __restrict__ m, const float* __restrict__ mu,
+                                                             const float* __restrict__ logvar, float* __restrict__ out4, int n_m, int n_z) {
+    __shared__ float red[2][4];
+    float sm = 0.f, sk = 0.f;
+    for (int i = threadIdx.x; i < n_m; i += 256) { const float df = m_hat[i] - m[i]; sm += df * df; }
+    for (int i = threadIdx.x; i < n_z; i += 256) sk += 1.f + logvar[i] - mu[i] * mu[i] - expf(logvar[i]);
+    sm = wave_sum(sm); sk = wave_sum(sk);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sm; red[1][threadIdx.x >> 6] = sk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out4[0] = 0.f; out4[1] = 0.f;
+        out4[2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        out4[3] = -0.5f * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+// d m_hat = 2 g gamma (m_hat - m); d mu = g mu; d logvar = 0.5 g (exp(logvar) - 1), g = *gout (1 when null)
+__global__ __launch_bounds__(256) void elbo_small_bwd_kernel(const float* __restrict__ m_hat, const float* __restrict__ m, const float* __restrict__ mu,
+                                                             const float* __restrict__ logvar, const float* __restrict__ gout, float gamma,
+                                                             float* __restrict__ d_mhat, float* __restrict__ dmu, float* __restrict__ dlv, int n_m, int n_z) {
+    const float g = gout ? *gout : 1.f;
+    for (int i = threadIdx.x; i < n_m; i += 256) d_mhat[i] = 2.f * g * gamma * (m_hat[i] - m[i]);
+    for (int i = threadIdx.x; i < n_z; i += 256) { dmu[i] = g * mu[i]; dlv[i] = 0.5f * g * (expf(logvar[i]) - 1.f); }
+}
+__global__ void elbo_combine_kernel(float* __restrict__ out4, float gamma) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out4[0] = out4[1] + gamma * out4[2] + out4[3];
+}
+
+bool up2x_ok(int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W) {
+    return B > 0 && d > 0 && h > 0 && w > 0 && (D == 2 * d || (D == 1 && d == 1)) && H == 2 * h && W == 2 * w && (w % 4) == 0 && B * D * H * W < (int64_t)1 << 31;
+}
+
+}  // namespace
+
+extern "C" int cvae_up2x_supported(int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W) { return up2x_ok(B, d, h, w, D, H, W) ? 1 : 0; }
+
+extern "C" int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int dtype, void* stream) {
+    if (!up2x_ok(B, d, h, w, D, H, W)) return CVAE_E_UNSUPPORTED;
+    if (!src || !dst) return CVAE_E_NULLPTR;
+    const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
+    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+    else if (dtype == CVAE_F32) hipLaunchKernelGGL((up2x_block_kernel<float, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+    else return CVAE_E_DTYPE;
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+extern "C" int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
+                                  float* out4, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z,
+                                  int dtype, void* stream) {
+    if (!up2x_ok(B, d, h, w, D, H, W) || n_m < 0 || n_z < 0 || n_m > (1 << 24) || n_z > (1 << 24)) return CVAE_E_UNSUPPORTED;
+    if (!src || !x || !m_hat || !m || !mu || !logvar || !out4) return CVAE_E_NULLPTR;
+    if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(elbo_small_fwd_kernel, dim3(1), dim3(256), 0, st, m_hat, m, mu, logvar, out4, (int)n_m, (int)n_z);
+    CVAE_CHECK_LAUNCH();
+    const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
+    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 1>), dim3(grid), dim3(256), 0, st, (const bf16*)src, x, nullptr, out4 + 1, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+    else hipLaunchKernelGGL((up2x_block_kernel<float, 1>), dim3(grid), dim3(256), 0, st, (const float*)src, x, nullptr, out4 + 1, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(elbo_combine_kernel, dim3(1), dim3(64), 0, st, out4, gamma);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+extern "C" int cvae_elbo_up2x_bwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
+                                  const float* g_loss, float* t1, void* dsrc, float* d_mhat, float* dmu, float* dlv, int64_t B, int64_t d, int64_t h, int64_t w,
+                                  int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z, int dtype, void* stream) {
+    if (!up2x_ok(B, d, h, w, D, H, W) || n_m < 0 || n_z < 0 || n_m > (1 << 24) || n_z > (1 << 24)) return CVAE_E_UNSUPPORTED;
+    if (!src || !x || !m_hat || !m || !mu || !logvar || !t1 || !dsrc || !d_mhat || !dmu || !dlv) return CVAE_E_NULLPTR;
+    if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(elbo_small_bwd_kernel, dim3(1), dim3(256), 0, st, m_hat, m, mu, logvar, g_loss, gamma, d_mhat, dmu, dlv, (int)n_m, (int)n_z);
+    CVAE_CHECK_LAUNCH();
+    const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
+    if (dtype == CVAE_BF16) {
+        hipLaunchKernelGGL((up2x_block_kernel<bf16, 2>), dim3(grid), dim3(256), 0, st, (const bf16*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        CVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(up2x_bwd_b_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const float*)t1, (bf16*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H);
+    } else {
+        hipLaunchKernelGGL((up2x_block_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        CVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(up2x_bwd_b_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)t1, (float*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H);
+    }
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}

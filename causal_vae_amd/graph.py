@@ -15,9 +15,10 @@ from .optim import FusedAdam
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, batch, loss_fn, reducer=None, warmup=3):
+    def __init__(self, model, optimizer, batch, loss_fn=None, reducer=None, warmup=3):
         """batch: (x, m, t) example tensors on the GPU (their storage becomes the static input buffers).
-        loss_fn(model_outputs, x, m) -> (loss, *others): 0-dim tensors; `loss` is back-propagated."""
+        loss_fn(model_outputs, x, m) -> (loss, *others): 0-dim tensors; `loss` is back-propagated.  None: the model's own
+        forward_elbo(x, m, t) (what causal_cascade.train.train_step runs)."""
         if not isinstance(optimizer, FusedAdam) or not optimizer.device_step:
             raise CvaeError("GraphedTrainStep needs FusedAdam(..., device_step=True): the step count must live on the device")
         self.model, self.opt, self.reducer = model, optimizer, reducer
@@ -49,8 +50,10 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         self.opt.zero_grad(set_to_none=True)
-        outs = self.model(self.x, self.m, self.t)
-        res = self.loss_fn(outs, self.x, self.m)
+        if self.loss_fn is None:
+            res = self.model.forward_elbo(self.x, self.m, self.t)
+        else:
+            res = self.loss_fn(self.model(self.x, self.m, self.t), self.x, self.m)
         res[0].backward()
         return tuple(r.detach() for r in res)
 

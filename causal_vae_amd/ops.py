@@ -422,7 +422,10 @@ class UpsampleLinear(torch.autograd.Function):
         B, d, h, w, Cc = _cl_dims(x)
         D, H, W = size
         out = _empty((B, D, H, W, Cc), torch.float32, x)
-        check(lib.cvae_upsample_linear_fwd(ptr(x), ptr(out), B, d, h, w, D, H, W, Cc, L.dtype_code(x.dtype), stream()), "upsample_fwd")
+        if Cc == 1 and lib.cvae_up2x_supported(B, d, h, w, D, H, W):          # exact 2x, one channel: the block kernel of csrc/recon_loss.hip
+            check(lib.cvae_up2x_fwd(ptr(x), ptr(out), B, d, h, w, D, H, W, L.dtype_code(x.dtype), stream()), "up2x_fwd")
+        else:
+            check(lib.cvae_upsample_linear_fwd(ptr(x), ptr(out), B, d, h, w, D, H, W, Cc, L.dtype_code(x.dtype), stream()), "upsample_fwd")
         ctx.meta = (x.shape, x.dtype, size)
         return out
 
@@ -665,6 +668,54 @@ class Elbo(torch.autograd.Function):
             dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
             check(lib.cvae_reparam_kld_bwd(None, ptr(scales[2][0]), scales[2][1], ptr(mu), ptr(logvar), None, ptr(dmu), ptr(dlv), mu.numel(), stream()), "kld_bwd")
         return d_recon, None, d_mhat, None, dmu, dlv, None
+
+
+class ElboUp2x(torch.autograd.Function):
+    """The same ELBO with the exact-2x resize of the decoder output folded in: recon = SSE(F.interpolate(src, size(x)), x) without
+    ever writing the resized volume (csrc/recon_loss.hip).  src: channels-last decoder output [B, d, h, w, 1] (conv dtype);
+    x: [B, 1, D, H, W] / [B, 1, H, W] fp32 with D = 2d (3D), H = 2h, W = 2w.  Returns (loss, recon, m_loss, kld)."""
+
+    @staticmethod
+    def dims(src, x):
+        B, d, h, w, Cc = _cl_dims(src)
+        sp = tuple(x.shape[2:])
+        D, H, W = sp if len(sp) == 3 else (1,) + sp
+        return B, d, h, w, Cc, D, H, W
+
+    @staticmethod
+    def supported(src, x):
+        B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
+        return (Cc == 1 and x.shape[0] == B and x.shape[1] == 1 and x.dtype == torch.float32 and bool(lib.cvae_up2x_supported(B, d, h, w, D, H, W)))
+
+    @staticmethod
+    def forward(ctx, src, x, m_hat, m, mu, logvar, gamma):
+        L.require_gpu(src, x, m_hat, m, mu, logvar)
+        src = src.contiguous()
+        x, m_hat, m, mu, logvar = (t.contiguous().float() for t in (x, m_hat, m, mu, logvar))
+        if m_hat.shape != m.shape or mu.shape != logvar.shape:
+            raise RuntimeError(f"The size of tensor a {tuple(m_hat.shape)} must match the size of tensor b {tuple(m.shape)}")
+        B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
+        buf = torch.empty(4, dtype=torch.float32, device=x.device)
+        check(lib.cvae_elbo_up2x_fwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), float(gamma), ptr(buf), B, d, h, w, D, H, W,
+                                     m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_fwd")
+        ctx.save_for_backward(src, x, m_hat, m, mu, logvar)
+        ctx.gamma = float(gamma)
+        ctx.set_materialize_grads(False)
+        return buf[0], buf[1], buf[2], buf[3]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_recon, g_m, g_kld):
+        src, x, m_hat, m, mu, logvar = ctx.saved_tensors
+        if g_recon is not None or g_m is not None or g_kld is not None:
+            raise L.CvaeError("ElboUp2x back-propagates the total loss only; for a single term use loss_function on the model's recon_x")
+        if g_loss is None:
+            return None, None, None, None, None, None, None
+        B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
+        t1 = torch.empty(B * D * H * w, dtype=torch.float32, device=x.device)
+        dsrc, d_mhat, dmu, dlv = torch.empty_like(src), torch.empty_like(m_hat), torch.empty_like(mu), torch.empty_like(mu)
+        check(lib.cvae_elbo_up2x_bwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), ctx.gamma, ptr(g_loss.contiguous()), ptr(t1), ptr(dsrc),
+                                     ptr(d_mhat), ptr(dmu), ptr(dlv), B, d, h, w, D, H, W, m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_bwd")
+        return dsrc, None, d_mhat, None, dmu, dlv, None
 
 
 def sse(a, b):

@@ -101,6 +101,23 @@ int cvae_conv_up(const void* S, const void* w, const float* bias, const void* ma
                  int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                  int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* ---- Exact-2x linear resize (decoder output d x h x w, one channel -> 2d x 2h x 2w; D == d == 1 for 2D) fused with the ELBO ----
+ * causal_cascade/models.py:84-87 + train.py:5-17: the resized volume is recomputed from the small tensor wherever it is needed
+ * instead of being written and re-read (csrc/recon_loss.hip).  cvae_up2x_supported: 1 when the shapes qualify (w % 4 == 0). */
+int cvae_up2x_supported(int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W);
+/* dst fp32 [B][D][H][W] = F.interpolate(src, (D, H, W), 'trilinear' | 'bilinear', align_corners=False) */
+int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int dtype, void* stream);
+/* out4 = {loss, recon, m_loss, kld}: recon = sum (up(src) - x)^2, m_loss = sum (m_hat - m)^2 (n_m elements),
+ * kld = -0.5 sum (1 + logvar - mu^2 - exp(logvar)) (n_z elements), loss = recon + gamma * m_loss + kld. */
+int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
+                       float* out4, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z,
+                       int dtype, void* stream);
+/* Gradients of `loss` scaled by the device scalar *g_loss (NULL = 1): dsrc (src's dtype), d_mhat, dmu, dlv.
+ * t1: scratch of B*D*H*w floats. */
+int cvae_elbo_up2x_bwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
+                       const float* g_loss, float* t1, void* dsrc, float* d_mhat, float* dmu, float* dlv, int64_t B, int64_t d, int64_t h, int64_t w,
+                       int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z, int dtype, void* stream);
+
 /* ---- The dense bottleneck of CausalBioVAE in 5 + 5 launches (batch M <= 16, fp32 arithmetic) --------------------------------
  * Replaces, between the last encoder conv and the first decoder conv (causal_cascade/models.py:57-79):
  *   AdaptiveAvgPool + Flatten, cat([x_feat, m, t]), enc_fc (Linear-ReLU-Linear-ReLU), fc_mu, fc_logvar, reparameterize,

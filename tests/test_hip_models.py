@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     import causal_vae_amd
     from causal_vae_amd import FusedAdam
+    from causal_vae_amd import ops as ops_mod
     from causal_vae_amd._lib import CvaeError
     from causal_vae_amd.causal_cascade import CausalBioVAE, CausalBioVAE3D, loss_function, train_one_epoch, train_step
     from causal_vae_amd.mnist_baseline import CausalMorphVAE12, LatentDiscriminator
@@ -374,3 +375,36 @@ def test_fused_bottleneck_equals_layer_by_layer_path(cls, shape, dtype):
             grad_close(b["grads"][k], a["grads"][k].cpu(), k, l2=1e-3, linf=1e-2)    # atomics order + isolated ReLU-mask flips
         else:       # bf16 convs: a flipped bf16 rounding in dec_input's output / the pooled gradient moves conv gradients by ~1 bf16 ulp
             grad_close(b["grads"][k], a["grads"][k].cpu(), k, l2=2e-2, linf=5e-2)
+
+
+@pytest.mark.parametrize("cls,shape,dtype", [("3d", (2, 1, 128, 128, 128), torch.float32), ("3d", (2, 1, 128, 128, 128), torch.bfloat16),
+                                             ("2d", (4, 1, 128, 128), torch.float32)])     # the decoder emits 64^nd: these are the exact-2x resizes
+def test_forward_elbo_equals_forward_plus_loss_function(cls, shape, dtype):
+    """model.forward_elbo (exact-2x resize folded into the ELBO, recon_x never written) == loss_function(model(x, m, t)):
+    the three returned numbers and every gradient."""
+    Model = CausalBioVAE3D if cls == "3d" else CausalBioVAE
+    g = torch.Generator().manual_seed(5)
+    B = shape[0]
+    x, m = torch.randn(*shape, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (B,), generator=g).to(DEV)
+    eps = torch.randn(B, 64, generator=g).to(DEV)
+    runs = []
+    for fused in (False, True):
+        torch.manual_seed(42)
+        model = Model().to(DEV).train().set_compute_dtype(dtype)
+        if fused:
+            out = model.forward_elbo(x, m, t, eps=eps)
+            assert ops_mod.ElboUp2x.supported(model._forward_cl(x, m, t, eps)[0], x)
+        else:
+            model.fuse_recon_loss = False
+            o = model(x, m, t, eps=eps)
+            out = loss_function(o[0], x, o[1], m, o[2], o[3])
+        model.zero_grad()
+        out[0].backward()
+        runs.append((out, {k: p.grad.clone() for k, p in model.named_parameters()}))
+    (oa, ga), (ob, gb) = runs
+    for u, v, name in zip(oa, ob, ("loss", "recon", "m_loss")):
+        assert rel(v, u) < 2e-6, (name, float(u), float(v))
+    for k in ga:
+        if k != NOISE_KEY:
+            grad_close(gb[k], ga[k].cpu(), k, l2=1e-3 if dtype == torch.float32 else 2e-2, linf=1e-2 if dtype == torch.float32 else 5e-2)
