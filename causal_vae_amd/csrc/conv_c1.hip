@@ -34,7 +34,7 @@ template <> struct C1Ops<bf16> {
         const uint32_t* p1 = (const uint32_t*)(halo + pb + (2 * h + 1) * IW);
         union { uint32_t u[4]; bf16x8 v; } a;
         a.u[0] = p0[0]; a.u[1] = p0[1]; a.u[2] = p1[0]; a.u[3] = p1[1];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, bfr.v, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.v, a.v, acc, 0, 0, 0);       // D = W x im2col^T: rows = channels, columns = positions
     }
 };
 template <> struct C1Ops<float> {
@@ -50,7 +50,7 @@ template <> struct C1Ops<float> {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {                     // tap (within the block) = 2s + h: kh = s >> 1, kw = 2 (s & 1) + h
             const float a = halo[pb + (s >> 1) * IW + 2 * (s & 1) + h];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr.v[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr.v[s], a, acc, 0, 0, 0);
         }
     }
 };
@@ -79,16 +79,23 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
         const int pos = t + i * 256;
         const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
         const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - 1 + x;
-        const bool ok = pos < NPOS && gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
-        hv[i] = ok ? L[(((size_t)b * ld + gz) * lh + gy) * lw + gx] : from_f32<T>(0.f);
+        const bool ok = (pos < NPOS) & (gz >= 0) & (gz < ld) & (gy >= 0) & (gy < lh) & (gx >= 0) & (gx < lw);
+        const T v = L[(((size_t)b * ld + min(max(gz, 0), ld - 1)) * lh + min(max(gy, 0), lh - 1)) * lw + min(max(gx, 0), lw - 1)];    // clamped: unconditional load
+        hv[i] = ok ? v : from_f32<T>(0.f);
     }
     typename OP::BFrag bfr[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) OP::load_b(bfr[kb], w + (size_t)r * TAPS, kb, h);
-    const float bv = bias ? bias[r] : 0.f;
 #pragma unroll
     for (int i = 0; i < HN; ++i) if (t + i * 256 < NPOS) halo[t + i * 256] = hv[i];
     __syncthreads();
+    float bv[2][8];                                          // bias of this lane's two 8-channel pieces (channels 16 j + 8 h + q)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (bias) { b0 = *(const float4*)(bias + 16 * j + 8 * h); b1 = *(const float4*)(bias + 16 * j + 8 * h + 4); }
+        bv[j][0] = b0.x; bv[j][1] = b0.y; bv[j][2] = b0.z; bv[j][3] = b0.w; bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
+    }
     // ---- each wave: 2 sub-tiles of 32 positions ----
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -100,66 +107,132 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) OP::template mma_block<IW>(acc, halo, pb + kb * IH * IW, h, bfr[kb]);
+        // D rows are channels, columns positions: lane (r, h) holds channels (e & 3) + 8 (e >> 2) + 4 h of position r.  Two
+        // v_permlane32_swap per register pair regroup them into channels 8h..8h+7 and 16+8h..23+8h: 16-byte stores and mask loads.
+        const int mo = (wave * 2 + ms) * 32 + r;
+        const int ow = o0w + mo % TW, oh = o0h + mo / TW % TH, od = o0d + mo / (TW * TH);
+        const bool ok = od < sd && oh < sh && ow < sw;
+        const size_t pidx = ((((size_t)b * sd + od) * sh + oh) * sw + ow) * CS;
+        float v[2][8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int mo = (wave * 2 + ms) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int ow = o0w + mo % TW, oh = o0h + mo / TW % TH, od = o0d + mo / (TW * TH);
-            if (od >= sd || oh >= sh || ow >= sw) continue;
-            const size_t idx = ((((size_t)b * sd + od) * sh + oh) * sw + ow) * CS + r;
-            float v = apply_act(acc[e] + bv, act);
-            if (mask && !(to_f32(mask[idx]) > 0.f)) v = 0.f;
-            S[idx] = from_f32<T>(v);
+        for (int i = 0; i < 4; ++i) {
+            const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[4 + i]), false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 + i]), __float_as_uint(acc[12 + i]), false, false);
+            v[0][i] = __uint_as_float(lo[0]); v[0][4 + i] = __uint_as_float(lo[1]);
+            v[1][i] = __uint_as_float(hi[0]); v[1][4 + i] = __uint_as_float(hi[1]);
+        }
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = 16 * j + 8 * h;
+                __attribute__((aligned(16))) T mv[8], ov[8];
+                constexpr int NU = (8 * sizeof(T)) / 16;
+                if (mask) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) ((uint4*)mv)[u] = ((const uint4*)(mask + pidx + c))[u];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float x = apply_act(v[j][q] + bv[j][q], act);
+                    if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
+                    ov[q] = from_f32<T>(x);
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ((uint4*)(S + pidx + c))[u] = ((const uint4*)ov)[u];
+            }
         }
     }
 }
 
 // -------------------------------------------------------------------------------------- up, Cl == 1
-// One thread per output voxel: 2 (s, k) pairs per strided dim -> 8 (3D) / 4 (2D) taps x CS channels.
+// One thread per (source voxel q, half of the CS channels): the 2 x 2 x 2 (3D) / 2 x 2 (2D) outputs around q read the 3^nd
+// neighbourhood of q, so each neighbour's 16 channels are loaded ONCE (two 16-byte loads) and feed every output parity that
+// uses it — 2.4x fewer loads than one thread per output voxel.  Weights sit in LDS as fp32 [tap][cs] and are read as
+// wave-uniform broadcasts; the two channel halves of a voxel meet in a shuffle.
 template <typename T, int ND, int CS>
 __global__ __launch_bounds__(256) void up_c1_kernel(const T* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
                                                     const T* __restrict__ mask, T* __restrict__ L, int B, int sd, int sh, int sw, int ld, int lh, int lw, int act) {
-    constexpr int TAPS = (ND == 3) ? 64 : 16;
+    static_assert(CS == 32, "two 16-channel halves");
+    constexpr int TAPS = (ND == 3) ? 64 : 16, NP = (ND == 3) ? 8 : 4;
     __shared__ __attribute__((aligned(16))) float wl[TAPS * CS];      // [tap][cs]
     for (int i = threadIdx.x; i < TAPS * CS; i += 256) { const int tap = i / CS, cs = i % CS; wl[i] = w[cs * TAPS + tap]; }
     __syncthreads();
-    const int64_t n = (int64_t)B * ld * lh * lw;
-    const float b0 = bias ? bias[0] : 0.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t rr = i;
-        const int lx = (int)(rr % lw); rr /= lw;
-        const int ly = (int)(rr % lh); rr /= lh;
-        const int lz = (int)(rr % ld);
-        const int b = (int)(rr / ld);
-        float acc = 0.f;
+    const int n = B * sd * sh * sw;                          // host bounds it below 2^30
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int q = gid >> 1, hc = gid & 1;                    // lanes 2k, 2k+1: the two channel halves of voxel q
+    const bool live = q < n;
+    int rr = live ? q : 0;
+    const int qx = rr % sw; rr /= sw;
+    const int qy = rr % sh; rr /= sh;
+    const int qz = rr % sd;
+    const int b = rr / sd;
+    float acc[NP];
 #pragma unroll
-        for (int a = 0; a < ((ND == 3) ? 2 : 1); ++a) {
-            const int rz = lz & 1, sz = (ND == 3) ? (lz >> 1) - 1 + rz + a : 0, kd = (ND == 3) ? 3 - rz - 2 * a : 0;
-            if (sz < 0 || sz >= sd) continue;
+    for (int p = 0; p < NP; ++p) acc[p] = 0.f;
+    // output parity (pz, py, px) of voxel q: l = 2 q + p reads neighbour q + (p - 1 + a), a in {0, 1}, through tap k = 3 - p - 2 a
+    // (per dimension).  Neighbour offset o = p - 1 + a in {-1, 0, 1}: o = -1 <- (p 0, a 0, k 3); o = 0 <- (p 0, a 1, k 1), (p 1, a 0, k 2);
+    // o = +1 <- (p 1, a 1, k 0).
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int ry = ly & 1, sy = (ly >> 1) - 1 + ry + bb, kh = 3 - ry - 2 * bb;
-                if (sy < 0 || sy >= sh) continue;
+    for (int oz = (ND == 3 ? -1 : 0); oz <= (ND == 3 ? 1 : 0); ++oz) {
+        const int z = qz + oz;
+        if (ND == 3 && (z < 0 || z >= sd)) continue;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int rx = lx & 1, sx = (lx >> 1) - 1 + rx + c, kw = 3 - rx - 2 * c;
-                    if (sx < 0 || sx >= sw) continue;
-                    const T* sp = S + ((((size_t)b * sd + sz) * sh + sy) * sw + sx) * CS;
-                    const float* wr = &wl[((kd * 4 + kh) * 4 + kw) * CS];
+        for (int oy = -1; oy <= 1; ++oy) {
+            const int y = qy + oy;
+            if (y < 0 || y >= sh) continue;
 #pragma unroll
-                    for (int c8 = 0; c8 < CS / 8; ++c8) {
-                        __attribute__((aligned(16))) T v[8];
-                        constexpr int NU = (8 * sizeof(T)) / 16;
+            for (int ox = -1; ox <= 1; ++ox) {
+                const int x = qx + ox;
+                if (x < 0 || x >= sw) continue;
+                const T* sp = S + ((((size_t)b * sd + z) * sh + y) * sw + x) * CS + 16 * hc;
+                float sv[16];
+                {
+                    constexpr int NU = (16 * sizeof(T)) / 16;
+                    __attribute__((aligned(16))) T raw[16];
 #pragma unroll
-                        for (int u = 0; u < NU; ++u) ((uint4*)v)[u] = ((const uint4*)(sp + 8 * c8))[u];
+                    for (int u = 0; u < NU; ++u) ((uint4*)raw)[u] = ((const uint4*)sp)[u];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc += to_f32(v[e]) * wr[8 * c8 + e];
+                    for (int e = 0; e < 16; ++e) sv[e] = to_f32(raw[e]);
+                }
+                // every (parity, tap) pair per dimension that maps onto this offset
+#pragma unroll
+                for (int cz = 0; cz < (ND == 3 ? 2 : 1); ++cz) {
+                    const int pz = (ND == 3) ? (oz == -1 ? 0 : (oz == 1 ? 1 : cz)) : 0;
+                    const int kd = (ND == 3) ? (oz == -1 ? 3 : (oz == 1 ? 0 : (cz == 0 ? 1 : 2))) : 0;
+                    if (ND == 3 && oz != 0 && cz == 1) continue;
+#pragma unroll
+                    for (int cy = 0; cy < 2; ++cy) {
+                        const int py = oy == -1 ? 0 : (oy == 1 ? 1 : cy), kh = oy == -1 ? 3 : (oy == 1 ? 0 : (cy == 0 ? 1 : 2));
+                        if (oy != 0 && cy == 1) continue;
+#pragma unroll
+                        for (int cx = 0; cx < 2; ++cx) {
+                            const int px = ox == -1 ? 0 : (ox == 1 ? 1 : cx), kw = ox == -1 ? 3 : (ox == 1 ? 0 : (cx == 0 ? 1 : 2));
+                            if (ox != 0 && cx == 1) continue;
+                            const float* wr = &wl[((kd * 4 + kh) * 4 + kw) * CS + 16 * hc];
+                            float a = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) a += sv[e] * wr[e];
+                            acc[(pz * 2 + py) * 2 + px] += a;
+                        }
                     }
                 }
             }
         }
-        float v = apply_act(acc + b0, act);
-        if (mask && !(to_f32(mask[i]) > 0.f)) v = 0.f;
-        L[i] = from_f32<T>(v);
+    }
+    const float b0 = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] += __shfl_xor(acc[p], 1, 64);      // the other channel half
+    if (!live) return;
+    // lane hc writes the outputs with px == hc ... each lane stores half of the 2^nd outputs (x-adjacent pairs stay contiguous per py, pz)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if ((p & 1) != hc) continue;
+        const int pz = (ND == 3) ? (p >> 2) : 0, py = (p >> 1) & 1, px = p & 1;
+        const int lz = (ND == 3) ? 2 * qz + pz : 0, ly = 2 * qy + py, lx = 2 * qx + px;
+        const size_t idx = (((size_t)b * ld + lz) * lh + ly) * lw + lx;
+        float v = apply_act(acc[p] + b0, act);
+        if (mask && !(to_f32(mask[idx]) > 0.f)) v = 0.f;
+        L[idx] = from_f32<T>(v);
     }
 }
 
@@ -342,8 +415,9 @@ int cvae_conv_down_c1(const void* L, const float* w, const float* bias, const vo
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream) {
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
-    const int64_t n = B * ld * lh * lw;
-    dim3 grid((unsigned)cvae_grid_1d(n, 256));
+    const int64_t n = B * sd * sh * sw;                     // one thread per (source voxel, channel half)
+    if (n >= ((int64_t)1 << 30) || ld != 2 * sd && nd == 3 || lh != 2 * sh || lw != 2 * sw) return CVAE_E_UNSUPPORTED;
+    dim3 grid((unsigned)((2 * n + 255) / 256));
 #define LAUNCH_UP_C1(T, ND)                                                                                                          \
     hipLaunchKernelGGL((up_c1_kernel<T, ND, 32>), grid, dim3(256), 0, stream, (const T*)S, w, bias, (const T*)mask, (T*)L, (int)B, (int)sd,   \
                        (int)sh, (int)sw, (int)ld, (int)lh, (int)lw, act)
