@@ -152,6 +152,12 @@ class CausalBioVAE(nn.Module):
 
     fuse_recon_loss = True
 
+    def early_gradient_parameters(self):
+        """Parameters whose gradients are complete before the encoder's backward starts (everything but enc_conv): candidates for
+        FusedAdam.overlap_backward."""
+        enc = {id(p) for p in self.enc_conv.parameters()}
+        return [p for p in self.parameters() if id(p) not in enc]
+
 
 class CausalBioVAE3D(CausalBioVAE):
     """The 3D vessel-volume model: x is [B, 1, D, H, W]."""

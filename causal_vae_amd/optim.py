@@ -21,50 +21,98 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.device_step = device_step
         self._step_dev = None
+        self._early, self._early_hooks, self._side = [], [], None
+        self._early_left, self._early_ran, self._counted = 0, False, False
+
+    # ---- Adam of the early-finished gradients under the rest of the backward --------------------------------------------------
+    def overlap_backward(self, early_params):
+        """Run the update of `early_params` on a side stream as soon as the LAST of their gradients has been accumulated, i.e. while
+        the backward of everything upstream of them is still running (Adam is HBM-bound, the remaining convolutions are not).
+        step() then joins the side stream and updates the other parameters.  Single parameter group, no grad_scale; call with
+        an empty list to switch it off.  Gradient exchange between ranks must not be pending on these parameters."""
+        for h in self._early_hooks:
+            h.remove()
+        self._early_hooks, self._early = [], [p for p in early_params if p.requires_grad]
+        if not self._early:
+            return
+        if len(self.param_groups) != 1:
+            raise L.CvaeError("FusedAdam.overlap_backward: one parameter group expected")
+        self._early_ids = {id(p) for p in self._early}
+        self._early_left, self._early_ran = len(self._early), False
+        for p in self._early:
+            self._early_hooks.append(p.register_post_accumulate_grad_hook(self._early_hook))
+
+    def _early_hook(self, p):
+        self._early_left -= 1
+        if self._early_left == 0:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            with torch.no_grad():
+                self._count_step(self._early[0].device)          # on the main stream, before the fork
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self._update(self.param_groups[0], self._early, None)
+            self._early_ran = True
+
+    def zero_grad(self, set_to_none=True):
+        self._early_left, self._early_ran = len(self._early), False
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def _count_step(self, device):
+        if self.device_step and not self._counted:
+            if self._step_dev is None:
+                self._step_dev = torch.zeros((), dtype=torch.int32, device=device)
+            check(lib.cvae_counter_add(ptr(self._step_dev), 1, stream()), "counter_add")
+            self._counted = True
+
+    def _update(self, group, ps, grad_scale):
+        import ctypes as C
+        b1, b2 = group["betas"]
+        L.require_gpu(*ps)
+        t = None
+        gs = []
+        for p in ps:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise L.CvaeError("FusedAdam: contiguous float32 parameters expected")
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            st["step"] += 1
+            if t is None:
+                t = st["step"]
+            elif t != st["step"]:
+                raise L.CvaeError("FusedAdam: parameters of one group must share a step count")
+            gs.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        n = len(ps)
+        arr = lambda vals: (C.c_void_p * n)(*vals)
+        sizes = (C.c_int64 * n)(*[p.numel() for p in ps])
+        step_ptr = ptr(self._step_dev) if self.device_step else None
+        check(lib.cvae_adam_multi(arr([p.data_ptr() for p in ps]), arr([g.data_ptr() for g in gs]),
+                                  arr([self.state[p]["exp_avg"].data_ptr() for p in ps]),
+                                  arr([self.state[p]["exp_avg_sq"].data_ptr() for p in ps]), sizes, n, group["lr"], b1, b2,
+                                  group["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, step_ptr, ptr(grad_scale), stream()), "adam_multi")
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
         """grad_scale: optional 0-dim device tensor multiplied into every gradient (clip_grad_norm_ coefficient)."""
-        import ctypes as C
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        early_done = self._early_ran
+        if early_done and grad_scale is not None:
+            raise L.CvaeError("FusedAdam: grad_scale cannot be combined with overlap_backward (part of the update has already run)")
         for group in self.param_groups:
-            b1, b2 = group["betas"]
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
-                continue
-            L.require_gpu(*ps)
-            t = None
-            gs = []
-            for p in ps:
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise L.CvaeError("FusedAdam: contiguous float32 parameters expected")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
-                if t is None:
-                    t = st["step"]
-                elif t != st["step"]:
-                    raise L.CvaeError("FusedAdam: parameters of one group must share a step count")
-                gs.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
-            n = len(ps)
-            arr = lambda vals: (C.c_void_p * n)(*vals)
-            sizes = (C.c_int64 * n)(*[p.numel() for p in ps])
-            step_ptr = None
-            if self.device_step:
-                if self._step_dev is None:
-                    self._step_dev = torch.zeros((), dtype=torch.int32, device=ps[0].device)
-                check(lib.cvae_counter_add(ptr(self._step_dev), 1, stream()), "counter_add")
-                step_ptr = ptr(self._step_dev)
-            check(lib.cvae_adam_multi(arr([p.data_ptr() for p in ps]), arr([g.data_ptr() for g in gs]),
-                                      arr([self.state[p]["exp_avg"].data_ptr() for p in ps]),
-                                      arr([self.state[p]["exp_avg_sq"].data_ptr() for p in ps]), sizes, n, group["lr"], b1, b2,
-                                      group["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, step_ptr, ptr(grad_scale), stream()), "adam_multi")
+            ps = [p for p in group["params"] if p.grad is not None and not (early_done and id(p) in self._early_ids)]
+            if ps:
+                self._count_step(ps[0].device)
+                self._update(group, ps, grad_scale)
+        if early_done:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._counted, self._early_ran, self._early_left = False, False, len(self._early)
         return loss
 
 

@@ -408,3 +408,34 @@ def test_forward_elbo_equals_forward_plus_loss_function(cls, shape, dtype):
     for k in ga:
         if k != NOISE_KEY:
             grad_close(gb[k], ga[k].cpu(), k, l2=1e-3 if dtype == torch.float32 else 2e-2, linf=1e-2 if dtype == torch.float32 else 5e-2)
+
+
+def test_adam_overlapped_with_backward_gives_the_same_training():
+    """FusedAdam.overlap_backward: the non-encoder update runs on a side stream under the encoder backward; same losses and
+    parameters as the plain step (up to the atomic-order drift bounded in test_graphed_step_matches_eager_steps)."""
+    from causal_vae_amd.graph import GraphedTrainStep
+    g = torch.Generator().manual_seed(13)
+    x, m = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (2,), generator=g).to(DEV)
+    runs = []
+    for mode in ("plain", "overlap", "overlap-graph"):
+        torch.manual_seed(42)
+        model = CausalBioVAE3D().to(DEV).train()
+        opt = FusedAdam(model.parameters(), lr=1e-4, device_step=True)
+        if mode != "plain":
+            opt.overlap_backward(model.early_gradient_parameters())
+        if mode == "overlap-graph":
+            gs = GraphedTrainStep(model, opt, (x, m, t), None, warmup=3)
+            losses = [float(gs()[0]) for _ in range(3)]
+        else:
+            losses = [float(train_step(model, opt, x, m, t)[0]) for _ in range(6)][3:]
+        torch.cuda.synchronize()
+        runs.append((losses, [p.detach().clone() for p in model.parameters()], [int(opt.state[p]["step"]) for p in model.parameters()]))
+    for losses, params, steps in runs[1:]:
+        for a, b in zip(runs[0][0], losses):
+            assert rel(b, a) < 2e-4, (runs[0][0], losses)
+        for (k, _), p, q in zip(CausalBioVAE3D().named_parameters(), runs[0][1], params):
+            if k != NOISE_KEY:
+                dlt = (p - q).abs()
+                assert float(dlt.max()) <= 2 * 1e-4 * 6 + 1e-6 and float(dlt.mean()) <= 5e-5, k
+    assert len(set(runs[1][2])) == 1 and runs[1][2][0] == 6          # every parameter stepped exactly once per iteration
