@@ -38,6 +38,7 @@ struct TailGrads {
 struct TailSaved { float *h1, *h2, *mu, *logvar, *xhat, *invstd, *a1n, *a2, *m_hat, *zm; };
 struct MechFwdArgs { const float* t_onehot; float *running_mean, *running_var; long long* num_batches_tracked; float momentum, bn_eps; int bn_training; };
 struct MechBwdArgs { const float *dzm_part, *g_mhat, *t_onehot; };
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };       // float4 at dword alignment
 
 __device__ __forceinline__ int pool_lo(int o, int in, int out) { return (o * in) / out; }
 __device__ __forceinline__ int pool_hi(int o, int in, int out) { return ((o + 1) * in + out - 1) / out; }
@@ -96,17 +97,26 @@ __global__ __launch_bounds__(256) void skinny_fwd_partial_kernel(const float* __
     const float* wr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wr[r] = Wt + (size_t)min(n0 + r, N - 1) * K;
-#pragma unroll 4
-    for (int k = k0 + threadIdx.x; k < k1; k += 256) {
-        float xv[MT], wv[R];
+    // 16-byte loads at dword alignment (rows of odd length are not 16-byte aligned); the < 4-element tail of the slice goes scalar
+    const int kvec = k0 + ((k1 - k0) & ~3);
+#pragma unroll 2
+    for (int k = k0 + 4 * threadIdx.x; k < kvec; k += 1024) {
+        F4U xv[MT], wv[R];
 #pragma unroll
-        for (int mm = 0; mm < MT; ++mm) xv[mm] = mm < M ? x[(size_t)mm * K + k] : 0.f;
+        for (int mm = 0; mm < MT; ++mm) xv[mm] = mm < M ? *(const F4U*)(x + (size_t)mm * K + k) : F4U{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < R; ++r) wv[r] = wr[r][k];
+        for (int r = 0; r < R; ++r) wv[r] = *(const F4U*)(wr[r] + k);
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int mm = 0; mm < MT; ++mm) acc[r][mm] += wv[r] * xv[mm];
+            for (int mm = 0; mm < MT; ++mm) acc[r][mm] += wv[r].x * xv[mm].x + wv[r].y * xv[mm].y + wv[r].z * xv[mm].z + wv[r].w * xv[mm].w;
+    }
+    for (int k = kvec + threadIdx.x; k < k1; k += 256) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int mm = 0; mm < MT; ++mm)
+                if (mm < M) acc[r][mm] += wr[r][k] * x[(size_t)mm * K + k];
     }
     __shared__ float red[4][R * MT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -580,11 +590,16 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
         return;
     }
     __shared__ float gs[MT][64];
-    const int k = blockIdx.x * 256 + threadIdx.x, ns = blockIdx.y;
+    // thread owns columns k0 .. k0 + 3: 16-byte loads of W and stores of dW at 4-byte alignment (rows of odd length K are not
+    // 16-byte aligned; global_load/store_dwordx4 take dword-aligned addresses), a quarter of the memory instructions of the scalar form
+    const int k0 = (blockIdx.x * 256 + threadIdx.x) * 4, ns = blockIdx.y;
     const int n0 = ns * nslice, n1 = min(N, n0 + nslice);
-    float xv[MT], acc[MT];
+    const int nk = min(4, K - k0);                           // live columns of this thread (<= 0: none)
+    float xv[MT][4], acc[MT][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { xv[m] = (m < M && k < K) ? x[(size_t)m * K + k] : 0.f; acc[m] = 0.f; }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { xv[m][c] = (m < M && c < nk) ? x[(size_t)m * K + k0 + c] : 0.f; acc[m][c] = 0.f; }
     for (int nb = n0; nb < n1; nb += 64) {
         const int cnt = min(64, n1 - nb);
         __syncthreads();
@@ -593,22 +608,39 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
             gs[m][j] = (m < M && j < cnt) ? g[(size_t)m * N + nb + j] : 0.f;
         }
         __syncthreads();
-        if (k < K) {
-#pragma unroll 16
+        if (nk == 4) {
+#pragma unroll 8
             for (int j = 0; j < cnt; ++j) {
-                const float w = Wt[(size_t)(nb + j) * K + k];
-                float dw = 0.f;
+                const F4U w = *(const F4U*)(Wt + (size_t)(nb + j) * K + k0);
+                F4U dw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < MT; ++m) { dw += gs[m][j] * xv[m]; acc[m] += gs[m][j] * w; }
-                dW[(size_t)(nb + j) * K + k] = dw;
+                for (int m = 0; m < MT; ++m) {
+                    const float gv = gs[m][j];
+                    dw.x += gv * xv[m][0]; dw.y += gv * xv[m][1]; dw.z += gv * xv[m][2]; dw.w += gv * xv[m][3];
+                    acc[m][0] += gv * w.x; acc[m][1] += gv * w.y; acc[m][2] += gv * w.z; acc[m][3] += gv * w.w;
+                }
+                *(F4U*)(dW + (size_t)(nb + j) * K + k0) = dw;
             }
+        } else if (nk > 0) {                                 // the row tail (K % 4 columns)
+            for (int j = 0; j < cnt; ++j)
+                for (int c = 0; c < nk; ++c) {
+                    const float w = Wt[(size_t)(nb + j) * K + k0 + c];
+                    float dw = 0.f;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) { dw += gs[m][j] * xv[m][c]; acc[m][c] += gs[m][j] * w; }
+                    dW[(size_t)(nb + j) * K + k0 + c] = dw;
+                }
         }
     }
-    if (k < F) {
-        const int c = k / S, s = k - c * S, C = F / S;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            if (m < M) dxp[(((size_t)ns * M + m) * S + s) * C + c] = acc[m];
+    for (int c = 0; c < 4; ++c) {
+        const int k = k0 + c;
+        if (k < F) {
+            const int ch = k / S, sp = k - ch * S, C = F / S;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m < M) dxp[(((size_t)ns * M + m) * S + sp) * C + ch] = acc[m][c];
+        }
     }
 }
 
@@ -681,7 +713,7 @@ template <int MT>
 static void launch_bwd_colwise(const float* g, const float* x, const float* W1, float* dW, float* dxp, int M, int K, int N, int NS, int F, int S, const TailDims& d,
                                const TailParams& p, const TailGrads& tg, const TailSaved& sv, const MechBwdArgs& mb, hipStream_t st) {
     const int nslice = (N + NS - 1) / NS;
-    hipLaunchKernelGGL(skinny_bwd_colwise_kernel<MT>, dim3((unsigned)((K + 255) / 256), (unsigned)(NS + 1)), dim3(256), mech_bwd_lds(d), st, g, x, W1, dW, dxp, M, K, N,
+    hipLaunchKernelGGL(skinny_bwd_colwise_kernel<MT>, dim3((unsigned)((K + 1023) / 1024), (unsigned)(NS + 1)), dim3(256), mech_bwd_lds(d), st, g, x, W1, dW, dxp, M, K, N,
                        nslice, F, S, NS, d, p, tg, sv, mb);
 }
 
