@@ -191,7 +191,7 @@ def main():
                                    f"Adam lr {args.lr:g}, ELBO = MSE-sum + 2000*MSE-sum(m) + KLD", "global_batch": world * args.batch,
                        "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}",
                        "params": sum(p.numel() for p in model.parameters())},
-            "final_loss": final_loss, "loss_trajectory": traj[:4] + traj[-2:], "lr": args.lr, "hip_graph": use_graph, "side_stream_fork": args.fork,
+            "final_loss": final_loss, "loss_trajectory": traj if len(traj) <= 6 else traj[:4] + traj[-2:], "lr": args.lr, "hip_graph": use_graph, "side_stream_fork": args.fork,
         }
         if timer is not None:
             summ = timer.summary()
