@@ -87,6 +87,12 @@ SIGNATURES = {
     "cvae_up2x_fwd": [_p, _p] + [_i64] * 7 + [_i, _p],
     "cvae_elbo_up2x_fwd": [_p] * 6 + [_f, _p] + [_i64] * 9 + [_i, _p],
     "cvae_elbo_up2x_bwd": [_p] * 6 + [_f] + [_p] * 6 + [_i64] * 9 + [_i, _p],
+    "cvae_conv3_to_k4": [_p, _p, _i64, _i64, _p],
+    "cvae_k4_to_conv3_grad": [_p, _p, _i64, _i64, _p],
+    "cvae_clamp_fwd": [_p, _p, _f, _f, _i64, _p],
+    "cvae_clamp_bwd": [_p, _p, _p, _f, _f, _i64, _p],
+    "cvae_bn2d_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _i, _i, _i, _p],
+    "cvae_bn2d_bwd": [_p] * 9 + [_i64, _i64, _i, _i, _p],
     "cvae_bottleneck_sizes": [_p, _p, _p, _p, _p, _p],
     "cvae_bottleneck_fwd": [_p] * 9 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p],
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],

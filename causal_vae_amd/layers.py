@@ -96,6 +96,48 @@ class BatchNorm1d(nn.BatchNorm1d):
         return ops.bn1d_eval(x, self.weight, self.bias, self.running_mean, self.running_var, float(self.eps))
 
 
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d on channels-last tensors; `forward_cl(x_cl, act)` fuses the activation that follows it."""
+
+    def forward_cl(self, x_cl, act=None):
+        require_gpu(x_cl)
+        if self.training:
+            if x_cl.numel() // x_cl.shape[-1] <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x_cl.shape)}")
+            if self.momentum is None:
+                raise CvaeError("BatchNorm2d: cumulative-average momentum=None is not implemented")
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+        use_batch = self.training or not self.track_running_stats
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        return ops.BatchNorm2dAct.apply(x_cl, self.weight, self.bias, rm, rv, float(self.momentum or 0.0), float(self.eps), use_batch, act)
+
+    def forward(self, x):                                   # NCHW fp32 in / out, like the stock layer
+        require_gpu(x)
+        return ops.FromChannelsLast.apply(self.forward_cl(ops.ToChannelsLast.apply(x, torch.float32)), 2)
+
+
+class UpConv2dK3(nn.Conv2d):
+    """The nn.Conv2d(Cin, Cout, 3, 1, 1) of an `nn.Upsample(scale_factor=2, mode='nearest') -> Conv2d` pair.  `forward_up2_cl` runs the
+    PAIR (nearest x2, then the conv) as one transposed k4/s2/p1 product on the existing kernels (ops.Conv3ToK4)."""
+    compute_dtype = torch.float32
+
+    def __init__(self, *a, **k):
+        nn.Conv2d.__init__(self, *a, **k)
+        if (tuple(self.kernel_size), tuple(self.stride), tuple(self.padding), tuple(self.dilation), self.groups) != ((3, 3), (1, 1), (1, 1), (1, 1), 1) \
+                or self.padding_mode != "zeros":
+            raise CvaeError("UpConv2dK3: kernel 3 / stride 1 / padding 1 only")
+
+    def forward_up2_cl(self, x_cl, act=None):
+        k4 = ops.Conv3ToK4.apply(self.weight)
+        return ops.ConvUp.apply(x_cl, k4, self.bias, 2, act, False, False, None)
+
+    def forward(self, x):
+        raise CvaeError("UpConv2dK3 is the conv of an Upsample(x2, nearest) + Conv2d(k3) pair: call the enclosing decoder stack "
+                        "(a bare 3x3 convolution has no gfx950 kernel here)")
+
+
 _ACT_NAME = {nn.ReLU: "relu", nn.Sigmoid: "sigmoid"}
 
 
@@ -201,11 +243,58 @@ class MLP(nn.Sequential):
         return x
 
 
+class BNConvStack(nn.Sequential):
+    """Encoder of CausalVesselVAE: [Conv2d(k4,s2,p1), BatchNorm2d, LeakyReLU(0.2)]* + Flatten.  forward(x NCHW fp32) -> [B, F] fp32."""
+    compute_dtype = torch.float32
+
+    def forward(self, x):
+        require_gpu(x)
+        mods = list(self)
+        h = ops.ToChannelsLast.apply(x, self.compute_dtype)
+        i = 0
+        while i < len(mods) and isinstance(mods[i], _ConvBase):
+            conv, bn = mods[i], mods[i + 1]
+            if not isinstance(bn, BatchNorm2d) or _act_of(mods[i + 2]) is None:
+                raise CvaeError("BNConvStack: Conv2d, BatchNorm2d, activation triples expected")
+            h = bn.forward_cl(conv.forward_cl(h, act=None), act=_act_of(mods[i + 2]))
+            i += 3
+        if i != len(mods) - 1 or not isinstance(mods[i], nn.Flatten):
+            raise CvaeError("BNConvStack: trailing Flatten expected")
+        return ops.FromChannelsLast.apply(h, 2).flatten(1)
+
+
+class UpConvStack(nn.Sequential):
+    """Decoder of CausalVesselVAE: [Upsample(x2, nearest), Conv2d(k3,s1,p1), BatchNorm2d, ReLU]* + Upsample, Conv2d(k3), Sigmoid.
+    forward(h NCHW fp32) -> NCHW fp32; every Upsample + Conv2d pair runs as one transposed-conv product."""
+    compute_dtype = torch.float32
+
+    def forward_cl(self, h):
+        mods = list(self)
+        x = ops.ToChannelsLast.apply(h, self.compute_dtype)
+        i = 0
+        while i < len(mods):
+            up, conv = mods[i], mods[i + 1]
+            if not isinstance(up, nn.Upsample) or up.mode != "nearest" or float(up.scale_factor) != 2.0 or not isinstance(conv, UpConv2dK3):
+                raise CvaeError("UpConvStack: Upsample(scale_factor=2, mode='nearest') + Conv2d(k3) pairs expected")
+            if i + 2 < len(mods) and isinstance(mods[i + 2], BatchNorm2d):
+                x = mods[i + 2].forward_cl(conv.forward_up2_cl(x, act=None), act=_act_of(mods[i + 3]))
+                i += 4
+            else:
+                act = _act_of(mods[i + 2]) if i + 2 < len(mods) else None
+                x = conv.forward_up2_cl(x, act=act)
+                i += 3 if act else 2
+        return x
+
+    def forward(self, h):
+        require_gpu(h)
+        return ops.FromChannelsLast.apply(self.forward_cl(h), 2)
+
+
 def set_compute_dtype(module, dtype):
     """bf16 or fp32 conv arithmetic (weights stay fp32 masters; linears, losses and BN always fp32)."""
     if dtype not in (torch.float32, torch.bfloat16):
         raise CvaeError(f"compute dtype must be float32 or bfloat16, got {dtype}")
     for m in module.modules():
-        if isinstance(m, (_ConvBase, ConvStack, DeconvStack)):
+        if isinstance(m, (_ConvBase, ConvStack, DeconvStack, BNConvStack, UpConvStack, UpConv2dK3)):
             m.compute_dtype = dtype
     return module

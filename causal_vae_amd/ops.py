@@ -882,3 +882,88 @@ class BioBottleneck(torch.autograd.Function):
                                       ptr(t_onehot), ptr(eps), ptr(xcat), ptr(y_cl), 1, ptr(dzm_part), ptr(g1), ptr(dx_part), ptr(dy_cl),
                                       L.dtype_code(y_cl.dtype), stream()), "bottleneck_bwd")
         return (dy_cl, None, None, None, *grads, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------ CausalVesselVAE extras
+class BatchNorm2dAct(torch.autograd.Function):
+    """nn.BatchNorm2d (+ the activation that follows it) on a channels-last tensor [B, D, H, W, C] (csrc/vessel2d.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, act):
+        L.require_gpu(x, weight, bias)
+        x = x.contiguous()
+        Cc = x.shape[-1]
+        P = x.numel() // Cc
+        y = torch.empty_like(x)
+        if training:
+            mean, rstd = _empty((Cc,), torch.float32, x), _empty((Cc,), torch.float32, x)
+        else:
+            mean, rstd = running_mean.float().clone(), torch.rsqrt(running_var.float() + eps)
+        check(lib.cvae_bn2d_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean) if training else None,
+                                ptr(running_var) if training else None, P, Cc, float(momentum), float(eps), 1 if training else 0, L.act_code(act),
+                                L.dtype_code(x.dtype), stream()), "bn2d_fwd")
+        ctx.save_for_backward(x, y, weight, mean, rstd)
+        ctx.cfg = (training, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        training, act = ctx.cfg
+        if not training:
+            raise L.CvaeError("BatchNorm2d in eval mode is forward-only here (the reference consumers run it under no_grad)")
+        Cc = x.shape[-1]
+        P = x.numel() // Cc
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        dw, db = _empty((Cc,), torch.float32, x), _empty((Cc,), torch.float32, x)
+        check(lib.cvae_bn2d_bwd(ptr(x), ptr(g), ptr(y), ptr(weight), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), P, Cc, L.act_code(act),
+                                L.dtype_code(x.dtype), stream()), "bn2d_bwd")
+        return dx, dw, db, None, None, None, None, None, None
+
+
+class Clamp(torch.autograd.Function):
+    """torch.clamp(x, min, max) with its pass-through gradient mask (vessel_analysis/00_core/models.py:148-149,156)."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        L.require_gpu(x)
+        x = x.contiguous().float()
+        y = torch.empty_like(x)
+        check(lib.cvae_clamp_fwd(ptr(x), ptr(y), float(lo), float(hi), x.numel(), stream()), "clamp_fwd")
+        ctx.save_for_backward(x)
+        ctx.lim = (float(lo), float(hi))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.cvae_clamp_bwd(ptr(x), ptr(g), ptr(dx), ctx.lim[0], ctx.lim[1], x.numel(), stream()), "clamp_bwd")
+        return dx, None, None
+
+
+class Conv3ToK4(torch.autograd.Function):
+    """Weight of nn.Conv2d(Cin, Cout, 3, 1, 1) applied after a nearest x2 upsample -> the equivalent transposed k4/s2/p1 weight
+    [Cin][Cout][4][4] for ConvUp (K4 = A W3 A^T, csrc/vessel2d.hip); the backward maps dK4 to dW3."""
+
+    @staticmethod
+    def forward(ctx, w3):
+        L.require_gpu(w3)
+        w3 = w3.contiguous()
+        Cout, Cin = w3.shape[0], w3.shape[1]
+        if tuple(w3.shape[2:]) != (3, 3):
+            raise L.CvaeError("Conv3ToK4: a [Cout, Cin, 3, 3] weight expected")
+        k4 = torch.empty(Cin, Cout, 4, 4, dtype=torch.float32, device=w3.device)
+        check(lib.cvae_conv3_to_k4(ptr(w3), ptr(k4), Cout, Cin, stream()), "conv3_to_k4")
+        ctx.shape = (Cout, Cin)
+        return k4
+
+    @staticmethod
+    def backward(ctx, g):
+        Cout, Cin = ctx.shape
+        g = g.contiguous()
+        dw3 = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=g.device)
+        check(lib.cvae_k4_to_conv3_grad(ptr(g), ptr(dw3), Cout, Cin, stream()), "k4_to_conv3_grad")
+        return dw3

@@ -16,3 +16,36 @@ def loss_function(recon_x, x, m_hat, m, mu, logvar, m_mu, m_logvar):
 
 def total_loss(recon, kld, morph, sparsity, beta=0.5, lambda_morph=1.0):
     return recon + beta * kld + lambda_morph * morph + 0.3 * sparsity
+
+
+def train_step(vae, opt_vae, x, m, t, eps=None, beta=0.5, lambda_morph=1.0, max_norm=5.0):
+    """One iteration of train_one_epoch's body (vessel_analysis/01_train/train.py:70-86): zero_grad -> 6-tuple forward -> vessel loss ->
+    backward -> clip_grad_norm_(5.0) -> step.  With a FusedAdam the clip coefficient stays on the device (no host sync) and is applied
+    inside the update; any other optimizer gets torch's in-place clip.  Returns (loss, recon, kld, morph) as 0-dim device tensors."""
+    from ..optim import FusedAdam, clip_grad_norm_
+    opt_vae.zero_grad(set_to_none=True)
+    out = vae(x, m, t) if eps is None else vae(x, m, t, eps=eps)
+    recon, kld, morph, sparsity = loss_function(out[0], x, out[1], m, out[2], out[3], out[4], out[5])
+    loss = total_loss(recon, kld, morph, sparsity, beta=beta, lambda_morph=lambda_morph)
+    loss.backward()
+    params = [p for p in vae.parameters() if p.grad is not None]
+    if isinstance(opt_vae, FusedAdam):
+        clip_grad_norm_(params, max_norm)
+        opt_vae.step()
+    else:
+        import torch
+        torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+        opt_vae.step()
+    return loss.detach(), recon.detach(), kld.detach(), morph.detach()
+
+
+def train_one_epoch(epoch, vae, train_loader, opt_vae, device="cuda", beta=0.5):
+    """train_one_epoch(epoch, vae, train_loader, opt_vae) of the reference (:62-98): returns sum of batch losses / len(dataset); the
+    per-batch `.item()` syncs are replaced by on-device accumulation."""
+    vae.train()
+    total = None
+    for x, m, t in train_loader:
+        x, m, t = x.to(device, non_blocking=True), m.to(device, non_blocking=True), t.to(device, non_blocking=True)
+        loss = train_step(vae, opt_vae, x, m, t, beta=beta)[0]
+        total = loss if total is None else total + loss
+    return float(total.item()) / len(train_loader.dataset)

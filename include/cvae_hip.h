@@ -118,6 +118,24 @@ int cvae_elbo_up2x_bwd(const void* src, const float* x, const float* m_hat, cons
                        const float* g_loss, float* t1, void* dsrc, float* d_mhat, float* dmu, float* dlv, int64_t B, int64_t d, int64_t h, int64_t w,
                        int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z, int dtype, void* stream);
 
+/* ---- CausalVesselVAE extras (vessel_analysis/00_core/models.py:9-166): BatchNorm2d, clamp, Upsample(nearest x2) + Conv2d(k3, s1, p1) ----
+ * nn.Upsample(scale_factor=2, 'nearest') followed by nn.Conv2d(Cin, Cout, 3, 1, 1) equals the transposed k4/s2/p1 product of
+ * cvae_conv_up with K4[cin][cout] = A W3[cout][cin] A^T, A = [[0,0,1],[0,1,1],[1,1,0],[1,0,0]] (csrc/vessel2d.hip): the layer runs on
+ * cvae_conv_up / cvae_conv_down / cvae_conv_wgrad with the transformed weight; its gradient maps back with A^T . A. */
+int cvae_conv3_to_k4(const float* w3 /* [Cout][Cin][3][3] */, float* k4 /* [Cin][Cout][4][4] */, int64_t Cout, int64_t Cin, void* stream);
+int cvae_k4_to_conv3_grad(const float* dk4, float* dw3, int64_t Cout, int64_t Cin, void* stream);
+/* torch.clamp(x, lo, hi) and its backward (the gradient passes where lo <= x <= hi); fp32 */
+int cvae_clamp_fwd(const float* x, float* y, float lo, float hi, int64_t n, void* stream);
+int cvae_clamp_bwd(const float* x, const float* g, float* dx, float lo, float hi, int64_t n, void* stream);
+/* nn.BatchNorm2d (+ fused activation `act`) on a channels-last tensor [P = B*H*W][C] (C % 8 == 0).  training: two-pass batch
+ * statistics (mean, then sum of squared deviations) into mean / rstd, running_* updated with the unbiased variance (may be NULL);
+ * otherwise mean / rstd are inputs (running mean, 1/sqrt(running_var + eps)).  y = act((x - mean) rstd gamma + beta). */
+int cvae_bn2d_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean, float* running_var,
+                  int64_t P, int64_t C, float momentum, float eps, int training, int act, int dtype, void* stream);
+/* training-mode backward through the activation and the normalisation: dx, dgamma, dbeta (y = the forward's output, for act') */
+int cvae_bn2d_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                  float* dbeta, int64_t P, int64_t C, int act, int dtype, void* stream);
+
 /* ---- The dense bottleneck of CausalBioVAE in 5 + 5 launches (batch M <= 16, fp32 arithmetic) --------------------------------
  * Replaces, between the last encoder conv and the first decoder conv (causal_cascade/models.py:57-79):
  *   AdaptiveAvgPool + Flatten, cat([x_feat, m, t]), enc_fc (Linear-ReLU-Linear-ReLU), fc_mu, fc_logvar, reparameterize,

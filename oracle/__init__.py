@@ -21,7 +21,7 @@ goldens plus the slice-degeneracy test (3D with a single depth tap == 2D).
 from .params import init_state_dict, MODEL_KINDS  # noqa: F401
 from .functional import (  # noqa: F401
     bio_vae_forward, morph_vae_forward, morph_vae6_forward, discriminator_forward,
-    reparameterize, cascade_loss, vessel_loss, mnist_vae_losses, gaussian_nll, bio_decode, morph_decode,
+    reparameterize, cascade_loss, vessel_loss, mnist_vae_losses, gaussian_nll, bio_decode, morph_decode, vessel_vae_forward,
 )
 from .steps import (  # noqa: F401
     adam_init, adam_update, cascade_train_step, mnist_adversarial_step, clip_grad_norm,

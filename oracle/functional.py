@@ -145,6 +145,49 @@ def morph_vae6_forward(sd, x, m, t, eps):
     return dict(recon_x=recon_x, m_hat=m_mu, mu=mu, logvar=logvar, z=z, m_mu=m_mu, m_logvar=m_logvar)
 
 
+def _bn_train(sd, prefix, x, training, update_running=True, momentum=0.1, bn_eps=1e-5):
+    """nn.BatchNorm1d / nn.BatchNorm2d through the aten kernel the reference's modules call (batch statistics in training mode,
+    running statistics updated in place unless told otherwise)."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if training and update_running:
+        with torch.no_grad():
+            sd[prefix + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, rm, rv, w, b, True, momentum, bn_eps)
+    if training:
+        return F.batch_norm(x, None, None, w, b, True, momentum, bn_eps)
+    return F.batch_norm(x, rm, rv, w, b, False, momentum, bn_eps)
+
+
+def vessel_vae_forward(sd, x, m, t, eps, *, training=True, update_running=True):
+    """CausalVesselVAE.forward (vessel_analysis/00_core/models.py:142-166): t is the one-hot [B, 19] float the vessel dataset
+    yields (dataset.py), the decoder sees the real m (:161), logvar / mu / m_logvar are clamped (:148-149, :156)."""
+    h = x
+    for i in range(7):                                                    # :32-40
+        h = F.conv2d(h, sd[f"enc_conv.{3*i}.weight"], sd[f"enc_conv.{3*i}.bias"], stride=2, padding=1)
+        h = F.leaky_relu(_bn_train(sd, f"enc_conv.{3*i+1}", h, training, update_running), 0.2)
+    h = torch.cat([h.flatten(1), m, t], dim=1)                            # :144-145
+    h = F.leaky_relu(_bn_train(sd, "enc_fc.1", _lin(sd, "enc_fc.0", h), training, update_running), 0.2)
+    mu, logvar = _lin(sd, "enc_fc.3", h).chunk(2, dim=1)                  # :146
+    logvar = torch.clamp(logvar, min=-10, max=10)                         # :148
+    mu = torch.clamp(mu, min=-100, max=100)                               # :149
+    z = reparameterize(mu, logvar, eps)
+    g = F.leaky_relu(_lin(sd, "morph_predictor_shared.0", t), 0.2)        # :153
+    g = F.leaky_relu(_lin(sd, "morph_predictor_shared.2", g), 0.2)
+    m_mu = _lin(sd, "morph_predictor_mu", g)
+    m_logvar = torch.clamp(_lin(sd, "morph_predictor_logvar", g), min=-10, max=10)      # :156
+    d = _lin(sd, "dec_fc.0", torch.cat([m, z], dim=1))                    # :161-162
+    d = F.leaky_relu(_bn_train(sd, "dec_fc.1", d, training, update_running), 0.2)
+    d = F.relu(_lin(sd, "dec_fc.3", d)).view(-1, 512, 6, 10)              # :163
+    for i in range(6):                                                    # :108-131
+        d = F.interpolate(d, scale_factor=2, mode="nearest")
+        d = F.conv2d(d, sd[f"dec_conv.{4*i+1}.weight"], sd[f"dec_conv.{4*i+1}.bias"], stride=1, padding=1)
+        d = F.relu(_bn_train(sd, f"dec_conv.{4*i+2}", d, training, update_running))
+    d = F.interpolate(d, scale_factor=2, mode="nearest")
+    recon_x = torch.sigmoid(F.conv2d(d, sd["dec_conv.25.weight"], sd["dec_conv.25.bias"], stride=1, padding=1))     # :133
+    return dict(recon_x=recon_x, m_hat=m_mu, mu=mu, logvar=logvar, z=z, m_mu=m_mu, m_logvar=m_logvar)
+
+
 def discriminator_forward(sd, z):
     """LatentDiscriminator.forward (mnist_test/01_baseline_causal_vae/models.py:102-111)."""
     h = F.leaky_relu(_lin(sd, "net.0", z), 0.2)

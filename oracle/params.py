@@ -15,13 +15,14 @@ Construction orders followed:
   morph12       : mnist_test/01_baseline_causal_vae/models.py:19-48
   morph12g      : mnist_test/06_model_experiment/models.py:19-50 (Gaussian head)
   disc          : mnist_test/01_baseline_causal_vae/models.py:102-108
+  vessel2d      : vessel_analysis/00_core/models.py:32-134 (incl. the dead first dec_conv :70-105, whose draws advance the RNG)
 """
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 
-MODEL_KINDS = ("bio2d", "bio3d", "morph12", "morph12g", "disc")
+MODEL_KINDS = ("bio2d", "bio3d", "morph12", "morph12g", "disc", "vessel2d")
 
 
 def _file(sd, prefix, layer):
@@ -72,6 +73,35 @@ def _morph12(m_dim, t_dim, z_dim, gaussian_head):
     return sd
 
 
+def _vessel2d(m_dim, t_dim, z_dim):
+    sd = OrderedDict()
+    cin = 1
+    for i, cout in enumerate((32, 64, 128, 256, 512, 512, 512)):          # models.py:32-40
+        _file(sd, f"enc_conv.{3 * i}", nn.Conv2d(cin, cout, 4, 2, 1))
+        _file(sd, f"enc_conv.{3 * i + 1}", nn.BatchNorm2d(cout))
+        cin = cout
+    flat = 512 * 6 * 10
+    _file(sd, "enc_fc.0", nn.Linear(flat + m_dim + t_dim, 1024))          # :46-50
+    _file(sd, "enc_fc.1", nn.BatchNorm1d(1024))
+    _file(sd, "enc_fc.3", nn.Linear(1024, 2 * z_dim))
+    _file(sd, "morph_predictor_shared.0", nn.Linear(t_dim, 64))           # :54-61
+    _file(sd, "morph_predictor_shared.2", nn.Linear(64, 64))
+    _file(sd, "morph_predictor_mu", nn.Linear(64, m_dim))
+    _file(sd, "morph_predictor_logvar", nn.Linear(64, m_dim))
+    _file(sd, "dec_fc.0", nn.Linear(m_dim + z_dim, 1024))                 # :64-69
+    _file(sd, "dec_fc.1", nn.BatchNorm1d(1024))
+    _file(sd, "dec_fc.3", nn.Linear(1024, flat))
+    for ci, co in ((512, 512),) * 4 + ((512, 256), (256, 128), (128, 64), (64, 32), (32, 1)):   # the dead decoder :70-105 (RNG only)
+        nn.ConvTranspose2d(ci, co, 4, 2, 1)
+    cin = 512
+    for i, cout in enumerate((512, 512, 256, 128, 64, 32)):               # :108-131
+        _file(sd, f"dec_conv.{4 * i + 1}", nn.Conv2d(cin, cout, 3, 1, 1))
+        _file(sd, f"dec_conv.{4 * i + 2}", nn.BatchNorm2d(cout))
+        cin = cout
+    _file(sd, "dec_conv.25", nn.Conv2d(32, 1, 3, 1, 1))                   # :133
+    return sd
+
+
 def _disc(z_dim, t_dim):
     sd = OrderedDict()
     _file(sd, "net.0", nn.Linear(z_dim, 64))
@@ -96,4 +126,6 @@ def init_state_dict(kind, seed=None, *, img_channels=1, m_dim=12, t_dim=None,
         return _morph12(m_dim, 10 if t_dim is None else t_dim, z_dim, kind == "morph12g")
     if kind == "disc":
         return _disc(z_dim, 10 if t_dim is None else t_dim)
+    if kind == "vessel2d":
+        return _vessel2d(m_dim, 19 if t_dim is None else t_dim, 128)
     raise ValueError(f"unknown model kind {kind!r}; expected one of {MODEL_KINDS}")

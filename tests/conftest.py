@@ -72,3 +72,15 @@ def golden():
             cache[name] = Golden(name)
         return cache[name]
     return load
+
+
+def vessel2d_inputs(B, seed):
+    """The synthetic vessel batch of tools/make_golden.py:vessel2d_inputs (binary sparse 768 x 1280 image, standardised m, one-hot t,
+    injected eps), regenerated from its seed instead of being stored (7.8 MB of image)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(B, 1, 768, 1280, generator=g) < 0.08).float()
+    m = torch.randn(B, 12, generator=g)
+    t = F.one_hot(torch.randint(0, 19, (B,), generator=g), 19).float()
+    eps = torch.randn(B, 128, generator=g)
+    return x, m, t, eps

@@ -4,6 +4,9 @@ gradients, 1e-4 relative on the ELBO (the BASELINE target); the bf16 path states
 """
 import copy
 import io
+import math
+
+import numpy as np
 
 import pytest
 import torch
@@ -439,3 +442,85 @@ def test_adam_overlapped_with_backward_gives_the_same_training():
                 dlt = (p - q).abs()
                 assert float(dlt.max()) <= 2 * 1e-4 * 6 + 1e-6 and float(dlt.mean()) <= 5e-5, k
     assert len(set(runs[1][2])) == 1 and runs[1][2][0] == 6          # every parameter stepped exactly once per iteration
+
+
+def test_vessel2d_matches_reference_golden(golden):
+    """CausalVesselVAE (fp32 MFMA path) at the reference's 768 x 1280 resolution vs tensors produced by the reference class itself:
+    init, 6-tuple forward, the vessel loss, every gradient, the BatchNorm buffers (tools/make_golden.py:vessel2d_case)."""
+    from conftest import vessel2d_inputs
+    from causal_vae_amd.vessel import CausalVesselVAE, loss_function as vessel_loss, total_loss
+    g = golden("vessel2d_b4")
+    torch.manual_seed(42)
+    model = CausalVesselVAE().to(DEV).train()
+    for k, v in model.state_dict().items():
+        g.check("sd0", k, v, rtol=0, atol=0)
+    B, seed = (int(v) for v in g.t("in/seed"))
+    x, m, t, eps = (v.to(DEV) for v in vessel2d_inputs(B, seed))
+    out = model(x, m, t, eps=eps)
+    assert len(out) == 6
+    names = ("recon_x", "m_hat", "mu", "logvar", "m_mu", "m_logvar")
+    for k, v in zip(names, out):
+        g.check("fwd", k, v, rtol=1e-3, atol=2e-4)
+    recon, kld, morph, sparsity = vessel_loss(out[0], x, out[1], m, out[2], out[3], out[4], out[5])
+    total = total_loss(recon, kld, morph, sparsity, beta=0.5, lambda_morph=1.0)
+    for k, v in dict(recon=recon, kld=kld, morph=morph, sparsity=sparsity, total=total).items():
+        assert rel(v, g.t("fwd/" + k)) < 1e-4, (k, float(v), float(g.t("fwd/" + k)))
+    total.backward()
+    noise = {f"enc_conv.{3 * i}.bias" for i in range(7)} | {f"dec_conv.{4 * i + 1}.bias" for i in range(6)} | {"enc_fc.0.bias", "dec_fc.0.bias"}
+    for k, p in model.named_parameters():
+        d = g.z["grad/" + k + "#digest"]
+        f = p.grad.detach().double().flatten().cpu()
+        ref_l2 = math.sqrt(d[2])
+        if k in noise:              # a bias in front of a train-mode BatchNorm: exactly zero gradient in real arithmetic, rounding noise in both
+            assert float(f.abs().max()) < 1e-5 * 4e6, k
+            continue
+        got_l2 = float(f.norm())
+        assert abs(got_l2 - ref_l2) <= 2e-3 * ref_l2, (k, got_l2, ref_l2)
+        assert abs(float(f.sum()) - d[0]) <= 5e-3 * d[1] + 1e-6, (k, "sum", float(f.sum()), d[0])
+        np_head = f[:8].numpy()
+        # single entries of a BatchNorm-chain gradient are sums with heavy cancellation (run-to-run +-0.3 % with atomic partial sums)
+        assert np.allclose(np_head, d[3:3 + len(np_head)], rtol=5e-2, atol=1e-2 * float(f.abs().max())), (k, np_head, d[3:11])
+    for k in g.keys("sd1"):
+        g.check("sd1", k, model.state_dict()[k], rtol=1e-3, atol=1e-5)
+
+
+def test_vessel2d_bf16_step_tracks_fp32():
+    """bf16 conv arithmetic on the 2D vessel model: loss within 1e-2 of the fp32 path on the same batch, finite gradients."""
+    from conftest import vessel2d_inputs
+    from causal_vae_amd.vessel import CausalVesselVAE, loss_function as vessel_loss, total_loss
+    x, m, t, eps = (v.to(DEV) for v in vessel2d_inputs(2, 99))
+    tot = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        torch.manual_seed(42)
+        model = CausalVesselVAE().to(DEV).train().set_compute_dtype(dtype)
+        out = model(x, m, t, eps=eps)
+        total = total_loss(*vessel_loss(out[0], x, out[1], m, out[2], out[3], out[4], out[5]))
+        total.backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        tot[dtype] = float(total)
+    assert abs(tot[torch.bfloat16] - tot[torch.float32]) <= 1e-2 * abs(tot[torch.float32]), tot
+
+
+def test_vessel2d_train_step_clip_and_adam_follow_torch():
+    """The vessel recipe's step (forward, vessel loss, backward, clip_grad_norm_ 5.0, Adam 1e-4) with FusedAdam == the same model stepped
+    with torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on its (HIP-computed) gradients: losses and updated weights over 2 steps."""
+    from conftest import vessel2d_inputs
+    from causal_vae_amd.vessel import CausalVesselVAE, train_step as vessel_step
+    x, m, t, eps = (v.to(DEV) for v in vessel2d_inputs(4, 7))
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(42)
+        model = CausalVesselVAE().to(DEV).train()
+        opt = FusedAdam(model.parameters(), lr=1e-4) if fused else torch.optim.Adam(model.parameters(), lr=1e-4)
+        losses = [float(vessel_step(model, opt, x, m, t, eps=eps)[0]) for _ in range(2)]
+        res.append((losses, {k: p.detach().clone() for k, p in model.named_parameters()}))
+    (la, pa), (lb, pb) = res
+    for a, b in zip(la, lb):
+        assert rel(a, b) < 1e-5, (la, lb)
+    noise = {f"enc_conv.{3 * i}.bias" for i in range(7)} | {f"dec_conv.{4 * i + 1}.bias" for i in range(6)} | {"enc_fc.0.bias", "dec_fc.0.bias"}
+    for k in pa:
+        p, q = pa[k], pb[k]
+        assert float((p - q).abs().max()) <= 2 * 1e-4 * 2 + 1e-7          # Adam: +-lr per step where a clipped gradient is ~0
+        if k in noise:                                                     # zero-gradient biases in front of a BatchNorm: Adam steps on rounding noise
+            continue
+        assert float((p - q).abs().mean()) <= 1e-5                          # 5 % of one Adam step: run-to-run noise of the BatchNorm-chain gradients

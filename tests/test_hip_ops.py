@@ -411,3 +411,75 @@ def test_gradient_bucket_pack_unpack_roundtrip():
     red.unpack()
     for p, r in zip(ps, ref):
         assert torch.equal(p.grad, 2.0 * r)
+
+
+# --------------------------------------------------------------------------------------------- CausalVesselVAE extras
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,C,H,W,act", [(2, 32, 12, 20, "leaky02"), (3, 512, 6, 10, "relu"), (2, 64, 33, 17, None), (1, 128, 48, 80, "leaky02")])
+def test_batchnorm2d_train_forward_backward_and_running_stats(B, C, H, W, act, dtype):
+    """nn.BatchNorm2d (batch statistics) + the activation after it, on channels-last tensors: y, dx, dgamma, dbeta, running stats."""
+    from causal_vae_amd import layers as hl
+    g = torch.Generator().manual_seed(21)
+    x = rnd(torch.randn(B, C, H, W, generator=g) * 1.7 + 0.4, dtype).requires_grad_(True)
+    ref = torch.nn.BatchNorm2d(C).train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(C, generator=g) + 0.5); ref.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    fact = {"leaky02": lambda v: F.leaky_relu(v, 0.2), "relu": F.relu, None: lambda v: v}[act]
+    y_ref = fact(ref(x))
+    gy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, ref.weight, ref.bias], gy)
+    bn = hl.BatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(ref.weight); bn.bias.copy_(ref.bias)
+    xg = to_cl(x.detach(), dtype).requires_grad_(True)
+    y = bn.forward_cl(xg, act=act)
+    close(from_cl(y, 2), y_ref.detach(), dtype, "y")
+    y.backward(to_cl(gy, dtype))
+    close(from_cl(xg.grad, 2), gx_ref, dtype, "dx", scale=float(gx_ref.abs().max()) * (1 if dtype == torch.float32 else 4))
+    close(bn.weight.grad.cpu(), gw_ref, torch.float32, "dgamma", scale=float(gw_ref.abs().max()) * (1 if dtype == torch.float32 else 30))
+    close(bn.bias.grad.cpu(), gb_ref, torch.float32, "dbeta", scale=float(gb_ref.abs().max()) * (1 if dtype == torch.float32 else 30))
+    torch.testing.assert_close(bn.running_mean.cpu(), ref.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn.running_var.cpu(), ref.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+    bn.eval(); ref.eval()
+    with torch.no_grad():
+        close(from_cl(bn.forward_cl(xg.detach(), act=act), 2), fact(ref(x.detach())), dtype, "eval y")
+
+
+def test_clamp_forward_and_gradient_mask():
+    g = torch.Generator().manual_seed(22)
+    x = (torch.randn(5, 128, generator=g) * 8).requires_grad_(True)
+    y_ref = torch.clamp(x, min=-10, max=10)
+    gy = torch.randn(5, 128, generator=g)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = ops.Clamp.apply(xg, -10.0, 10.0)
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=0, atol=0)
+    y.backward(gy.to(DEV))
+    torch.testing.assert_close(xg.grad.cpu(), gx_ref, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,size", [(2, 64, 32, (12, 20)), (1, 512, 512, (6, 10)), (2, 32, 1, (24, 40)), (3, 128, 64, (7, 9))])
+def test_upsample_nearest_conv3_runs_as_transposed_conv(B, Cin, Cout, size, dtype):
+    """nn.Upsample(x2, nearest) + nn.Conv2d(k3, s1, p1) == conv_up with K4 = A W3 A^T: y, dx, dW3, db."""
+    from causal_vae_amd import layers as hl
+    g = torch.Generator().manual_seed(23)
+    x = rnd(torch.randn(B, Cin, *size, generator=g), dtype).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    y_ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, stride=1, padding=1)
+    gy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, w, b], gy)
+    conv = hl.UpConv2dK3(Cin, Cout, 3, 1, 1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w); conv.bias.copy_(b)
+    xg = to_cl(x.detach(), dtype).requires_grad_(True)
+    y = conv.forward_up2_cl(xg, act=None)
+    # bf16: the kernel rounds K4 (sums of up to four W3 taps) to bf16, the reference applies unrounded fp32 weights
+    scale = float(y_ref.abs().max()) * (1 if dtype == torch.float32 else 3)
+    close(from_cl(y, 2), y_ref.detach(), dtype, "y", scale=scale)
+    y.backward(to_cl(gy, dtype))
+    close(from_cl(xg.grad, 2), gx_ref, dtype, "dx", scale=float(gx_ref.abs().max()) * (1 if dtype == torch.float32 else 3))
+    close(conv.weight.grad.cpu(), gw_ref, torch.float32, "dW3", scale=float(gw_ref.abs().max()) * (1 if dtype == torch.float32 else 30))
+    close(conv.bias.grad.cpu(), gb_ref, torch.float32, "db", scale=float(gb_ref.abs().max()) * 3)

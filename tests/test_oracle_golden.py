@@ -112,6 +112,39 @@ def test_vessel_loss_matches_reference(golden, tag):
         g.check(tag, "g_" + k, a[k].grad, rtol=1e-5, atol=1e-6)
 
 
+def test_vessel2d_matches_reference(golden):
+    """CausalVesselVAE (vessel_analysis/00_core/models.py:9-166): init, forward, the vessel loss and every gradient of the oracle's
+    restatement against the reference class run on the same batch (B = 2, 768 x 1280; tools/make_golden.py:vessel2d_case)."""
+    from conftest import vessel2d_inputs
+    g = golden("vessel2d_b4")
+    sd = oracle.init_state_dict("vessel2d", seed=42)
+    assert sorted(sd) == g.keys("sd0")
+    for k, v in sd.items():
+        g.check("sd0", k, v, rtol=0, atol=0)
+    B, seed = (int(v) for v in g.t("in/seed"))
+    x, m, t, eps = vessel2d_inputs(B, seed)
+    g.check("in", "x", x, rtol=0, atol=0)
+    torch.testing.assert_close(m, g.t("in/m"), rtol=0, atol=0)
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    out = ofn.vessel_vae_forward(leaves, x, m, t, eps)
+    for k in ("recon_x", "m_hat", "mu", "logvar", "m_mu", "m_logvar"):
+        g.check("fwd", k, out[k], rtol=2e-5, atol=2e-6)
+    recon, kld, morph, sparsity = ofn.vessel_loss(out["recon_x"], x, out["m_hat"], m, out["mu"], out["logvar"], out["m_mu"], out["m_logvar"])
+    total = recon + 0.5 * kld + morph + 0.3 * sparsity
+    for k, v in dict(recon=recon, kld=kld, morph=morph, sparsity=sparsity, total=total).items():
+        g.check("fwd", k, v, rtol=2e-5, atol=1e-3)
+    keys = [k for k in g.keys("grad")]
+    noise = {f"enc_conv.{3 * i}.bias" for i in range(7)} | {f"dec_conv.{4 * i + 1}.bias" for i in range(6)} | {"enc_fc.0.bias", "dec_fc.0.bias"}
+    grads = torch.autograd.grad(total, [leaves[k] for k in keys])
+    for k, gr in zip(keys, grads):
+        scale = float(gr.abs().max())
+        if k in noise:              # biases in front of a train-mode BatchNorm: zero in exact arithmetic, rounding noise in both implementations
+            continue
+        g.check("grad", k, gr, rtol=5e-4, atol=5e-4 * scale)
+    for k in g.keys("sd1"):
+        g.check("sd1", k, leaves[k], rtol=2e-5, atol=1e-6)
+
+
 def test_bio3d_degenerates_to_2d_slicewise():
     """a 3D conv whose weight is zero except one depth tap reproduces the 2D
     result slice-wise — ties the 3D lift's conv/convT arithmetic to the golden-pinned 2D path."""

@@ -8,6 +8,7 @@ What is imported from /root/reference (read-only, nothing is written there):
   * causal_cascade/train.py   -> loss_function          (a6)
   * mnist_test/01_baseline_causal_vae/{config,models}.py -> CausalMorphVAE12, LatentDiscriminator (a8)
   * mnist_test/06_model_experiment/{config,models}.py    -> Gaussian-head CausalMorphVAE12
+  * vessel_analysis/00_core/models.py: the text of ``CausalVesselVAE`` is compiled with its two unimportable imports dropped (a11)
   * vessel_analysis/01_train/train.py: only the text of ``loss_function`` is compiled (the module
     itself cannot be imported: it pulls tifffile/torchvision through ``dataset``) (a10)
 The MNIST adversarial loop body (mnist_test/01_baseline_causal_vae/train.py:34-93) cannot be imported
@@ -226,8 +227,54 @@ def vessel_loss_case(name):
     print(name, "keys", len(store))
 
 
+def vessel2d_inputs(B, seed):
+    """Deterministic synthetic batch in the vessel dataset's format (dataset.py:192-248): binary sparse image, standardised m, one-hot t."""
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(B, 1, 768, 1280, generator=g) < 0.08).float()
+    m = torch.randn(B, 12, generator=g)
+    t = F.one_hot(torch.randint(0, 19, (B,), generator=g), 19).float()
+    eps = torch.randn(B, 128, generator=g)
+    return x, m, t, eps
+
+
+def vessel2d_case(name, B=4, seed_data=4321):
+    """CausalVesselVAE (vessel_analysis/00_core/models.py:9-166).  The module imports torchvision and a bare `config`, neither importable
+    here, so the class text up to `class CausalViTVAE` is compiled with those two import lines dropped and CONFIG injected; the loss is the
+    reference loss_function text as in vessel_loss_case; total as train_one_epoch composes it (01_train/train.py:82)."""
+    src = open(os.path.join(REF, "vessel_analysis", "00_core", "models.py")).read()
+    src = src.replace("import torchvision\n", "").replace("from config import CONFIG\n", "")
+    ns = {"CONFIG": {"M_DIM": 12, "T_DIM": 19, "Z_DIM": 128}}
+    exec(compile(src[:src.index("class CausalViTVAE")], "<reference vessel models.py>", "exec"), ns)
+    lsrc = open(os.path.join(REF, "vessel_analysis", "01_train", "train.py")).read()
+    fn_node = next(n for n in ast.parse(lsrc).body if isinstance(n, ast.FunctionDef) and n.name == "loss_function")
+    lns = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=[fn_node], type_ignores=[]), "<reference vessel loss_function>", "exec"), lns)
+    torch.manual_seed(42)
+    model = ns["CausalVesselVAE"]()
+    model.train()
+    store = {}
+    pack("sd0", model.state_dict(), store)
+    x, m, t, eps = vessel2d_inputs(B, seed_data)
+    model.reparameterize = lambda mu, logvar: mu + eps * torch.exp(0.5 * logvar)     # :137-140 with the draw injected
+    recon_x, m_hat, mu, logvar, m_mu, m_logvar = model(x, m, t)
+    recon, kld, morph, sparsity = lns["loss_function"](recon_x, x, m_hat, m, mu, logvar, m_mu, m_logvar)
+    total = recon + 0.5 * kld + morph + 0.3 * sparsity
+    total.backward()
+    store.update({"in/m": m.numpy(), "in/t": t.numpy(), "in/eps": eps.numpy(), "in/seed": np.array([B, seed_data], dtype=np.int64)})
+    pack("in", dict(x=x), store)
+    pack("fwd", dict(recon_x=recon_x, m_hat=m_hat, mu=mu, logvar=logvar, m_mu=m_mu, m_logvar=m_logvar, recon=recon, kld=kld, morph=morph,
+                     sparsity=sparsity, total=total), store)
+    pack("grad", {k: p.grad for k, p in model.named_parameters()}, store)
+    pack("sd1", {k: v for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}, store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print(name, "total", float(total), "keys", len(store))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "vessel2d":
+        vessel2d_case("vessel2d_b4")
+        return
     sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))   # unused import in some ref files
     bio2d_case("bio2d_b4_64x96", 4, 64, 96, 1234)       # non-identity bilinear + non-divisible adaptive pool (6 -> 4)
     bio2d_case("bio2d_b2_64x64", 2, 64, 64, 1235)       # identity resize, identity pool
@@ -235,6 +282,7 @@ def main():
     morph_case("morph12_b8", 8, 1234, gaussian_head=False)
     morph_case("morph12g_b8", 8, 1234, gaussian_head=True)
     vessel_loss_case("vessel_loss")
+    vessel2d_case("vessel2d_b4")          # B = 4: at B = 2 a train-mode BatchNorm1d backward is (g1 - g2)(1 - xhat^2) ~ eps/var, pure cancellation
 
 
 if __name__ == "__main__":
