@@ -119,7 +119,7 @@ def _oracle_step(kind, x, m, t, eps, nd):
     return sd0, sd, st
 
 
-@pytest.mark.parametrize("B,size", [(2, 32), (2, 64), (2, 48)])
+@pytest.mark.parametrize("B,size", [(2, 32), (2, 64), (2, 48), (16, 64)])          # (16, 64): BASELINE.json configs[2], 64^3 fp32 patches, batch 16
 def test_bio3d_fp32_matches_oracle(B, size):
     """3D lift vs the CPU oracle: forward, ELBO (<= 1e-4 rel), gradients, one Adam step."""
     g = torch.Generator().manual_seed(1234)
@@ -524,3 +524,25 @@ def test_vessel2d_train_step_clip_and_adam_follow_torch():
         if k in noise:                                                     # zero-gradient biases in front of a BatchNorm: Adam steps on rounding noise
             continue
         assert float((p - q).abs().mean()) <= 1e-5                          # 5 % of one Adam step: run-to-run noise of the BatchNorm-chain gradients
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-3)], ids=["f32", "bf16"])
+def test_mnist_batch_1024_step_matches_oracle(dtype, tol):
+    """BASELINE.json configs[1]: the MNIST CausalMorphVAE12 adversarial step at batch 1024 (fp32 parity; bf16 = the configuration named there)
+    against the CPU oracle's step on the same batch: every loss term, and the direction of the VAE / discriminator updates."""
+    g = torch.Generator().manual_seed(1024)
+    B = 1024
+    x, m = torch.rand(B, 1, 28, 28, generator=g), torch.rand(B, 12, generator=g)
+    t = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float()
+    eps = tuple(torch.randn(B, 10, generator=g) for _ in range(3))
+    sd_v, sd_d = oracle.init_state_dict("morph12", seed=42), oracle.init_state_dict("disc", seed=7)
+    vae, disc = CausalMorphVAE12().to(DEV).train(), LatentDiscriminator().to(DEV).train()
+    vae.load_state_dict(sd_v); disc.load_state_dict(sd_d)
+    vae.set_compute_dtype(dtype)
+    ref = oracle.mnist_adversarial_step(sd_v, sd_d, x, m, t, *eps, apply_update=False)
+    opt_vae, opt_d = FusedAdam(vae.parameters(), lr=1e-3), FusedAdam(disc.parameters(), lr=1e-3)
+    # the oracle's VAE half uses the UPDATED discriminator; apply_update=False keeps both on the initial weights, so mirror that: lr = 0 for D
+    opt_d.param_groups[0]["lr"] = 0.0
+    r = mnist_train_step(vae, disc, opt_vae, opt_d, x.to(DEV), m.to(DEV), t.to(DEV), eps=tuple(e.to(DEV) for e in eps))
+    for k in ("loss_d", "loss", "recon", "kld", "morph", "adv"):
+        assert rel(r[k], ref[k]) < tol, (k, float(r[k]), float(ref[k]))
