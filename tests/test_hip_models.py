@@ -546,3 +546,28 @@ def test_mnist_batch_1024_step_matches_oracle(dtype, tol):
     r = mnist_train_step(vae, disc, opt_vae, opt_d, x.to(DEV), m.to(DEV), t.to(DEV), eps=tuple(e.to(DEV) for e in eps))
     for k in ("loss_d", "loss", "recon", "kld", "morph", "adv"):
         assert rel(r[k], ref[k]) < tol, (k, float(r[k]), float(ref[k]))
+
+
+def test_mnist_adversarial_step_replays_as_one_hip_graph():
+    """The whole MNIST step (D update, then VAE update; two device-step FusedAdams, Philox eps) captured once and replayed == eager steps."""
+    from causal_vae_amd.graph import GraphedCallable
+    g = torch.Generator().manual_seed(77)
+    B = 256
+    x, m = torch.rand(B, 1, 28, 28, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
+    t = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float().to(DEV)
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(42)
+        vae, disc = CausalMorphVAE12().to(DEV).train(), LatentDiscriminator().to(DEV).train()
+        ov, od = FusedAdam(vae.parameters(), lr=1e-3, device_step=True), FusedAdam(disc.parameters(), lr=1e-3, device_step=True)
+        step = lambda: mnist_train_step(vae, disc, ov, od, x, m, t)
+        if graphed:
+            gs = GraphedCallable(step, warmup=3)
+            losses = [{k: float(v) for k, v in gs().items()} for _ in range(3)]
+        else:
+            losses = [{k: float(v) for k, v in step().items()} for _ in range(6)][3:]
+        runs.append(losses)
+    for a, b in zip(*runs):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-4, (k, runs)
+    assert len({l["loss"] for l in runs[1]}) == 3

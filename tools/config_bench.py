@@ -34,6 +34,12 @@ vae, disc = CausalMorphVAE12().to(DEV).train().set_compute_dtype(torch.bfloat16)
 ov, od = FusedAdam(vae.parameters(), lr=1e-3), FusedAdam(disc.parameters(), lr=1e-3)
 dt = timeit(lambda: mnist_step(vae, disc, ov, od, x, m, t))
 print(f"MNIST CausalMorphVAE12 bf16 B=1024 (eager)      {dt * 1e3:8.3f} ms/step  {B / dt:10.0f} samples/s")
+from causal_vae_amd.graph import GraphedCallable
+vae2, disc2 = CausalMorphVAE12().to(DEV).train().set_compute_dtype(torch.bfloat16), LatentDiscriminator().to(DEV).train()
+ov2, od2 = FusedAdam(vae2.parameters(), lr=1e-3, device_step=True), FusedAdam(disc2.parameters(), lr=1e-3, device_step=True)
+gs = GraphedCallable(lambda: mnist_step(vae2, disc2, ov2, od2, x, m, t))
+dt = timeit(gs, n=50)
+print(f"MNIST CausalMorphVAE12 bf16 B=1024 (HIP graph)  {dt * 1e3:8.3f} ms/step  {B / dt:10.0f} samples/s")
 # configs[2]: 3D 64^3 fp32, batch 16
 B = 16
 x, m = torch.randn(B, 1, 64, 64, 64, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
