@@ -372,25 +372,28 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
     for (int i = t; i < 32 * RW; i += 256) slab[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-// Sum the per-workgroup slabs: block (x, y, z) adds 64 slabs (z-th group) for 64 outputs, then one atomic per output
-// (n_split/64 <= 16 adders per address).  dW / dbias are zeroed by the launcher.
+// Sum the per-workgroup slabs: block (x, y) owns 16 outputs of channel block y; its 256 threads are 16 outputs x 16 slab groups, every
+// group walks n_split / 16 slabs, LDS adds the groups.  Plain stores into dW / dbias: no zero-fill, no atomics, fixed summation order.
 template <int ND>
-__global__ void wgrad_c1_finish_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias, int n_split) {
+__global__ __launch_bounds__(256) void wgrad_c1_finish_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias, int n_split) {
     constexpr int TAPS = (ND == 3) ? 64 : 16, NTS = (TAPS + 31) / 32, RW = NTS * 32 + 1;
-    __shared__ float part[4][64];
-    const int o = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    __shared__ float part[16][17];
+    const int ol = threadIdx.x & 15, q = threadIdx.x >> 4, o = blockIdx.x * 16 + ol;
     const float* base = ws + (size_t)blockIdx.y * n_split * (32 * RW);
-    const int x0 = blockIdx.z * 64, x1 = min(n_split, x0 + 64);
     float acc = 0.f;
-    if (o < 32 * RW)
-        for (int x = x0 + q; x < x1; x += 4) acc += base[(size_t)x * (32 * RW) + o];
-    part[q][threadIdx.x & 63] = acc;
+    if (o < 32 * RW) {
+#pragma unroll 8
+        for (int x = q; x < n_split; x += 16) acc += base[(size_t)x * (32 * RW) + o];
+    }
+    part[q][ol] = acc;
     __syncthreads();
     if (q == 0 && o < 32 * RW) {
-        const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += part[k][ol];
         const int row = o / RW, col = o % RW, cs = blockIdx.y * 32 + row;
-        if (col == NTS * 32) { if (dbias) atomicAdd(&dbias[cs], v); }
-        else if (col < TAPS) atomicAdd(&dW[(size_t)cs * TAPS + col], v);
+        if (col == NTS * 32) { if (dbias) dbias[cs] = v; }
+        else if (col < TAPS) dW[(size_t)cs * TAPS + col] = v;
     }
 }
 
@@ -453,10 +456,8 @@ int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, vo
     else { if (nd == 3) LAUNCH_WG_C1(float, 3); else LAUNCH_WG_C1(float, 2); }
 #undef LAUNCH_WG_C1
     CVAE_CHECK_LAUNCH();
-    const int rw = ((nd == 3) ? 64 : 32) + 1, taps = (nd == 3) ? 64 : 16;
-    if (hipMemsetAsync(dW, 0, (size_t)Cs * taps * sizeof(float), stream) != hipSuccess) return CVAE_E_LAUNCH;
-    if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cs * sizeof(float), stream) != hipSuccess) return CVAE_E_LAUNCH;
-    dim3 fgrid((unsigned)((32 * rw + 63) / 64), (unsigned)(Cs / 32), (unsigned)((n_split + 63) / 64));
+    const int rw = ((nd == 3) ? 64 : 32) + 1;
+    dim3 fgrid((unsigned)((32 * rw + 15) / 16), (unsigned)(Cs / 32), 1);
     if (nd == 3) hipLaunchKernelGGL(wgrad_c1_finish_kernel<3>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split);
     else hipLaunchKernelGGL(wgrad_c1_finish_kernel<2>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split);
     CVAE_CHECK_LAUNCH();

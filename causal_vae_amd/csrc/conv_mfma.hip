@@ -559,10 +559,20 @@ __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(PairTable tb) {
     __syncthreads();
     T* od = (T*)tb.down[ti];
     T* ou = (T*)tb.up[ti];
-    const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
-    for (int tap = 0; tap < taps; ++tap) {
-        od[((size_t)(tap * nclt + clt) * Cs + cs0 + a) * 16 + b] = from_f32<T>(tile[(a * 17 + b) * TP + tap]);      // (cs = a, cl = b)
-        ou[((size_t)(tap * ncst + cst) * Cl + cl0 + a) * 16 + b] = from_f32<T>(tile[(b * 17 + a) * TP + tap]);      // (cl = a, cs = b)
+    // per tap both panels are 256 contiguous elements ([16][16]); a thread writes 8 of them (16 bytes bf16) for one of 8 taps at a time
+    const int tg = threadIdx.x >> 5, e0 = (threadIdx.x & 31) * 8, a = e0 >> 4, b0 = e0 & 15;
+    for (int tap = tg; tap < taps; tap += 8) {
+        __attribute__((aligned(16))) T vd[8], vu[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            vd[q] = from_f32<T>(tile[(a * 17 + b0 + q) * TP + tap]);             // down: (cs = a, cl = b0 + q)
+            vu[q] = from_f32<T>(tile[((b0 + q) * 17 + a) * TP + tap]);           // up:   (cl = a, cs = b0 + q)
+        }
+        T* pd = od + ((size_t)(tap * nclt + clt) * Cs + cs0 + a) * 16 + b0;
+        T* pu = ou + ((size_t)(tap * ncst + cst) * Cl + cl0 + a) * 16 + b0;
+        constexpr int NU = (8 * sizeof(T)) / 16;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { ((uint4*)pd)[u] = ((const uint4*)vd)[u]; ((uint4*)pu)[u] = ((const uint4*)vu)[u]; }
     }
 }
 
