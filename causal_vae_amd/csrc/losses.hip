@@ -409,10 +409,12 @@ extern "C" int cvae_adam_step(float* p, const float* g, float* m, float* v, int6
     return CVAE_OK;
 }
 // Multi-tensor Adam: ONE launch for the whole parameter list (the pointer table travels as a kernel argument), each block
-// owns a 4096-element span of one tensor.  `step_dev` (optional) is a device step counter: when given, the bias
+// owns a 1024-element span of one tensor (one float4 per stream per thread) and uses nontemporal loads and stores: every byte is
+// touched once per step, so keeping it out of L2 leaves the cache to the activations (measured 5.2 vs 3.5 TB/s with 4096-spans).  `step_dev` (optional) is a device step counter: when given, the bias
 // corrections are computed in-kernel so that a captured HIP graph replays with advancing corrections.
 #define ADAM_MAX_TENSORS 32
 #define ADAM_SPAN 4096
+#define ADAM_MULTI_SPAN 1024
 struct AdamTable {
     float* p[ADAM_MAX_TENSORS];
     const float* g[ADAM_MAX_TENSORS];
@@ -422,6 +424,7 @@ struct AdamTable {
     int blk_start[ADAM_MAX_TENSORS + 1];
     int count;
 };
+template <int SPAN, bool NT = false>
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float bc1, float bc2,
                                                          const int* __restrict__ step_dev, const float* __restrict__ gscale) {
     int ti = 0;
@@ -431,19 +434,30 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr,
     const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
     float* p = tb.p[ti]; const float* g = tb.g[ti]; float* m = tb.m[ti]; float* v = tb.v[ti];
     const long long n = tb.n[ti];
-    const long long base = (long long)((int)blockIdx.x - tb.blk_start[ti]) * ADAM_SPAN;
-    const long long end = min(n, base + ADAM_SPAN);
+    const long long base = (long long)((int)blockIdx.x - tb.blk_start[ti]) * SPAN;
+    const long long end = min(n, base + SPAN);
     const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
-    if (vec && end - base == ADAM_SPAN) {
+    if (vec && end - base == SPAN) {
 #pragma unroll
-        for (int k = 0; k < ADAM_SPAN / (256 * 4); ++k) {
+        for (int k = 0; k < SPAN / (256 * 4); ++k) {
             const long long i = base / 4 + k * 256 + threadIdx.x;
-            float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+            float4 P, G, M, V;
+            if (NT) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v a = __builtin_nontemporal_load((f4v*)p + i), b = __builtin_nontemporal_load((const f4v*)g + i);
+                f4v c = __builtin_nontemporal_load((f4v*)m + i), d = __builtin_nontemporal_load((f4v*)v + i);
+                P = make_float4(a.x, a.y, a.z, a.w); G = make_float4(b.x, b.y, b.z, b.w); M = make_float4(c.x, c.y, c.z, c.w); V = make_float4(d.x, d.y, d.z, d.w);
+            } else { P = ((float4*)p)[i]; G = ((const float4*)g)[i]; M = ((float4*)m)[i]; V = ((float4*)v)[i]; }
             adam1(P.x, G.x * gs, M.x, V.x, b1, b2, eps, step, rbc2);
             adam1(P.y, G.y * gs, M.y, V.y, b1, b2, eps, step, rbc2);
             adam1(P.z, G.z * gs, M.z, V.z, b1, b2, eps, step, rbc2);
             adam1(P.w, G.w * gs, M.w, V.w, b1, b2, eps, step, rbc2);
-            ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+            if (NT) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v a = {P.x, P.y, P.z, P.w}, c = {M.x, M.y, M.z, M.w}, d = {V.x, V.y, V.z, V.w};
+                __builtin_nontemporal_store(a, (f4v*)p + i); __builtin_nontemporal_store(c, (f4v*)m + i); __builtin_nontemporal_store(d, (f4v*)v + i);
+            }
+            else { ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V; }
         }
     } else {
         for (long long i = base + threadIdx.x; i < end; i += 256) adam1(p[i], g[i] * gs, m[i], v[i], b1, b2, eps, step, rbc2);
@@ -455,6 +469,7 @@ extern "C" int cvae_adam_multi(float* const* p, const float* const* g, float* co
     if (count == 0) return CVAE_OK;
     if (!p || !g || !m || !v || !n) return CVAE_E_NULLPTR;
     if (!step_dev && (bc1 <= 0.f || bc2 <= 0.f)) return CVAE_E_BADSHAPE;
+    const int span = ADAM_MULTI_SPAN;
     for (int c0 = 0; c0 < count; c0 += ADAM_MAX_TENSORS) {
         AdamTable tb;
         const int cnt = (count - c0 < ADAM_MAX_TENSORS) ? count - c0 : ADAM_MAX_TENSORS;
@@ -466,13 +481,13 @@ extern "C" int cvae_adam_multi(float* const* p, const float* const* g, float* co
             if (!p[c0 + i] || !g[c0 + i] || !m[c0 + i] || !v[c0 + i]) return CVAE_E_NULLPTR;
             tb.p[used] = p[c0 + i]; tb.g[used] = g[c0 + i]; tb.m[used] = m[c0 + i]; tb.v[used] = v[c0 + i]; tb.n[used] = ni;
             tb.blk_start[used] = blocks;
-            blocks += (int)((ni + ADAM_SPAN - 1) / ADAM_SPAN);
+            blocks += (int)((ni + span - 1) / span);
             ++used;
         }
         if (!used) continue;
         tb.blk_start[used] = blocks;
         tb.count = used;
-        hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb, lr, b1, b2, eps, bc1, bc2, step_dev, gscale);
+        hipLaunchKernelGGL((adam_multi_kernel<ADAM_MULTI_SPAN, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb, lr, b1, b2, eps, bc1, bc2, step_dev, gscale);
         CVAE_CHECK_LAUNCH();
     }
     return CVAE_OK;
