@@ -37,6 +37,7 @@ struct TailGrads {
 // saved activations (global), all [M][dim] row-major
 struct TailSaved { float *h1, *h2, *mu, *logvar, *xhat, *invstd, *a1n, *a2, *m_hat, *zm; };
 struct MechFwdArgs { const float* t_onehot; float *running_mean, *running_var; long long* num_batches_tracked; float momentum, bn_eps; int bn_training; };
+#define DZM_GROUPS 16           // copies of the d(zm) accumulator (dec_input_bwd)
 struct MechBwdArgs { const float *dzm_part, *g_mhat, *t_onehot; };
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };       // float4 at dword alignment
 
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p,
     extern __shared__ float lds[];
     const int M = d.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K4 = d.Z + d.DM;
     if (blockIdx.x == 0 && dzm_acc)                          // the backward accumulates d(zm) here with atomics: leave it zeroed
-        for (int i = tid; i < M * K4; i += 256) dzm_acc[i] = 0.f;
+        for (int i = tid; i < DZM_GROUPS * M * K4; i += 256) dzm_acc[i] = 0.f;
     float* h2s = lds;                                        // [M][N2]
     for (int i = tid; i < M * d.N2; i += 256) h2s[i] = sv.h2[i];
     __syncthreads();
@@ -332,8 +333,9 @@ __global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p,
 }
 
 // ------------------------------------------------------------------------------------------------ dec_input_fwd
-// out[b][s][c] = sum_k zm[b][k] Wd[c * S + s][k] + bd[c * S + s].  grid (S, C / 64), 256 threads: the 64 weight rows of one
-// (cell, channel block) are staged in LDS with coalesced loads; thread (r, q) owns row r and a quarter of k.
+// out[b][s][c] = sum_k zm[b][k] Wd[c * S + s][k] + bd[c * S + s].  grid C * S / 64, 256 threads: a block takes 64 CONSECUTIVE
+// weight rows n = c * S + s (one contiguous run of 64 * K4 floats, float4 loads when K4 % 4 == 0) into LDS; thread (r, q) owns row r
+// and a quarter of k.  The (small) output is what gets scattered instead of the weight reads.
 template <typename T>
 __global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restrict__ zm, const float* __restrict__ Wd, const float* __restrict__ bd,
                                                             T* __restrict__ out, int M, int K4, int S, int C) {
@@ -342,10 +344,18 @@ __global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restr
     float* ws = lds;                                         // [64][KP]
     float* zs = ws + 64 * KP;                                // [M][K4]
     float* part = zs + M * K4;                               // [4][M][64]
-    const int s = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
-    for (int i = tid; i < 64 * K4; i += 256) {
-        const int r = i / K4, k = i - r * K4;
-        ws[r * KP + k] = Wd[((size_t)(c0 + r) * S + s) * K4 + k];
+    const int tid = threadIdx.x;
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    const float* wsrc = Wd + row0 * K4;
+    if ((K4 & 3) == 0) {
+        for (int i = tid * 4; i < 64 * K4; i += 1024) {
+            const float4 w4 = *(const float4*)(wsrc + i);
+            const int r = i / K4, k = i - r * K4;
+            float* d = ws + r * KP + k;
+            d[0] = w4.x; d[1] = w4.y; d[2] = w4.z; d[3] = w4.w;
+        }
+    } else {
+        for (int i = tid; i < 64 * K4; i += 256) { const int r = i / K4, k = i - r * K4; ws[r * KP + k] = wsrc[i]; }
     }
     for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
     __syncthreads();
@@ -366,56 +376,92 @@ __global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restr
     __syncthreads();
     for (int i = tid; i < M * 64; i += 256) {
         const int m = i >> 6, rr = i & 63;
-        const float v = part[(0 * M + m) * 64 + rr] + part[(1 * M + m) * 64 + rr] + part[(2 * M + m) * 64 + rr] + part[(3 * M + m) * 64 + rr] +
-                        bd[(size_t)(c0 + rr) * S + s];
-        out[((size_t)m * S + s) * C + c0 + rr] = from_f32<T>(v);
+        const int n = (int)row0 + rr, c = n / S, sc = n - c * S;
+        const float v = part[(0 * M + m) * 64 + rr] + part[(1 * M + m) * 64 + rr] + part[(2 * M + m) * 64 + rr] + part[(3 * M + m) * 64 + rr] + bd[n];
+        out[((size_t)m * S + sc) * C + c] = from_f32<T>(v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ dec_input_bwd
 // g[b][n] = gcl[b][s][c] (n = c * S + s).  dWd[n][k] = sum_b g[b][n] zm[b][k]; dbd[n] = sum_b g[b][n];
-// dzm[b][k] += sum_{n in block} g[b][n] Wd[n][k]  (fp32 atomics onto the M x K4 accumulator, which the forward left zeroed and
-// pool_bwd zeroes again: a tree over the 256 blocks would cost an extra dependent launch).  grid (S, C / 64) as the forward.
+// dzm[b][k] += sum_{n in block} g[b][n] Wd[n][k].  A block owns R = 64 CONSECUTIVE rows n (C % 64 == 0), so its slice of Wd and
+// dWd is one contiguous run of R * K4 floats (float4 when K4 % 4 == 0).  The d(zm) partial sums go with fp32 atomics
+// onto DZM_GROUPS copies of the M x K4 accumulator (block -> copy round robin: 16x fewer adds per address; a tree over the blocks
+// would cost an extra dependent launch); the consumers add the copies up (load_dzm).  The forward leaves the copies zeroed and
+// pool_bwd zeroes them again.
 template <typename T>
 __global__ __launch_bounds__(256) void dec_input_bwd_kernel(const T* __restrict__ gcl, const float* __restrict__ zm, const float* __restrict__ Wd,
                                                             float* __restrict__ dWd, float* __restrict__ dbd, float* __restrict__ dzm_acc,
                                                             int M, int K4, int S, int C) {
     extern __shared__ float lds[];
+    constexpr int R = 64;
     const int KP = K4 | 1;
-    float* ws = lds;                                         // [64][KP]
-    float* zs = ws + 64 * KP;                                // [M][K4]
-    float* gs = zs + M * K4;                                 // [M][64]
-    const int s = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
-    for (int i = tid; i < 64 * K4; i += 256) {
-        const int r = i / K4, k = i - r * K4;
-        ws[r * KP + k] = Wd[((size_t)(c0 + r) * S + s) * K4 + k];
+    float* ws = lds;                                         // [R][KP]
+    float* zs = ws + R * KP;                                 // [M][K4]
+    float* gs = zs + M * K4;                                 // [M][R]
+    const int tid = threadIdx.x;
+    const size_t row0 = (size_t)blockIdx.x * R;
+    const float* wsrc = Wd + row0 * K4;
+    float* wdst = dWd + row0 * K4;
+    const bool v4 = (K4 & 3) == 0;                           // rows start 16-byte aligned
+    if (v4) {
+        for (int i = tid * 4; i < R * K4; i += 1024) {
+            const float4 w4 = *(const float4*)(wsrc + i);
+            const int r = i / K4, k = i - r * K4;
+            float* d = ws + r * KP + k;
+            d[0] = w4.x; d[1] = w4.y; d[2] = w4.z; d[3] = w4.w;
+        }
+    } else {
+        for (int i = tid; i < R * K4; i += 256) { const int r = i / K4, k = i - r * K4; ws[r * KP + k] = wsrc[i]; }
     }
     for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
-    for (int i = tid; i < M * 64; i += 256) gs[i] = to_f32(gcl[((size_t)(i >> 6) * S + s) * C + c0 + (i & 63)]);
+    for (int i = tid; i < M * R; i += 256) {
+        const int m = i / R, n = (int)row0 + (i - m * R), c = n / S, sc = n - c * S;
+        gs[i] = to_f32(gcl[((size_t)m * S + sc) * C + c]);
+    }
     __syncthreads();
-    for (int i = tid; i < 64 * K4; i += 256) {
-        const int r = i / K4, k = i - r * K4;
-        float acc = 0.f;
-        for (int m = 0; m < M; ++m) acc += gs[m * 64 + r] * zs[m * K4 + k];
-        dWd[((size_t)(c0 + r) * S + s) * K4 + k] = acc;
+    if (v4) {
+        for (int i = tid * 4; i < R * K4; i += 1024) {
+            const int r = i / K4, k = i - r * K4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int m = 0; m < M; ++m) {
+                const float gv = gs[m * R + r];
+                const float* z = zs + m * K4 + k;
+                a.x += gv * z[0]; a.y += gv * z[1]; a.z += gv * z[2]; a.w += gv * z[3];
+            }
+            *(float4*)(wdst + i) = a;
+        }
+    } else {
+        for (int i = tid; i < R * K4; i += 256) {
+            const int r = i / K4, k = i - r * K4;
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) acc += gs[m * R + r] * zs[m * K4 + k];
+            wdst[i] = acc;
+        }
     }
-    if (tid < 64) {
+    for (int r = tid; r < R; r += 256) {
         float acc = 0.f;
-        for (int m = 0; m < M; ++m) acc += gs[m * 64 + tid];
-        dbd[(size_t)(c0 + tid) * S + s] = acc;
+        for (int m = 0; m < M; ++m) acc += gs[m * R + r];
+        dbd[row0 + r] = acc;
     }
+    float* dz = dzm_acc + (size_t)(blockIdx.x % DZM_GROUPS) * M * K4;
     for (int i = tid; i < M * K4; i += 256) {
         const int m = i / K4, k = i - m * K4;
         float acc = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < 64; ++r) acc += gs[m * 64 + r] * ws[r * KP + k];
-        atomicAdd(&dzm_acc[i], acc);
+        for (int r = 0; r < R; ++r) acc += gs[m * R + r] * ws[r * KP + k];
+        atomicAdd(&dz[i], acc);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ d(zm) -> LDS
 __device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dzs[i] = dzm_acc[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < DZM_GROUPS; ++q) v += dzm_acc[(size_t)q * n + i];
+        dzs[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ mechanism_net backward
@@ -655,17 +701,42 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
         for (int i = threadIdx.x; i < n_dzm; i += 256) dzm_acc[i] = 0.f;
     const int ow = s % OW, oh = (s / OW) % OH, od = s / (OW * OH);
     const int d0 = pool_lo(od, D, OD), d1 = pool_hi(od, D, OD), h0 = pool_lo(oh, H, OH), h1 = pool_hi(oh, H, OH), w0 = pool_lo(ow, W, OW), w1 = pool_hi(ow, W, OW);
-    const float inv = 1.f / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.f;
-        for (int ns = 0; ns < NS; ++ns) acc += dxp[(((size_t)ns * M + b) * S + s) * C + c];
-        acc *= inv;
-        for (int dd = d0; dd < d1; ++dd)
-            for (int hh = h0; hh < h1; ++hh)
-                for (int ww = w0; ww < w1; ++ww) {
-                    const size_t idx = ((((size_t)b * D + dd) * H + hh) * W + ww) * C + c;
-                    dy[idx] = from_f32<T>((!relu_mask || to_f32(y[idx]) > 0.f) ? acc : 0.f);
-                }
+    const int nh = h1 - h0, nw = w1 - w0, nvox = (d1 - d0) * nh * nw;
+    const float inv = 1.f / (float)nvox;
+    // 256 channels at a time: 4 thread groups split the NS partials (float4 = 4 channels per thread), LDS combines them, then the
+    // window is written in 16-byte pieces (one piece of the ReLU mask read per piece written).
+    __shared__ float4 part[4][64];
+    __shared__ __attribute__((aligned(16))) float val[256];
+    constexpr int EPP = 16 / sizeof(T);                      // channels per 16-byte piece
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cw = min(256, C - c0);                     // multiple of 64
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * l < cw)
+            for (int ns = q; ns < NS; ns += 4) {
+                const float4 v = *(const float4*)(dxp + (((size_t)ns * M + b) * S + s) * C + c0 + 4 * l);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        part[q][l] = a;
+        __syncthreads();
+        if (q == 0) {
+            const float4 b1 = part[1][l], b2 = part[2][l], b3 = part[3][l];
+            *(float4*)(val + 4 * l) = make_float4((a.x + b1.x + b2.x + b3.x) * inv, (a.y + b1.y + b2.y + b3.y) * inv, (a.z + b1.z + b2.z + b3.z) * inv,
+                                                  (a.w + b1.w + b2.w + b3.w) * inv);
+        }
+        __syncthreads();
+        const int ppv = cw / EPP;                            // pieces per voxel
+        for (int i = threadIdx.x; i < nvox * ppv; i += 256) {
+            const int v = i / ppv, pc = (i - v * ppv) * EPP;
+            const int ww = w0 + v % nw, hh = h0 + (v / nw) % nh, dd = d0 + v / (nw * nh);
+            const size_t idx = ((((size_t)b * D + dd) * H + hh) * W + ww) * C + c0 + pc;
+            union { uint4 u; T e[EPP]; } mk, o;
+            if (relu_mask) mk.u = *(const uint4*)(y + idx);
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) o.e[e] = from_f32<T>((!relu_mask || to_f32(mk.e[e]) > 0.f) ? val[pc + e] : 0.f);
+            *(uint4*)(dy + idx) = o.u;
+        }
+        __syncthreads();
     }
 }
 
@@ -697,7 +768,7 @@ extern "C" int cvae_bottleneck_sizes(const cvae_bottleneck_dims* q, int64_t* K1,
     if (K1) *K1 = k1;
     if (K4) *K4 = k4;
     if (fwd_partial_floats) *fwd_partial_floats = (int64_t)fwd_ksplit(k1) * q->M * q->N1;
-    if (dzm_partial_floats) *dzm_partial_floats = q->M * k4;
+    if (dzm_partial_floats) *dzm_partial_floats = DZM_GROUPS * q->M * k4;
     if (dx_partial_floats) *dx_partial_floats = (int64_t)bwd_nsplit(q->N1) * q->M * F;
     return CVAE_OK;
 }
@@ -750,9 +821,9 @@ extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bot
     CVAE_CHECK_LAUNCH();
     const size_t lds_d = sizeof(float) * ((size_t)64 * (K4 | 1) + (size_t)M * K4 + (size_t)4 * M * 64);
     if (dtype == CVAE_BF16)
-        hipLaunchKernelGGL(dec_input_fwd_kernel<bf16>, dim3(S, C / 64), dim3(256), lds_d, st, (const float*)sv->zm, w->Wd, w->bd, (bf16*)dec_cl, M, K4, S, C);
+        hipLaunchKernelGGL(dec_input_fwd_kernel<bf16>, dim3(C * S / 64), dim3(256), lds_d, st, (const float*)sv->zm, w->Wd, w->bd, (bf16*)dec_cl, M, K4, S, C);
     else
-        hipLaunchKernelGGL(dec_input_fwd_kernel<float>, dim3(S, C / 64), dim3(256), lds_d, st, (const float*)sv->zm, w->Wd, w->bd, (float*)dec_cl, M, K4, S, C);
+        hipLaunchKernelGGL(dec_input_fwd_kernel<float>, dim3(C * S / 64), dim3(256), lds_d, st, (const float*)sv->zm, w->Wd, w->bd, (float*)dec_cl, M, K4, S, C);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
@@ -769,10 +840,10 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     const int K1 = F + (int)q->m_dim + (int)q->t_dim, K4 = (int)(q->Z + q->m_dim), NS = bwd_nsplit(q->N1), P = S;
     const size_t lds_d = sizeof(float) * ((size_t)64 * (K4 | 1) + (size_t)M * K4 + (size_t)M * 64);
     if (dtype == CVAE_BF16)
-        hipLaunchKernelGGL(dec_input_bwd_kernel<bf16>, dim3(S, C / 64), dim3(256), lds_d, st, (const bf16*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
+        hipLaunchKernelGGL(dec_input_bwd_kernel<bf16>, dim3(F / 64), dim3(256), lds_d, st, (const bf16*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
                            dzm_partial, M, K4, S, C);
     else
-        hipLaunchKernelGGL(dec_input_bwd_kernel<float>, dim3(S, C / 64), dim3(256), lds_d, st, (const float*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
+        hipLaunchKernelGGL(dec_input_bwd_kernel<float>, dim3(F / 64), dim3(256), lds_d, st, (const float*)g_dec_cl, (const float*)sv->zm, w->Wd, gr->dWd, gr->dbd,
                            dzm_partial, M, K4, S, C);
     CVAE_CHECK_LAUNCH();
     const TailDims d = tail_dims(q, 0, P);
@@ -793,10 +864,10 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     CVAE_CHECK_LAUNCH();
     if (dtype == CVAE_BF16)
         hipLaunchKernelGGL(pool_bwd_kernel<bf16>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const bf16*)y_cl, (bf16*)dy_cl, NS, M, (int)q->D, (int)q->H,
-                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, M * K4);
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, DZM_GROUPS * M * K4);
     else
         hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const float*)y_cl, (float*)dy_cl, NS, M, (int)q->D, (int)q->H,
-                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, M * K4);
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, DZM_GROUPS * M * K4);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

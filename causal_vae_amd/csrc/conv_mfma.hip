@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
 // Only `down` splits: an `up` launch already has 8 (4) parity classes per tile and its output is 8x (4x) its input, so the fp32 slabs
 // cost more than the shorter K loop saves (measured: enc4 backward-data 23 -> 34 us, dec2 forward 12 -> 22 us with split-K).
 static int pick_ksplit(bool up, long long nwg, int nchunks) {
-    if (up || nwg >= 384 || nchunks < 2) return 1;
+    if (up || nwg >= 384 || nwg < 1 || nchunks < 2) return 1;
     long long target = (512 + nwg - 1) / nwg;
     if (target > 16) target = 16;
     int best = 1;

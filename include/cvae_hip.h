@@ -160,7 +160,8 @@ int cvae_bottleneck_sizes(const cvae_bottleneck_dims* dims, int64_t* K1, int64_t
 /* Forward.  t_onehot [M][t_dim], eps [M][Z] (the reparameterisation noise).  bn_training: batch statistics + running-stat /
  * num_batches_tracked update (running_* may be NULL), else running statistics.  Outputs: saved->mu / logvar / m_hat (the
  * model's outputs) and dec_cl [M][OD][OH][OW][C] (conv dtype) = dec_input(cat(z, m_hat)) viewed [M, C, 4..] channels-last.
- * dzm_acc: the M*K4 accumulator the backward adds d(zm) into; the forward zeroes it (keep it until the backward has run). */
+ * dzm_acc: the accumulator (dzm_partial_floats of cvae_bottleneck_sizes) the backward adds d(zm) into; the forward zeroes it (keep it until
+ * the backward has run). */
 int cvae_bottleneck_fwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, const float* t_onehot,
                         const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
                         int bn_training, float* xcat, float* fwd_partial, float* dzm_acc, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype,
