@@ -531,42 +531,50 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackTable tb) {
     }
 }
 
-// Both directions of every weight in one launch, through an LDS transpose: a block takes a 16 cs x 16 cl x taps tile of one fp32
-// master (16 contiguous rows of 16 * taps floats), and writes the `down` panel ([tap][cl / 16][cs][16 cl]) and the `up` panel
-// ([tap][cs / 16][cl][16 cs]) in 512-byte (bf16) runs — the gather form above reads every source line 16 times.
+// Both directions of every weight in one launch, through an LDS transpose: a block takes a 16 cs x 16 cl x 16 taps tile of one fp32
+// master (64-byte runs, float4 loads), and writes the `down` panel ([tap][cl / 16][cs][16 cl]) and the `up` panel
+// ([tap][cs / 16][cl][16 cs]) in 512-byte (bf16) runs — the gather form above reads every source line 16 times.  3D weights
+// (64 taps) take 4 blocks per (cs, cl) tile: ~1300 small blocks for the model instead of ~330 long ones.
 #define PAIR_MAX 16
 struct PairTable {
     const float* w[PAIR_MAX];
     void* down[PAIR_MAX];
     void* up[PAIR_MAX];
     int Cs[PAIR_MAX], Cl[PAIR_MAX], blk_start[PAIR_MAX + 1];
-    int count, taps;
+    int count;
 };
-template <typename T>
+template <typename T, int TAPS>
 __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(PairTable tb) {
-    extern __shared__ float tile[];                          // [(cs * 17 + cl)][taps + 1]
+    constexpr int TT = 16, TSPLIT = TAPS / TT, TP = TT + 1;
+    __shared__ float tile[16 * 17 * TP];                     // [(cs * 17 + cl)][tap]
     int ti = 0;
     while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
-    const int Cs = tb.Cs[ti], Cl = tb.Cl[ti], taps = tb.taps, TP = taps + 1;
-    const int blk = (int)blockIdx.x - tb.blk_start[ti], nclt = Cl / 16, ncst = Cs / 16;
+    const int Cs = tb.Cs[ti], Cl = tb.Cl[ti];
+    int blk = (int)blockIdx.x - tb.blk_start[ti];
+    const int tq = blk % TSPLIT; blk /= TSPLIT;
+    const int nclt = Cl / 16, ncst = Cs / 16;
     const int cst = blk / nclt, clt = blk % nclt, cs0 = cst * 16, cl0 = clt * 16;
     const float* w = tb.w[ti];
-    const int row = 16 * taps;                               // floats of one cs row of the tile (contiguous in w)
-    for (int i = threadIdx.x; i < 16 * row; i += 256) {
-        const int cs = i / row, rem = i - cs * row, cl = rem / taps, tap = rem - cl * taps;
-        tile[(cs * 17 + cl) * TP + tap] = w[((size_t)(cs0 + cs) * Cl + cl0) * taps + rem];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256, f = i & 3, cl = (i >> 2) & 15, cs = i >> 6;
+        const float4 v = *(const float4*)(w + ((size_t)(cs0 + cs) * Cl + cl0 + cl) * TAPS + tq * TT + 4 * f);
+        float* d = tile + (cs * 17 + cl) * TP + 4 * f;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
     T* od = (T*)tb.down[ti];
     T* ou = (T*)tb.up[ti];
     // per tap both panels are 256 contiguous elements ([16][16]); a thread writes 8 of them (16 bytes bf16) for one of 8 taps at a time
     const int tg = threadIdx.x >> 5, e0 = (threadIdx.x & 31) * 8, a = e0 >> 4, b0 = e0 & 15;
-    for (int tap = tg; tap < taps; tap += 8) {
+#pragma unroll
+    for (int tl = tg; tl < TT; tl += 8) {
+        const int tap = tq * TT + tl;
         __attribute__((aligned(16))) T vd[8], vu[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            vd[q] = from_f32<T>(tile[(a * 17 + b0 + q) * TP + tap]);             // down: (cs = a, cl = b0 + q)
-            vu[q] = from_f32<T>(tile[((b0 + q) * 17 + a) * TP + tap]);           // up:   (cl = a, cs = b0 + q)
+            vd[q] = from_f32<T>(tile[(a * 17 + b0 + q) * TP + tl]);              // down: (cs = a, cl = b0 + q)
+            vu[q] = from_f32<T>(tile[((b0 + q) * 17 + a) * TP + tl]);            // up:   (cl = a, cs = b0 + q)
         }
         T* pd = od + ((size_t)(tap * nclt + clt) * Cs + cs0 + a) * 16 + b0;
         T* pu = ou + ((size_t)(tap * ncst + cst) * Cl + cl0 + a) * 16 + b0;
@@ -979,19 +987,10 @@ extern "C" int cvae_conv_pack_weight_pairs(const float* const* w, void* const* p
     if (count == 0) return CVAE_OK;
     if (!w || !packed_down || !packed_up || !Cs || !Cl) return CVAE_E_NULLPTR;
     if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
-    const int taps = (nd == 3) ? 64 : 16;
-    const size_t lds = (size_t)16 * 17 * (taps + 1) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)pack_weight_pairs_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 17 * 65 * 4) != hipSuccess ||
-            hipFuncSetAttribute((const void*)pack_weight_pairs_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 17 * 65 * 4) != hipSuccess)
-            return CVAE_E_LAUNCH;
-        attr_set = true;
-    }
+    const int tsplit = (nd == 3) ? 4 : 1;                    // blocks per (cs, cl) tile: 16 taps each
     for (int c0 = 0; c0 < count; c0 += PAIR_MAX) {
         PairTable tb;
         const int cnt = (count - c0 < PAIR_MAX) ? count - c0 : PAIR_MAX;
-        tb.taps = taps;
         long long blocks = 0;
         for (int i = 0; i < cnt; ++i) {
             const int64_t cs = Cs[c0 + i], cl = Cl[c0 + i];
@@ -1000,13 +999,20 @@ extern "C" int cvae_conv_pack_weight_pairs(const float* const* w, void* const* p
             if (!w[c0 + i] || !packed_down[c0 + i] || !packed_up[c0 + i]) return CVAE_E_NULLPTR;
             tb.w[i] = w[c0 + i]; tb.down[i] = packed_down[c0 + i]; tb.up[i] = packed_up[c0 + i]; tb.Cs[i] = (int)cs; tb.Cl[i] = (int)cl;
             tb.blk_start[i] = (int)blocks;
-            blocks += (cs / 16) * (cl / 16);
+            blocks += (cs / 16) * (cl / 16) * tsplit;
             if (blocks > (1 << 30)) return CVAE_E_BADSHAPE;
         }
         tb.blk_start[cnt] = (int)blocks;
         tb.count = cnt;
-        if (dtype == CVAE_BF16) hipLaunchKernelGGL(pack_weight_pairs_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, tb);
-        else hipLaunchKernelGGL(pack_weight_pairs_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, tb);
+        const dim3 grid((unsigned)blocks);
+        hipStream_t st = (hipStream_t)stream;
+        if (dtype == CVAE_BF16) {
+            if (nd == 3) hipLaunchKernelGGL((pack_weight_pairs_kernel<bf16, 64>), grid, dim3(256), 0, st, tb);
+            else hipLaunchKernelGGL((pack_weight_pairs_kernel<bf16, 16>), grid, dim3(256), 0, st, tb);
+        } else {
+            if (nd == 3) hipLaunchKernelGGL((pack_weight_pairs_kernel<float, 64>), grid, dim3(256), 0, st, tb);
+            else hipLaunchKernelGGL((pack_weight_pairs_kernel<float, 16>), grid, dim3(256), 0, st, tb);
+        }
         CVAE_CHECK_LAUNCH();
     }
     return CVAE_OK;
