@@ -85,7 +85,8 @@ SIGNATURES = {
     "cvae_clip_coef": [_p, _p, _f, _p],
     "cvae_up2x_supported": [_i64] * 7,
     "cvae_up2x_fwd": [_p, _p] + [_i64] * 7 + [_i, _p],
-    "cvae_elbo_up2x_fwd": [_p] * 6 + [_f, _p] + [_i64] * 9 + [_i, _p],
+    "cvae_elbo_up2x_partials": [_i64] * 4,
+    "cvae_elbo_up2x_fwd": [_p] * 6 + [_f, _p, _p] + [_i64] * 9 + [_i, _p],
     "cvae_elbo_up2x_bwd": [_p] * 6 + [_f] + [_p] * 6 + [_i64] * 9 + [_i, _p],
     "cvae_conv3_to_k4": [_p, _p, _i64, _i64, _p],
     "cvae_k4_to_conv3_grad": [_p, _p, _i64, _i64, _p],
@@ -98,7 +99,7 @@ SIGNATURES = {
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
-            "cvae_conv_data_workspace_bytes": _sz}
+            "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library disagree: fail at import

@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256) void up_c1_kernel(const T* __restrict__ S, con
 //         elements per lane); v_mfma_f32_32x32x16_bf16.  A third accumulator S^T . ones yields the bias gradient.
 //   fp32: v_mfma_f32_32x32x2_f32, one element per lane per operand.
 // Each workgroup walks `total / n_split` tiles of 128 positions and leaves with fp32 atomics directly in [Cs][1][taps].
-template <typename T, int ND>
+template <typename T, int ND, bool LSUM>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, bool want_bias, int B, int sd, int sh, int sw,
-                                                       int Cs, int ld, int lh, int lw, int tiles_d, int tiles_h, int tiles_w, int n_split) {
+                                                       int Cs, int ld, int lh, int lw, int tiles_d, int tiles_h, int tiles_w, int n_split, float* __restrict__ lsum_ws) {
     constexpr int TD = (ND == 3) ? 4 : 1, TH = (ND == 3) ? 4 : 8, TW = (ND == 3) ? 8 : 16;     // 128 positions
     constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, IW = 2 * TW + 2, NPOS = ID * IH * IW;
     constexpr int TAPS = (ND == 3) ? 64 : 16, NTS = (TAPS + 31) / 32;
@@ -273,6 +273,10 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
     // is consumed from LDS, so the HBM latency hides under the barriers, LDS traffic and MFMAs of the previous tile.
     uint4 sv[2][NU];
     T hv[HN];
+    // ConvTranspose bias gradient (the plain sum of L): every L element lies in the non-halo part of exactly one tile (host checks
+    // L == 2 S), so the channel block 0 workgroups add up what they load anyway; wgrad_c1_finish sums the per-workgroup partials.
+    const bool want_lsum = LSUM && blockIdx.y == 0;
+    float lacc = 0.f;
     auto issue = [&](int tile) {
         int tt = tile;
         const int tw_i = tt % tiles_w; tt /= tiles_w;
@@ -297,6 +301,10 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
             const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - 1 + x;
             const bool ok = pos < NPOS && gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
             hv[i] = ok ? L[(((size_t)b * ld + gz) * lh + gy) * lw + gx] : from_f32<T>(0.f);
+            if (LSUM) {
+                const bool inner = (ND == 2 || (z >= 1 && z <= 2 * TD)) && y >= 1 && y <= 2 * TH && x >= 1 && x <= 2 * TW;
+                if (want_lsum && ok && inner) lacc += to_f32(hv[i]);
+            }
         }
     };
     if ((int)blockIdx.x < total) issue(blockIdx.x);
@@ -370,13 +378,32 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
     __syncthreads();
     float* slab = ws + ((size_t)blockIdx.y * n_split + blockIdx.x) * (32 * RW);
     for (int i = t; i < 32 * RW; i += 256) slab[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (LSUM && want_lsum) {                                 // block-uniform
+        __shared__ float lred[4];
+        const float v = wave_sum(lacc);
+        if (lane == 0) lred[wave] = v;
+        __syncthreads();
+        if (t == 0) lsum_ws[blockIdx.x] = lred[0] + lred[1] + lred[2] + lred[3];
+    }
 }
 
 // Sum the per-workgroup slabs: block (x, y) owns 16 outputs of channel block y; its 256 threads are 16 outputs x 16 slab groups, every
 // group walks n_split / 16 slabs, LDS adds the groups.  Plain stores into dW / dbias: no zero-fill, no atomics, fixed summation order.
 template <int ND>
-__global__ __launch_bounds__(256) void wgrad_c1_finish_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias, int n_split) {
+__global__ __launch_bounds__(256) void wgrad_c1_finish_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias, int n_split,
+                                                              const float* __restrict__ lsum_ws, float* __restrict__ dbias_l, int main_blocks) {
     constexpr int TAPS = (ND == 3) ? 64 : 16, NTS = (TAPS + 31) / 32, RW = NTS * 32 + 1;
+    if ((int)blockIdx.x >= main_blocks) {                    // one extra block (channel block 0 only): the L-side bias = sum of the partial sums
+        if (blockIdx.y != 0 || !dbias_l) return;
+        __shared__ float lred[4];
+        float v = 0.f;
+        for (int i = threadIdx.x; i < n_split; i += 256) v += lsum_ws[i];
+        v = wave_sum(v);
+        if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) dbias_l[0] = lred[0] + lred[1] + lred[2] + lred[3];
+        return;
+    }
     __shared__ float part[16][17];
     const int ol = threadIdx.x & 15, q = threadIdx.x >> 4, o = blockIdx.x * 16 + ol;
     const float* base = ws + (size_t)blockIdx.y * n_split * (32 * RW);
@@ -433,11 +460,13 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
 
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd) {
     const int rw = ((nd == 3) ? 64 : 32) + 1;
-    return (size_t)1024 * 32 * rw * sizeof(float);           // (Cs/32) * n_split <= 1024 slabs of [32][rw]
+    return ((size_t)1024 * 32 * rw + 1024) * sizeof(float);  // (Cs/32) * n_split <= 1024 slabs of [32][rw], then <= 1024 partial sums of L
 }
 
-int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
+int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
                        int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream) {
+    // dbias: per-channel sum of S (Conv bias) or NULL; dbias_l: sum of L (ConvTranspose bias, one value; needs L == 2 S) or NULL
+    if (dbias_l && (lh != 2 * sh || lw != 2 * sw || (nd == 3 && ld != 2 * sd))) return CVAE_E_UNSUPPORTED;
     if (Cs % 32 || Cs > 1024 * 32) return CVAE_E_UNSUPPORTED;
     if (!workspace) return CVAE_E_NULLPTR;
     if (workspace_bytes < cvae_conv_wgrad_c1_workspace_bytes(Cs, nd)) return CVAE_E_WORKSPACE;
@@ -449,17 +478,22 @@ int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, vo
     if (n_split < 1) n_split = 1;
     dim3 grid((unsigned)n_split, (unsigned)(Cs / 32), 1);
     float* ws = (float*)workspace;
-#define LAUNCH_WG_C1(T, ND)                                                                                                           \
-    hipLaunchKernelGGL((wgrad_c1_kernel<T, ND>), grid, dim3(256), 0, stream, (const T*)S, (const T*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
-                       (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split)
-    if (dtype == CVAE_BF16) { if (nd == 3) LAUNCH_WG_C1(bf16, 3); else LAUNCH_WG_C1(bf16, 2); }
-    else { if (nd == 3) LAUNCH_WG_C1(float, 3); else LAUNCH_WG_C1(float, 2); }
-#undef LAUNCH_WG_C1
-    CVAE_CHECK_LAUNCH();
     const int rw = ((nd == 3) ? 64 : 32) + 1;
-    dim3 fgrid((unsigned)((32 * rw + 15) / 16), (unsigned)(Cs / 32), 1);
-    if (nd == 3) hipLaunchKernelGGL(wgrad_c1_finish_kernel<3>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split);
-    else hipLaunchKernelGGL(wgrad_c1_finish_kernel<2>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split);
+    float* lsum_ws = dbias_l ? ws + (size_t)1024 * 32 * rw : nullptr;
+#define LAUNCH_WG_C1(T, ND)                                                                                                           \
+    if (lsum_ws) LAUNCH_WG_C1_(T, ND, true); else LAUNCH_WG_C1_(T, ND, false)
+#define LAUNCH_WG_C1_(T, ND, LS)                                                                                                      \
+    hipLaunchKernelGGL((wgrad_c1_kernel<T, ND, LS>), grid, dim3(256), 0, stream, (const T*)S, (const T*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
+                       (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split, lsum_ws)
+    if (dtype == CVAE_BF16) { if (nd == 3) { LAUNCH_WG_C1(bf16, 3); } else { LAUNCH_WG_C1(bf16, 2); } }
+    else { if (nd == 3) { LAUNCH_WG_C1(float, 3); } else { LAUNCH_WG_C1(float, 2); } }
+#undef LAUNCH_WG_C1
+#undef LAUNCH_WG_C1_
+    CVAE_CHECK_LAUNCH();
+    const int main_blocks = (32 * rw + 15) / 16;
+    dim3 fgrid((unsigned)(main_blocks + (dbias_l ? 1 : 0)), (unsigned)(Cs / 32), 1);
+    if (nd == 3) hipLaunchKernelGGL(wgrad_c1_finish_kernel<3>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split, lsum_ws, dbias_l, main_blocks);
+    else hipLaunchKernelGGL(wgrad_c1_finish_kernel<2>, fgrid, dim3(256), 0, stream, ws, dW, dbias, (int)n_split, lsum_ws, dbias_l, main_blocks);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

@@ -921,7 +921,7 @@ int cvae_conv_down_c1(const void* L, const float* w, const float* bias, const vo
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd);
-int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
+int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
                        int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
 
 #ifdef CVAE_STAMP
@@ -1095,12 +1095,16 @@ extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* d
     }
     if (!S || !L) return CVAE_E_NULLPTR;
     if (Cl == 1) {
+        float* dbias_l = nullptr;
         if (dbias && dbias_side == 1) {                      // ConvTranspose to one channel: its bias gradient is the plain sum of L
-            const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, 1, dtype, stream);
-            if (rcb != CVAE_OK) return rcb;
+            if (lh == 2 * sh && lw == 2 * sw && (nd != 3 || ld == 2 * sd)) dbias_l = dbias;     // fused: the kernel reads all of L anyway
+            else {
+                const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, 1, dtype, stream);
+                if (rcb != CVAE_OK) return rcb;
+            }
             dbias = nullptr;
         }
-        return cvae_conv_wgrad_c1(S, L, dW, dbias, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);   // S-side bias sum fused (S^T . ones)
+        return cvae_conv_wgrad_c1(S, L, dW, dbias, dbias_l, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);   // S-side bias sum fused (S^T . ones)
     }
     if (Cs % 64 || Cl % 32) return CVAE_E_UNSUPPORTED;
     int bias_mode = dbias ? (dbias_side ? 2 : 1) : 0;

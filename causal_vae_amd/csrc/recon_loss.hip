@@ -56,10 +56,23 @@ __device__ __forceinline__ float2 even_w(int o) { return o == 0 ? make_float2(0.
 
 // MODE 0: dst = up(src).  MODE 1: *acc_out += sum (up(src) - xin)^2.  MODE 2: t1[b][od][oh][x] = sum_ow Ww(ow -> x) gs (up(src) - xin),
 // gs = 2 * (*gout) * gscale.  D == d (2D tensors) leaves the depth axis untouched.
+struct SmallBwd {                                            // the ELBO's small terms, ridden along the backward launch (MODE 2)
+    const float *m_hat, *m, *mu, *logvar;
+    float *d_mhat, *dmu, *dlv;
+    float gamma;
+    int n_m, n_z, main_blocks;
+};
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ src, const float* __restrict__ xin, float* __restrict__ dst,
                                                          float* __restrict__ acc_out, const float* __restrict__ gout, float gscale,
-                                                         int B, int d, int h, int w, int D, int H, int W) {
+                                                         int B, int d, int h, int w, int D, int H, int W, SmallBwd sb) {
+    if (MODE == 2 && sb.dmu && (int)blockIdx.x == sb.main_blocks) {     // extra block of the backward launch: the small ELBO terms' gradients
+        // d m_hat = 2 g gamma (m_hat - m); d mu = g mu; d logvar = 0.5 g (exp(logvar) - 1), g = *gout (1 when null)
+        const float g = gout ? *gout : 1.f;
+        for (int i = threadIdx.x; i < sb.n_m; i += 256) sb.d_mhat[i] = 2.f * g * sb.gamma * (sb.m_hat[i] - sb.m[i]);
+        for (int i = threadIdx.x; i < sb.n_z; i += 256) { sb.dmu[i] = g * sb.mu[i]; sb.dlv[i] = 0.5f * g * (expf(sb.logvar[i]) - 1.f); }
+        return;
+    }
     constexpr int J0 = (MODE == 2) ? -1 : 0, NJ = (MODE == 2) ? 10 : 8;     // outputs along w per row: local j <-> ow = ow0 + J0 + j
     const bool sdz = D != d;
     const float sw = (float)w / (float)W;
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
         sse = wave_sum(sse);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sse;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(acc_out, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) acc_out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];     // per-block partial: summed in a fixed order by elbo_finish_kernel
     }
 }
 
@@ -195,33 +208,24 @@ __global__ __launch_bounds__(256) void up2x_bwd_b_kernel(const float* __restrict
     for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(acc[q]);
 }
 
-// out4 = {0, 0, sum (m_hat - m)^2, -0.5 sum (1 + logvar - mu^2 - exp(logvar))}: the small terms of the ELBO in one block, which
-// also zeroes the accumulator of the reconstruction term (out4[1]).
-__global__ __launch_bounds__(256) void elbo_small_fwd_kernel(const float* __restrict__ m_hat, const float* __restrict__ m, const float* __restrict__ mu,
-                                                             const float* __restrict__ logvar, float* __restrict__ out4, int n_m, int n_z) {
-    __shared__ float red[2][4];
-    float sm = 0.f, sk = 0.f;
+// out4 = {loss, recon, m_loss, kld}: recon = sum of the per-block partial sums of up2x_block_kernel<MODE 1> (fixed order: the loss is
+// bit-reproducible), m_loss = sum (m_hat - m)^2, kld = -0.5 sum (1 + logvar - mu^2 - exp(logvar)), loss = recon + gamma m_loss + kld.
+__global__ __launch_bounds__(256) void elbo_finish_kernel(const float* __restrict__ partial, int n_partial, const float* __restrict__ m_hat,
+                                                          const float* __restrict__ m, const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                          float gamma, float* __restrict__ out4, int n_m, int n_z) {
+    __shared__ float red[3][4];
+    float sr = 0.f, sm = 0.f, sk = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) sr += partial[i];
     for (int i = threadIdx.x; i < n_m; i += 256) { const float df = m_hat[i] - m[i]; sm += df * df; }
     for (int i = threadIdx.x; i < n_z; i += 256) sk += 1.f + logvar[i] - mu[i] * mu[i] - expf(logvar[i]);
-    sm = wave_sum(sm); sk = wave_sum(sk);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sm; red[1][threadIdx.x >> 6] = sk; }
+    sr = wave_sum(sr); sm = wave_sum(sm); sk = wave_sum(sk);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sr; red[1][threadIdx.x >> 6] = sm; red[2][threadIdx.x >> 6] = sk; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out4[0] = 0.f; out4[1] = 0.f;
-        out4[2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        out4[3] = -0.5f * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        const float recon = red[0][0] + red[0][1] + red[0][2] + red[0][3], ml = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float kld = -0.5f * (red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+        out4[0] = recon + gamma * ml + kld; out4[1] = recon; out4[2] = ml; out4[3] = kld;
     }
-}
-// d m_hat = 2 g gamma (m_hat - m); d mu = g mu; d logvar = 0.5 g (exp(logvar) - 1), g = *gout (1 when null)
-__global__ __launch_bounds__(256) void elbo_small_bwd_kernel(const float* __restrict__ m_hat, const float* __restrict__ m, const float* __restrict__ mu,
-                                                             const float* __restrict__ logvar, const float* __restrict__ gout, float gamma,
-                                                             float* __restrict__ d_mhat, float* __restrict__ dmu, float* __restrict__ dlv, int n_m, int n_z) {
-    const float g = gout ? *gout : 1.f;
-    for (int i = threadIdx.x; i < n_m; i += 256) d_mhat[i] = 2.f * g * gamma * (m_hat[i] - m[i]);
-    for (int i = threadIdx.x; i < n_z; i += 256) { dmu[i] = g * mu[i]; dlv[i] = 0.5f * g * (expf(logvar[i]) - 1.f); }
-}
-__global__ void elbo_combine_kernel(float* __restrict__ out4, float gamma) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) out4[0] = out4[1] + gamma * out4[2] + out4[3];
 }
 
 bool up2x_ok(int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W) {
@@ -236,27 +240,27 @@ extern "C" int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, 
     if (!up2x_ok(B, d, h, w, D, H, W)) return CVAE_E_UNSUPPORTED;
     if (!src || !dst) return CVAE_E_NULLPTR;
     const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
-    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
-    else if (dtype == CVAE_F32) hipLaunchKernelGGL((up2x_block_kernel<float, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
+    else if (dtype == CVAE_F32) hipLaunchKernelGGL((up2x_block_kernel<float, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
     else return CVAE_E_DTYPE;
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
 
+extern "C" int64_t cvae_elbo_up2x_partials(int64_t B, int64_t d, int64_t h, int64_t w) { return (B * d * h * (w / 4) + 255) / 256; }
+
 extern "C" int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                                  float* out4, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z,
-                                  int dtype, void* stream) {
+                                  float* out4, float* partial, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
+                                  int64_t n_z, int dtype, void* stream) {
     if (!up2x_ok(B, d, h, w, D, H, W) || n_m < 0 || n_z < 0 || n_m > (1 << 24) || n_z > (1 << 24)) return CVAE_E_UNSUPPORTED;
-    if (!src || !x || !m_hat || !m || !mu || !logvar || !out4) return CVAE_E_NULLPTR;
+    if (!src || !x || !m_hat || !m || !mu || !logvar || !out4 || !partial) return CVAE_E_NULLPTR;
     if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(elbo_small_fwd_kernel, dim3(1), dim3(256), 0, st, m_hat, m, mu, logvar, out4, (int)n_m, (int)n_z);
+    const unsigned grid = (unsigned)cvae_elbo_up2x_partials(B, d, h, w);
+    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 1>), dim3(grid), dim3(256), 0, st, (const bf16*)src, x, nullptr, partial, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
+    else hipLaunchKernelGGL((up2x_block_kernel<float, 1>), dim3(grid), dim3(256), 0, st, (const float*)src, x, nullptr, partial, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
     CVAE_CHECK_LAUNCH();
-    const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
-    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 1>), dim3(grid), dim3(256), 0, st, (const bf16*)src, x, nullptr, out4 + 1, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
-    else hipLaunchKernelGGL((up2x_block_kernel<float, 1>), dim3(grid), dim3(256), 0, st, (const float*)src, x, nullptr, out4 + 1, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
-    CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(elbo_combine_kernel, dim3(1), dim3(64), 0, st, out4, gamma);
+    hipLaunchKernelGGL(elbo_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, (int)grid, m_hat, m, mu, logvar, gamma, out4, (int)n_m, (int)n_z);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
@@ -268,15 +272,14 @@ extern "C" int cvae_elbo_up2x_bwd(const void* src, const float* x, const float* 
     if (!src || !x || !m_hat || !m || !mu || !logvar || !t1 || !dsrc || !d_mhat || !dmu || !dlv) return CVAE_E_NULLPTR;
     if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(elbo_small_bwd_kernel, dim3(1), dim3(256), 0, st, m_hat, m, mu, logvar, g_loss, gamma, d_mhat, dmu, dlv, (int)n_m, (int)n_z);
-    CVAE_CHECK_LAUNCH();
     const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
+    const SmallBwd sb{m_hat, m, mu, logvar, d_mhat, dmu, dlv, gamma, (int)n_m, (int)n_z, (int)grid};
     if (dtype == CVAE_BF16) {
-        hipLaunchKernelGGL((up2x_block_kernel<bf16, 2>), dim3(grid), dim3(256), 0, st, (const bf16*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        hipLaunchKernelGGL((up2x_block_kernel<bf16, 2>), dim3(grid + 1), dim3(256), 0, st, (const bf16*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, sb);
         CVAE_CHECK_LAUNCH();
         hipLaunchKernelGGL(up2x_bwd_b_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const float*)t1, (bf16*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H);
     } else {
-        hipLaunchKernelGGL((up2x_block_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W);
+        hipLaunchKernelGGL((up2x_block_kernel<float, 2>), dim3(grid + 1), dim3(256), 0, st, (const float*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, sb);
         CVAE_CHECK_LAUNCH();
         hipLaunchKernelGGL(up2x_bwd_b_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)t1, (float*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H);
     }

@@ -695,8 +695,8 @@ class ElboUp2x(torch.autograd.Function):
         if m_hat.shape != m.shape or mu.shape != logvar.shape:
             raise RuntimeError(f"The size of tensor a {tuple(m_hat.shape)} must match the size of tensor b {tuple(m.shape)}")
         B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
-        buf = torch.empty(4, dtype=torch.float32, device=x.device)
-        check(lib.cvae_elbo_up2x_fwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), float(gamma), ptr(buf), B, d, h, w, D, H, W,
+        buf = torch.empty(4 + lib.cvae_elbo_up2x_partials(B, d, h, w), dtype=torch.float32, device=x.device)
+        check(lib.cvae_elbo_up2x_fwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), float(gamma), ptr(buf), buf.data_ptr() + 16, B, d, h, w, D, H, W,
                                      m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_fwd")
         ctx.save_for_backward(src, x, m_hat, m, mu, logvar)
         ctx.gamma = float(gamma)

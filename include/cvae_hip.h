@@ -108,10 +108,12 @@ int cvae_up2x_supported(int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, i
 /* dst fp32 [B][D][H][W] = F.interpolate(src, (D, H, W), 'trilinear' | 'bilinear', align_corners=False) */
 int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int dtype, void* stream);
 /* out4 = {loss, recon, m_loss, kld}: recon = sum (up(src) - x)^2, m_loss = sum (m_hat - m)^2 (n_m elements),
- * kld = -0.5 sum (1 + logvar - mu^2 - exp(logvar)) (n_z elements), loss = recon + gamma * m_loss + kld. */
+ * kld = -0.5 sum (1 + logvar - mu^2 - exp(logvar)) (n_z elements), loss = recon + gamma * m_loss + kld.
+ * partial: scratch of cvae_elbo_up2x_partials(B, d, h, w) floats (per-workgroup sums, added in a fixed order: no atomics). */
+int64_t cvae_elbo_up2x_partials(int64_t B, int64_t d, int64_t h, int64_t w);
 int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                       float* out4, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z,
-                       int dtype, void* stream);
+                       float* out4, float* partial, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
+                       int64_t n_z, int dtype, void* stream);
 /* Gradients of `loss` scaled by the device scalar *g_loss (NULL = 1): dsrc (src's dtype), d_mhat, dmu, dlv.
  * t1: scratch of B*D*H*w floats. */
 int cvae_elbo_up2x_bwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
