@@ -60,6 +60,7 @@ SIGNATURES = {
     "cvae_bn1d_train_bwd": [_p] * 8 + [_i64, _i64, _p],
     "cvae_bn1d_eval_fwd": [_p] * 6 + [_i64, _i64, _f, _p],
     "cvae_philox_normal": [_p, _i64, _u64, _u64, _p, _p],
+    "cvae_philox_normal_advance": [_p, _i64, _u64, _u64, _p, _p],
     "cvae_reparam_kld_fwd": [_p, _p, _p, _p, _p, _i64, _p],
     "cvae_reparam_kld_bwd": [_p, _p, _f] + [_p] * 5 + [_i64, _p],
     "cvae_sse_fwd": [_p, _p, _p, _i64, _p],

@@ -25,7 +25,7 @@ def train_step(model, optimizer, x, m, t, eps=None, gamma=2000.0, grad_hook=None
     else:
         recon_x, m_hat, mu, logvar = model(x, m, t) if eps is None else model(x, m, t, eps=eps)
         loss, l_recon, l_m = loss_function(recon_x, x, m_hat, m, mu, logvar, gamma)
-    loss.backward()
+    ops.backward_from(loss)
     if grad_hook is not None:
         grad_hook()
     optimizer.step()

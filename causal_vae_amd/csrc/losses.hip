@@ -342,8 +342,15 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
-__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, const int* __restrict__ call_dev) {
+// ADVANCE (single-block launches only): after every thread has read the call counter, thread 0 increments it — the draw and the
+// "next call draws fresh numbers" bookkeeping in one launch instead of two.
+template <bool ADVANCE>
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, int* __restrict__ call_dev) {
     if (call_dev) offset += ((uint64_t)(unsigned)(*call_dev)) << 24;       // device-side call counter: advances under graph replay
+    if (ADVANCE) {
+        __syncthreads();
+        if (threadIdx.x == 0) *call_dev += 1;
+    }
     const int64_t n4 = (n + 3) >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t ctr = offset + (uint64_t)i;
@@ -365,7 +372,21 @@ extern "C" int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t
     if (n < 0) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!out) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(philox_normal_kernel, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, call_counter);
+    hipLaunchKernelGGL(philox_normal_kernel<false>, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, (int*)call_counter);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+__global__ void add_int_kernel(int* c, int delta);
+extern "C" int cvae_philox_normal_advance(float* out, int64_t n, uint64_t seed, uint64_t offset, int* call_counter, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (!call_counter) return CVAE_E_NULLPTR;
+    if (n > 0 && !out) return CVAE_E_NULLPTR;
+    if (n > 0 && n <= 16384) {                               // small draws (the latent noise): one block does both
+        hipLaunchKernelGGL(philox_normal_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, call_counter);
+    } else {
+        if (n > 0) hipLaunchKernelGGL(philox_normal_kernel<false>, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, call_counter);
+        hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, call_counter, 1);
+    }
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

@@ -10,6 +10,8 @@ graph A = zero_grad..backward + pack of the flat gradient bucket, graph B = unpa
 """
 import torch
 
+from . import ops
+
 from ._lib import CvaeError
 from .optim import FusedAdam
 
@@ -54,7 +56,7 @@ class GraphedTrainStep:
             res = self.model.forward_elbo(self.x, self.m, self.t)
         else:
             res = self.loss_fn(self.model(self.x, self.m, self.t), self.x, self.m)
-        res[0].backward()
+        ops.backward_from(res[0])
         return tuple(r.detach() for r in res)
 
     def _reduce_eager(self):

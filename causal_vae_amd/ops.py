@@ -65,6 +65,20 @@ def _scalar(like):
     return torch.zeros((), dtype=torch.float32, device=like.device)
 
 
+_ONES = {}
+
+
+def backward_from(loss):
+    """loss.backward() without the fill kernel autograd launches for the implicit d(loss) = 1: the ones scalar is kept per device."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        if not (loss.is_cuda and torch.cuda.is_current_stream_capturing()):      # a tensor born inside a capture lives in that graph's pool
+            _ONES[key] = one
+    loss.backward(one)
+
+
 # ------------------------------------------------------------------------------------------------ layout plumbing
 class ToChannelsLast(torch.autograd.Function):
     """NC(D)HW fp32 -> channels-last [B, D, H, W, C] in `dtype` (cvae_ncs_to_nsc)."""
@@ -525,10 +539,8 @@ def philox_normal(shape, seed, offset, device, call_counter=None):
     """N(0,1) draws.  call_counter: optional device int32 tensor added (<< 24) to the offset and incremented afterwards —
     the device-side call count that keeps a captured HIP graph drawing fresh numbers on every replay."""
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(lib.cvae_philox_normal(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, ptr(call_counter), stream()),
-          "philox_normal")
-    if call_counter is not None:
-        check(lib.cvae_counter_add(ptr(call_counter), 1, stream()), "counter_add")
+    fn = lib.cvae_philox_normal if call_counter is None else lib.cvae_philox_normal_advance
+    check(fn(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, ptr(call_counter), stream()), "philox_normal")
     return out
 
 

@@ -231,6 +231,8 @@ int cvae_bn1d_eval_fwd(const float* x, const float* w, const float* b, const flo
 /* eps ~ N(0,1): Philox4x32-10 + Box-Muller, counter-based (seed, offset) -> reproducible per launch.  call_counter
  * (optional device int): offset += *call_counter << 24, so a captured HIP graph draws fresh numbers on every replay. */
 int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const int* call_counter, void* stream);
+/* The same draw followed by *call_counter += 1 (one launch for n <= 16384): what EpsSource issues once per forward pass. */
+int cvae_philox_normal_advance(float* out, int64_t n, uint64_t seed, uint64_t offset, int* call_counter, void* stream);
 /* z = mu + eps*exp(logvar/2) (if z != NULL);  *kld += -0.5*sum(1 + logvar - mu^2 - exp(logvar)) (if kld != NULL). */
 int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* stream);
 /* dmu = dz + gk*mu ; dlogvar = dz*eps*0.5*exp(logvar/2) + gk*0.5*(exp(logvar) - 1), gk = *gkld * gk_scale;
