@@ -236,6 +236,116 @@ __global__ __launch_bounds__(256) void up_c1_kernel(const T* __restrict__ S, con
     }
 }
 
+// -------------------------------------------------------------------------------------- up, Cl == 1, bf16 on the MFMA
+// The same product as a GEMM per source voxel q: out[2 q + p] = sum_{o in {-1,0,1}^nd} sum_c S[q + o][c] Wm[(o, c)][p], with
+// Wm[(o, c)][p] = W[c][tap(p, o)] where parity p reaches neighbour o (per dimension o = p - 1 + a, a in {0, 1}, tap k = 3 - p - 2 a)
+// and 0 elsewhere: M = voxels, K = 3^nd * 32, N = 2^nd parities (rows 0..7 of a 32-row MFMA tile; the other rows repeat them and are
+// ignored).  8/27 of Wm is non-zero, but the layer is ~3 us of MFMA time either way, against ~30 us for the scalar form above, which
+// was bound by its 1024 LDS weight reads per thread.  Weights ride as the A operand, so D rows are parities and D columns voxels: lane
+// (r, h) ends with the 2 x 2 (py, px) outputs of voxel r on plane pz = h — two 4-byte stores.
+// LDS: the 32-channel halo as 4 planes of 16-byte pieces (plane = channel piece: consecutive voxels are 16 B apart, conflict-free
+// ds_read_b128), and Wm^T as [chunk = (o, channel half)][h][parity] 16-byte rows built in-kernel from the fp32 master.
+template <int ND>
+__global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_h,
+                                                         int tiles_w, int act) {
+    constexpr int TD = (ND == 3) ? 4 : 1, TH = (ND == 3) ? 8 : 16, TW = (ND == 3) ? 8 : 16;     // 256 voxels
+    constexpr int ID = (ND == 3) ? TD + 2 : 1, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
+    constexpr int NNB = (ND == 3) ? 27 : 9, NCH = NNB * 2, TAPS = (ND == 3) ? 64 : 16, NPAR = (ND == 3) ? 8 : 4;
+    constexpr int HN = (NPOS * 4 + 255) / 256;
+    __shared__ uint4 halo[4][NPOS];
+    __shared__ __attribute__((aligned(16))) bf16 wfr[NCH * 2 * 8 * 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5, b = blockIdx.z;
+    int tile = blockIdx.x;
+    const int tw_i = tile % tiles_w; tile /= tiles_w;
+    const int th_i = tile % tiles_h; tile /= tiles_h;
+    const int o0d = tile * TD, o0h = th_i * TH, o0w = tw_i * TW;
+    // ---- halo: all loads in flight, then the weight rows are built while they land ----
+    uint4 hv[HN];
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+        const int it = t + i * 256, piece = it & 3, pos = min(it >> 2, NPOS - 1);
+        const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
+        const int gz = (ND == 3) ? o0d - 1 + z : 0, gy = o0h - 1 + y, gx = o0w - 1 + x;
+        const bool ok = (gz >= 0) & (gz < sd) & (gy >= 0) & (gy < sh) & (gx >= 0) & (gx < sw);
+        const uint4 v = *(const uint4*)(S + ((((size_t)b * sd + min(max(gz, 0), sd - 1)) * sh + min(max(gy, 0), sh - 1)) * sw + min(max(gx, 0), sw - 1)) * 32 + piece * 8);
+        hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int row = t; row < NCH * 2 * 8; row += 256) {      // one 16-byte row (8 channels of one (chunk, h, parity)) per pass
+        const int p = row & 7, hh = (row >> 3) & 1, chunk = row >> 4, nb = chunk >> 1, kc = chunk & 1;
+        const int c0 = kc * 16 + 8 * hh;
+        const int ox = nb % 3 - 1, oy = nb / 3 % 3 - 1, oz = (ND == 3) ? nb / 9 - 1 : 0;
+        const int px = p & 1, py = (p >> 1) & 1, pz = (ND == 3) ? (p >> 2) : 0;
+        const int ax = ox - px + 1, ay = oy - py + 1, az = oz - pz + 1;
+        const bool valid = (p < NPAR) & (ax >= 0) & (ax <= 1) & (ay >= 0) & (ay <= 1) & ((ND == 2) | ((az >= 0) & (az <= 1)));
+        const int kw = 3 - px - 2 * ax, kh = 3 - py - 2 * ay, kd = (ND == 3) ? 3 - pz - 2 * az : 0;
+        union { uint4 u; bf16 e[8]; } o;
+        o.u = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) {
+            const float* wp = w + c0 * TAPS + (kd * 4 + kh) * 4 + kw;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.e[j] = from_f32<bf16>(wp[j * TAPS]);
+        }
+        *(uint4*)(wfr + row * 8) = o.u;
+    }
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+        const int it = t + i * 256;
+        if (it < NPOS * 4) halo[it & 3][it >> 2] = hv[i];
+    }
+    __syncthreads();
+    // ---- each wave: 2 sub-tiles of 32 voxels, 2 * 3^nd k-chunks of 16 channels ----
+    int pb[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int m = (wave * 2 + ms) * 32 + r;
+        pb[ms] = ((m / (TW * TH)) * IH + m / TW % TH) * IW + m % TW;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ms][e] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) {
+        const int off = (((ND == 3) ? nb / 9 : 0) * IH + nb / 3 % 3) * IW + nb % 3;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            union { uint4 u; bf16x8 v; } a, b0, b1;
+            a.u = *(const uint4*)(wfr + (((nb * 2 + kc) * 2 + h) * 8 + (r & 7)) * 8);
+            b0.u = halo[kc * 2 + h][pb[0] + off];
+            b1.u = halo[kc * 2 + h][pb[1] + off];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b0.v, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b1.v, acc[1], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: D row (parity) = e + 4 h for e < 4: lane (r, h) holds (py, px) = (e >> 1, e & 1) on plane pz = h (2D: h == 0 only) ----
+    const float bz = bias ? bias[0] : 0.f;
+    const int ld = (ND == 3) ? 2 * sd : 1, lh = 2 * sh, lw = 2 * sw;
+    if (ND == 2 && h == 1) return;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int m = (wave * 2 + ms) * 32 + r;
+        const int qz = o0d + m / (TW * TH), qy = o0h + m / TW % TH, qx = o0w + m % TW;
+        if (qz >= sd || qy >= sh || qx >= sw) continue;
+        const int lz = (ND == 3) ? 2 * qz + h : 0;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const size_t idx = (((size_t)b * ld + lz) * lh + 2 * qy + py) * lw + 2 * qx;
+            float v0 = apply_act(acc[ms][2 * py] + bz, act), v1 = apply_act(acc[ms][2 * py + 1] + bz, act);
+            if (mask) {
+                union { uint32_t u; bf16 e[2]; } mk;
+                mk.u = *(const uint32_t*)(mask + idx);
+                if (!(to_f32(mk.e[0]) > 0.f)) v0 = 0.f;
+                if (!(to_f32(mk.e[1]) > 0.f)) v1 = 0.f;
+            }
+            union { uint32_t u; bf16 e[2]; } o;
+            o.e[0] = from_f32<bf16>(v0); o.e[1] = from_f32<bf16>(v1);
+            *(uint32_t*)(L + idx) = o.u;
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------- wgrad, Cl == 1
 // dW[cs][tap] = sum_pos S[pos][cs] * L[2 pos - 1 + k(tap)]  ==  S^T [32 x K] . im2col(L) [K x taps],  K = positions.
 //   bf16: A fragments (S^T) by the transposing LDS read; B fragments gathered from the 1-channel halo (8 stride-2
@@ -447,12 +557,21 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
     const int64_t n = B * sd * sh * sw;                     // one thread per (source voxel, channel half)
     if (n >= ((int64_t)1 << 30) || ld != 2 * sd && nd == 3 || lh != 2 * sh || lw != 2 * sw) return CVAE_E_UNSUPPORTED;
+    if (dtype == CVAE_BF16) {                               // MFMA form
+        const int td = (nd == 3) ? 4 : 1, th = (nd == 3) ? 8 : 16, tw = (nd == 3) ? 8 : 16;
+        const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
+        if ((int64_t)tiles_d * tiles_h * tiles_w > 0x7fffffff || B > 65535) return CVAE_E_BADSHAPE;
+        dim3 mgrid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
+        if (nd == 3) hipLaunchKernelGGL(up_c1_mfma_kernel<3>, mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_h, tiles_w, act);
+        else hipLaunchKernelGGL(up_c1_mfma_kernel<2>, mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_h, tiles_w, act);
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
     dim3 grid((unsigned)((2 * n + 255) / 256));
 #define LAUNCH_UP_C1(T, ND)                                                                                                          \
     hipLaunchKernelGGL((up_c1_kernel<T, ND, 32>), grid, dim3(256), 0, stream, (const T*)S, w, bias, (const T*)mask, (T*)L, (int)B, (int)sd,   \
                        (int)sh, (int)sw, (int)ld, (int)lh, (int)lw, act)
-    if (dtype == CVAE_BF16) { if (nd == 3) LAUNCH_UP_C1(bf16, 3); else LAUNCH_UP_C1(bf16, 2); }
-    else { if (nd == 3) LAUNCH_UP_C1(float, 3); else LAUNCH_UP_C1(float, 2); }
+    if (nd == 3) LAUNCH_UP_C1(float, 3); else LAUNCH_UP_C1(float, 2);      // bf16 took the MFMA form above
 #undef LAUNCH_UP_C1
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
