@@ -266,25 +266,54 @@ __global__ __launch_bounds__(256) void fc2_fwd_kernel(TailDims d, TailParams p, 
     extern __shared__ float lds[];
     const int M = d.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* h1s = lds;                                        // [M][N1]
-    for (int i = tid; i < M * d.N1; i += 256) {
-        float v[8];                                          // KS <= 8: all slab loads of an element are issued together
+    // Dependent global round trips (~1.5 us each) are what these small kernels consist of: the first HO * 64 elements of this wave's
+    // W2 row are requested before the h1 rebuild, so they travel together with the partial-sum loads.
+    constexpr int HO = 8;
+    const int n = blockIdx.x * 4 + wave;
+    float wpre[HO];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) v[ks] = ks < d.KS ? partial[(size_t)ks * M * d.N1 + i] : 0.f;
-        float acc = p.b1[i % d.N1];
+    for (int j = 0; j < HO; ++j) wpre[j] = p.W2[(size_t)min(n, d.N2 - 1) * d.N1 + min(lane + 64 * j, d.N1 - 1)];
+    // The struct's pointers carry no __restrict__, so a load placed after a global store waits for it: every loop below that both loads
+    // and stores global memory batches its loads first (U iterations' worth in registers), then computes and stores.
+    constexpr int U = 4;
+    for (int base = tid; base < M * d.N1; base += 256 * U) {
+        float v[U][8], bb[U];                                // KS <= 8 slabs per element
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc += v[ks];
-        acc = fmaxf(acc, 0.f);
-        h1s[i] = acc;
-        if (blockIdx.x == 0) sv.h1[i] = acc;
+        for (int u = 0; u < U; ++u) {
+            const int ii = min(base + u * 256, M * d.N1 - 1);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) v[u][ks] = ks < d.KS ? partial[(size_t)ks * M * d.N1 + ii] : 0.f;
+            bb[u] = p.b1[ii % d.N1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * 256;
+            if (i < M * d.N1) {
+                float acc = bb[u];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc += v[u][ks];
+                acc = fmaxf(acc, 0.f);
+                h1s[i] = acc;
+                if (blockIdx.x == 0) sv.h1[i] = acc;
+            }
+        }
     }
     __syncthreads();
-    const int n = blockIdx.x * 4 + wave;
     if (n >= d.N2) return;
     float acc[BN_MAXM];
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
+#pragma unroll
+    for (int j = 0; j < HO; ++j) {
+        const int k = lane + 64 * j;
+        if (k < d.N1) {
+#pragma unroll
+            for (int m = 0; m < BN_MAXM; ++m)
+                if (m < M) acc[m] += wpre[j] * h1s[m * d.N1 + k];
+        }
+    }
 #pragma unroll 8
-    for (int k = lane; k < d.N1; k += 64) {
+    for (int k = lane + 64 * HO; k < d.N1; k += 64) {
         const float w = p.W2[(size_t)n * d.N1 + k];
 #pragma unroll
         for (int m = 0; m < BN_MAXM; ++m)
@@ -306,15 +335,31 @@ __global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p,
     if (blockIdx.x == 0 && dzm_acc)                          // the backward accumulates d(zm) here with atomics: leave it zeroed
         for (int i = tid; i < DZM_GROUPS * M * K4; i += 256) dzm_acc[i] = 0.f;
     float* h2s = lds;                                        // [M][N2]
+    constexpr int HO = 4;                                    // this wave's first HO * 64 elements of both weight rows travel with the h2 loads
+    const int j = blockIdx.x * 4 + wave;
+    float wmp[HO], wlp[HO];
+#pragma unroll
+    for (int u = 0; u < HO; ++u) {
+        const size_t o = (size_t)min(j, d.Z - 1) * d.N2 + min(lane + 64 * u, d.N2 - 1);
+        wmp[u] = p.Wmu[o]; wlp[u] = p.Wlv[o];
+    }
     for (int i = tid; i < M * d.N2; i += 256) h2s[i] = sv.h2[i];
     __syncthreads();
-    const int j = blockIdx.x * 4 + wave;
     if (j >= d.Z) return;
     float am[BN_MAXM], al[BN_MAXM];
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m) { am[m] = 0.f; al[m] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < HO; ++u) {
+        const int k = lane + 64 * u;
+        if (k < d.N2) {
+#pragma unroll
+            for (int m = 0; m < BN_MAXM; ++m)
+                if (m < M) { am[m] += wmp[u] * h2s[m * d.N2 + k]; al[m] += wlp[u] * h2s[m * d.N2 + k]; }
+        }
+    }
 #pragma unroll 4
-    for (int k = lane; k < d.N2; k += 64) {
+    for (int k = lane + 64 * HO; k < d.N2; k += 64) {
         const float wm = p.Wmu[(size_t)j * d.N2 + k], wl = p.Wlv[(size_t)j * d.N2 + k];
 #pragma unroll
         for (int m = 0; m < BN_MAXM; ++m)
@@ -522,34 +567,62 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
     float* dlv = dmu + M * Z;            // [M][Z]
     float* h2c = dlv + M * Z;            // [M][64]  this block's columns of h2
     float* red = h2c + M * 64;           // [4][M][64]
-    load_dzm(dzm_part, dzs, M * K4);
+    // Everything this block reads from global memory is requested up front (first batch of weight rows, the element-wise operands of
+    // the first 256 (m, j) pairs, d(zm), this block's h2 columns): one round trip instead of four dependent ones.
     const int k0 = blockIdx.x * 64;
+    const int kl = tid & 63, q = tid >> 6, k = k0 + kl, kk = min(k, d.N2 - 1);
+    constexpr int U = 8;
+    float wm0[U], wl0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int nn = min(q + 4 * u, Z - 1);
+        wm0[u] = p.Wmu[(size_t)nn * d.N2 + kk]; wl0[u] = p.Wlv[(size_t)nn * d.N2 + kk];
+    }
+    const int ie = min(tid, M * Z - 1);
+    const float e_eps = eps[ie], e_lv = sv.logvar[ie], e_gm = g_mu ? g_mu[ie] : 0.f, e_gl = g_logvar ? g_logvar[ie] : 0.f;
+    load_dzm(dzm_part, dzs, M * K4);
     for (int i = tid; i < M * 64; i += 256) h2c[i] = (k0 + (i & 63) < d.N2) ? sv.h2[(i >> 6) * d.N2 + k0 + (i & 63)] : 0.f;
     __syncthreads();
     for (int i = tid; i < M * Z; i += 256) {
         const int m = i / Z, j = i - m * Z;
         const float dz = dzs[m * K4 + j];
-        dmu[i] = dz + (g_mu ? g_mu[i] : 0.f);
-        dlv[i] = dz * eps[i] * 0.5f * __expf(0.5f * sv.logvar[i]) + (g_logvar ? g_logvar[i] : 0.f);
+        const bool first = i < 256;                          // i == tid: operands already in registers
+        const float ve = first ? e_eps : eps[i], vl = first ? e_lv : sv.logvar[i];
+        const float vgm = first ? e_gm : (g_mu ? g_mu[i] : 0.f), vgl = first ? e_gl : (g_logvar ? g_logvar[i] : 0.f);
+        dmu[i] = dz + vgm;
+        dlv[i] = dz * ve * 0.5f * __expf(0.5f * vl) + vgl;
     }
     __syncthreads();
-    const int kl = tid & 63, q = tid >> 6, k = k0 + kl;
     float acc[BN_MAXM];
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
     if (k < d.N2) {
-        for (int n = q; n < Z; n += 4) {                     // thread (k, q): rows n = q, q + 4, ..
-            const float wm = p.Wmu[(size_t)n * d.N2 + k], wl = p.Wlv[(size_t)n * d.N2 + k];
-            float gm = 0.f, gl = 0.f;
+        for (int n0 = q; n0 < Z; n0 += 4 * U) {              // thread (k, q): rows n = q, q + 4, ..; loads of U rows first (see fc2_fwd)
+            float wm[U], wl[U];
 #pragma unroll
-            for (int m = 0; m < BN_MAXM; ++m)
-                if (m < M) {
-                    acc[m] += dmu[m * Z + n] * wm + dlv[m * Z + n] * wl;
-                    gm += dmu[m * Z + n] * h2c[m * 64 + kl];
-                    gl += dlv[m * Z + n] * h2c[m * 64 + kl];
+            for (int u = 0; u < U; ++u) {
+                if (n0 == q) { wm[u] = wm0[u]; wl[u] = wl0[u]; }
+                else {
+                    const int nn = min(n0 + 4 * u, Z - 1);
+                    wm[u] = p.Wmu[(size_t)nn * d.N2 + k]; wl[u] = p.Wlv[(size_t)nn * d.N2 + k];
                 }
-            gr.dWmu[(size_t)n * d.N2 + k] = gm;
-            gr.dWlv[(size_t)n * d.N2 + k] = gl;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + 4 * u;
+                if (n < Z) {
+                    float gm = 0.f, gl = 0.f;
+#pragma unroll
+                    for (int m = 0; m < BN_MAXM; ++m)
+                        if (m < M) {
+                            acc[m] += dmu[m * Z + n] * wm[u] + dlv[m * Z + n] * wl[u];
+                            gm += dmu[m * Z + n] * h2c[m * 64 + kl];
+                            gl += dlv[m * Z + n] * h2c[m * 64 + kl];
+                        }
+                    gr.dWmu[(size_t)n * d.N2 + k] = gm;
+                    gr.dWlv[(size_t)n * d.N2 + k] = gl;
+                }
+            }
         }
     }
 #pragma unroll
@@ -581,22 +654,33 @@ __global__ __launch_bounds__(256) void fc2_bwd_kernel(TailDims d, TailParams p, 
     float* h1c = dhs + M * N;            // [M][16]
     float* red = h1c + M * 16;           // [16][M][16]
     const int k0 = blockIdx.x * 16;
+    const int kl = tid & 15, q = tid >> 4, k = k0 + kl;
+    constexpr int U = 8;                                     // the first U rows of W2 travel with the dh2 / h1 loads (see fc2_fwd)
+    float w0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w0[u] = p.W2[(size_t)min(q + 16 * u, N - 1) * K + min(k, K - 1)];
     for (int i = tid; i < M * N; i += 256) dhs[i] = dh2[i];
     for (int i = tid; i < M * 16; i += 256) h1c[i] = (k0 + (i & 15) < K) ? sv.h1[(i >> 4) * K + k0 + (i & 15)] : 0.f;
     __syncthreads();
-    const int kl = tid & 15, q = tid >> 4, k = k0 + kl;
     float acc[BN_MAXM];
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
     if (k < K) {
-#pragma unroll 8
-        for (int n = q; n < N; n += 16) {
-            const float w = p.W2[(size_t)n * K + k];
-            float dw = 0.f;
+        for (int n0 = q; n0 < N; n0 += 16 * U) {
+            float wv[U];
 #pragma unroll
-            for (int m = 0; m < BN_MAXM; ++m)
-                if (m < M) { acc[m] += dhs[m * N + n] * w; dw += dhs[m * N + n] * h1c[m * 16 + kl]; }
-            gr.dW2[(size_t)n * K + k] = dw;
+            for (int u = 0; u < U; ++u) wv[u] = (n0 == q) ? w0[u] : p.W2[(size_t)min(n0 + 16 * u, N - 1) * K + k];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + 16 * u;
+                if (n < N) {
+                    float dw = 0.f;
+#pragma unroll
+                    for (int m = 0; m < BN_MAXM; ++m)
+                        if (m < M) { acc[m] += dhs[m * N + n] * wv[u]; dw += dhs[m * N + n] * h1c[m * 16 + kl]; }
+                    gr.dW2[(size_t)n * K + k] = dw;
+                }
+            }
         }
     }
 #pragma unroll
