@@ -96,7 +96,7 @@ SIGNATURES = {
     "cvae_bn2d_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _i, _i, _i, _p],
     "cvae_bn2d_bwd": [_p] * 9 + [_i64, _i64, _i, _i, _p],
     "cvae_bottleneck_sizes": [_p, _p, _p, _p, _p, _p],
-    "cvae_bottleneck_fwd": [_p] * 9 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p],
+    "cvae_bottleneck_fwd": [_p] * 10 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p],
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,

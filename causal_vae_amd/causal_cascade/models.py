@@ -82,7 +82,7 @@ class CausalBioVAE(nn.Module):
 
     fuse_bottleneck = True     # training forward: run pool .. dec_input as ops.BioBottleneck (4 + 4 launches) when the shapes allow
 
-    def _fused_bottleneck(self, x, m, t_onehot, eps):
+    def _fused_bottleneck(self, x, m, t, eps):
         """The same computation as encode -> reparameterize -> mechanism_net -> dec_input, layer for layer, in csrc/bottleneck.hip.
         Returns None (caller takes the layer-by-layer path) in eval mode, for B > 16 / B == 1, or pool windows that do not tile."""
         nd = self._ND
@@ -103,7 +103,9 @@ class CausalBioVAE(nn.Module):
         lin = [self.enc_fc[0], self.enc_fc[2], self.fc_mu, self.fc_logvar, self.mechanism_net[0]]
         params = [p for l in lin for p in (l.weight, l.bias)] + [bn.weight, bn.bias]
         params += [p for l in (self.mechanism_net[3], self.mechanism_net[5], self.dec_input) for p in (l.weight, l.bias)]
-        mu, logvar, m_hat, dec_cl = ops.BioBottleneck.apply(h, m, t_onehot, eps, *params, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+        if t.dim() != 1 or t.dtype != torch.int64:          # BioBottleneck builds the one-hot itself from int64 labels (one_hot raises otherwise)
+            t = ops.one_hot(t, self.t_dim)
+        mu, logvar, m_hat, dec_cl = ops.BioBottleneck.apply(h, m, t, eps, *params, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                                             bn.momentum, bn.eps, out_size)
         return mu, logvar, m_hat, self.dec_conv.forward_from_cl(dec_cl, packed=packed[len(we):])
 
@@ -112,11 +114,12 @@ class CausalBioVAE(nn.Module):
         nd = self._ND
         if x.dim() != nd + 2:
             raise RuntimeError(f"{type(self).__name__} expects a {nd + 2}-D input [B, C, {'D, ' if nd == 3 else ''}H, W], got {tuple(x.shape)}")
-        t_onehot = ops.one_hot(t, self.t_dim)
-        fused = self._fused_bottleneck(x, m, t_onehot, eps) if self.fuse_bottleneck else None
+        ops.L.require_gpu(x, m, t)                          # no CPU fallback: fail before any launch is attempted
+        fused = self._fused_bottleneck(x, m, t, eps) if self.fuse_bottleneck else None
         if fused is not None:
             mu, logvar, m_hat, out_cl = fused
         else:
+            t_onehot = ops.one_hot(t, self.t_dim)
             mu, logvar = self.encode(x, m, t_onehot)
             z = self.reparameterize(mu, logvar, eps)
             m_hat = self.mechanism_net(t_onehot)

@@ -48,12 +48,18 @@ __device__ __forceinline__ int pool_hi(int o, int in, int out) { return ((o + 1)
 // grid (S + 1, M): block (s, b) averages window s of sample b for all C channels (coalesced along c) and writes
 // xcat[b][c * S + s]; block (S, b) copies m and t behind the features.
 template <typename T>
-__global__ __launch_bounds__(256) void pool_cat_fwd_kernel(const T* __restrict__ y, const float* __restrict__ m, const float* __restrict__ t,
-                                                           float* __restrict__ xcat, int D, int H, int W, int C, int OD, int OH, int OW,
-                                                           int m_dim, int t_dim, int K1) {
+__global__ __launch_bounds__(256) void pool_cat_fwd_kernel(const T* __restrict__ y, const float* __restrict__ m, float* __restrict__ t,
+                                                           const long long* __restrict__ t_labels, float* __restrict__ xcat, int D, int H, int W, int C,
+                                                           int OD, int OH, int OW, int m_dim, int t_dim, int K1) {
     const int S = OD * OH * OW, b = blockIdx.y, s = blockIdx.x;
     float* row = xcat + (size_t)b * K1;
     if (s == S) {
+        if (t_labels) {                                      // F.one_hot(t).float() made here: t[b][.] is an output of this block
+            const long long lab = t_labels[b];
+            for (int i = threadIdx.x; i < t_dim; i += 256) { const float v = (i == lab) ? 1.f : 0.f; t[b * t_dim + i] = v; row[C * S + m_dim + i] = v; }
+            for (int i = threadIdx.x; i < m_dim; i += 256) row[C * S + i] = m[b * m_dim + i];
+            return;
+        }
         for (int i = threadIdx.x; i < m_dim + t_dim; i += 256) row[C * S + i] = i < m_dim ? m[b * m_dim + i] : t[b * t_dim + i - m_dim];
         return;
     }
@@ -872,8 +878,8 @@ static void launch_bwd_colwise(const float* g, const float* x, const float* W1, 
                        nslice, F, S, NS, d, p, tg, sv, mb);
 }
 
-extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, const float* t_onehot,
-                                   const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
+extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, float* t_onehot,
+                                   const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
                                    int bn_training, float* xcat, float* partial, float* dzm_acc, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype,
                                    void* stream) {
     if (!dims_ok(q)) return CVAE_E_BADSHAPE;
@@ -885,10 +891,10 @@ extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bot
     const int M = (int)q->M, S = (int)(q->OD * q->OH * q->OW), C = (int)q->C, F = C * S;
     const int K1 = F + (int)q->m_dim + (int)q->t_dim, K4 = (int)(q->Z + q->m_dim), KS = fwd_ksplit(K1);
     if (dtype == CVAE_BF16)
-        hipLaunchKernelGGL(pool_cat_fwd_kernel<bf16>, dim3(S + 1, M), dim3(256), 0, st, (const bf16*)y_cl, m, t_onehot, xcat, (int)q->D, (int)q->H, (int)q->W, C,
+        hipLaunchKernelGGL(pool_cat_fwd_kernel<bf16>, dim3(S + 1, M), dim3(256), 0, st, (const bf16*)y_cl, m, t_onehot, (const long long*)t_labels, xcat, (int)q->D, (int)q->H, (int)q->W, C,
                            (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1);
     else
-        hipLaunchKernelGGL(pool_cat_fwd_kernel<float>, dim3(S + 1, M), dim3(256), 0, st, (const float*)y_cl, m, t_onehot, xcat, (int)q->D, (int)q->H, (int)q->W, C,
+        hipLaunchKernelGGL(pool_cat_fwd_kernel<float>, dim3(S + 1, M), dim3(256), 0, st, (const float*)y_cl, m, t_onehot, (const long long*)t_labels, xcat, (int)q->D, (int)q->H, (int)q->W, C,
                            (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1);
     CVAE_CHECK_LAUNCH();
     const TailDims d = tail_dims(q, KS, 0);

@@ -433,7 +433,7 @@ extern "C" int cvae_adam_step(float* p, const float* g, float* m, float* v, int6
 // owns a 1024-element span of one tensor (one float4 per stream per thread) and uses nontemporal loads and stores: every byte is
 // touched once per step, so keeping it out of L2 leaves the cache to the activations (measured 5.2 vs 3.5 TB/s with 4096-spans).  `step_dev` (optional) is a device step counter: when given, the bias
 // corrections are computed in-kernel so that a captured HIP graph replays with advancing corrections.
-#define ADAM_MAX_TENSORS 32
+#define ADAM_MAX_TENSORS 64      // 2.8 KB of kernel arguments (limit 4 KB): the model's ~50 parameter tensors go in one launch
 #define ADAM_SPAN 4096
 #define ADAM_MULTI_SPAN 1024
 struct AdamTable {

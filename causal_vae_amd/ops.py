@@ -832,7 +832,7 @@ class BioBottleneck(torch.autograd.Function):
     """Everything between CausalBioVAE's last encoder conv and first decoder conv as 5 + 5 launches (csrc/bottleneck.hip):
     pool + flatten + cat, enc_fc, fc_mu / fc_logvar, reparameterize, mechanism_net (train-mode BatchNorm1d), cat, dec_input.
 
-    inputs : y_cl [B, D, H, W, C] (last encoder activation, a ReLU output), m [B, m_dim], t_onehot [B, t_dim], eps [B, Z],
+    inputs : y_cl [B, D, H, W, C] (last encoder activation, a ReLU output), m [B, m_dim], t_onehot [B, t_dim] (or the int64 labels [B]), eps [B, Z],
              the 18 parameters in _lib.BOTTLENECK_PARAMS order, then (running_mean, running_var, num_batches_tracked, momentum,
              bn_eps, out_size).  returns (mu, logvar, m_hat, dec_cl [B, OD, OH, OW, C] in y_cl's dtype).
     Same arithmetic (fp32) as the layer-by-layer path, which stays the general fallback (eval mode, B > 16, odd pool windows).
@@ -848,10 +848,14 @@ class BioBottleneck(torch.autograd.Function):
     def forward(ctx, y_cl, m, t_onehot, eps, *rest):
         params, (rm, rv, nbt, momentum, bn_eps, out_size) = rest[:18], rest[18:]
         L.require_gpu(y_cl, m, t_onehot, eps, *params)
-        y_cl, m, t_onehot, eps = y_cl.contiguous(), m.contiguous().float(), t_onehot.contiguous().float(), eps.contiguous().float()
         params = [p.contiguous() for p in params]
-        B, D, H, W, C = y_cl.shape
         W1, W2, Wmu, Wm0 = params[0], params[2], params[4], params[8]
+        t_labels = None
+        if t_onehot.dim() == 1 and not t_onehot.is_floating_point():           # class indices: the one-hot is written by the first launch
+            t_labels = t_onehot.contiguous().long()
+            t_onehot = torch.empty(t_labels.shape[0], Wm0.shape[1], dtype=torch.float32, device=y_cl.device)
+        y_cl, m, t_onehot, eps = y_cl.contiguous(), m.contiguous().float(), t_onehot.contiguous().float(), eps.contiguous().float()
+        B, D, H, W, C = y_cl.shape
         dims = L.BottleneckDims(B, D, H, W, C, *out_size, m.shape[1], t_onehot.shape[1], W1.shape[0], W2.shape[0], Wmu.shape[0], Wm0.shape[0])
         sizes = [C_.c_int64() for _ in range(5)]
         check(lib.cvae_bottleneck_sizes(C_.byref(dims), *[C_.byref(v) for v in sizes]), "bottleneck_sizes")
@@ -867,7 +871,7 @@ class BioBottleneck(torch.autograd.Function):
         dec_cl = torch.empty(B, *out_size, C, dtype=y_cl.dtype, device=dev)
         pstruct = L.BottleneckPtrs18(*[ptr(p) for p in params])
         sstruct = L.BottleneckSaved(*[ptr(saved[k]) for k in L.BOTTLENECK_SAVED])
-        check(lib.cvae_bottleneck_fwd(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
+        check(lib.cvae_bottleneck_fwd(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(t_labels), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
                                       float(bn_eps), 1, ptr(xcat), ptr(partial), ptr(dzm_acc), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), stream()), "bottleneck_fwd")
         ctx.dims, ctx.scratch = dims, n_dx
         ctx.save_for_backward(y_cl, t_onehot, eps, xcat, *params, *[saved[k] for k in L.BOTTLENECK_SAVED], dzm_acc)

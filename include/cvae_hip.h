@@ -159,13 +159,14 @@ typedef struct {                 /* activations kept for backward, all [M][dim] 
 /* Scratch sizes (in floats) for the given dims: xcat needs M*K1; the three partial buffers as returned. */
 int cvae_bottleneck_sizes(const cvae_bottleneck_dims* dims, int64_t* K1, int64_t* K4, int64_t* fwd_partial_floats, int64_t* dzm_partial_floats,
                           int64_t* dx_partial_floats);
-/* Forward.  t_onehot [M][t_dim], eps [M][Z] (the reparameterisation noise).  bn_training: batch statistics + running-stat /
+/* Forward.  t_onehot [M][t_dim] (F.one_hot(t).float(): an INPUT when t_labels is NULL; with t_labels [M] (int64 class indices) the call
+ * writes it itself, saving the caller's one-hot launch), eps [M][Z] (the reparameterisation noise).  bn_training: batch statistics + running-stat /
  * num_batches_tracked update (running_* may be NULL), else running statistics.  Outputs: saved->mu / logvar / m_hat (the
  * model's outputs) and dec_cl [M][OD][OH][OW][C] (conv dtype) = dec_input(cat(z, m_hat)) viewed [M, C, 4..] channels-last.
  * dzm_acc: the accumulator (dzm_partial_floats of cvae_bottleneck_sizes) the backward adds d(zm) into; the forward zeroes it (keep it until
  * the backward has run). */
-int cvae_bottleneck_fwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, const float* t_onehot,
-                        const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
+int cvae_bottleneck_fwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, float* t_onehot,
+                        const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
                         int bn_training, float* xcat, float* fwd_partial, float* dzm_acc, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype,
                         void* stream);
 /* Backward (training-mode BatchNorm only).  g_dec_cl: gradient of dec_cl; g_mu / g_logvar / g_mhat: gradients arriving at the
