@@ -143,8 +143,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     using TL = Tile<ND, BM>;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
     constexpr int STR = UP ? 1 : 2;
-    constexpr int ID = (ND == 3) ? (UP ? TD + 2 : 2 * TD + 2) : 1;
-    constexpr int IH = UP ? TH + 2 : 2 * TH + 2, IW = UP ? TW + 2 : 2 * TW + 2;
+    // UP: an output parity class reads q - 1 + pr + {0, 1} per dimension, so its halo box is (T + 1)^nd with the origin shifted by the
+    // parity — 405 instead of the parity-independent 600 positions for 4 x 8 x 8 tiles (the halo loads are the largest single cost of
+    // the `up` launches: 29 of 78 us on enc2's backward-data by ablation).
+    constexpr int ID = (ND == 3) ? (UP ? TD + 1 : 2 * TD + 2) : 1;
+    constexpr int IH = UP ? TH + 1 : 2 * TH + 2, IW = UP ? TW + 1 : 2 * TW + 2;
     constexpr int NPOS = ID * IH * IW;
     constexpr int FB = 8 * sizeof(T);                    // bytes of one fragment piece (8 channels)
     constexpr int NG = UP ? (ND == 3 ? 2 : 1) : (ND == 3 ? 16 : 4);   // tap groups of 4
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;       // tile origin in the M grid
     // input dims
     const int in_d = UP ? g.sd : g.ld, in_h = UP ? g.sh : g.lh, in_w = UP ? g.sw : g.lw;
-    const int g0d = (ND == 3) ? (UP ? o0d - 1 : 2 * o0d - 1) : 0;
-    const int g0h = UP ? o0h - 1 : 2 * o0h - 1, g0w = UP ? o0w - 1 : 2 * o0w - 1;
+    const int g0d = (ND == 3) ? (UP ? o0d - 1 + prd : 2 * o0d - 1) : 0;
+    const int g0h = UP ? o0h - 1 + prh : 2 * o0h - 1, g0w = UP ? o0w - 1 + prw : 2 * o0w - 1;
     const int nchunks = Cin / 16;
 
     // per-lane halo base position of each M sub-tile row
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
             return ((j & 1) * NROWS + kd * IH + kh) * RS + (j >> 1);      // kw = j: x-parity plane j & 1, slot shift j >> 1
         } else {
             const int a = (ND == 3) ? grp : 0, bb = j >> 1, c = j & 1;
-            return ((prd + a) * IH + (prh + bb)) * RS + (prw + c);
+            return (a * IH + bb) * RS + c;                                 // the halo origin already carries the parity
         }
     };
     auto tap_weight_idx = [&](int grp, int j) -> int {
@@ -434,8 +437,8 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
                     size_t workspace_bytes, hipStream_t stream) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
-    constexpr int ID = (ND == 3) ? (UP ? TL::TD + 2 : 2 * TL::TD + 2) : 1;
-    constexpr int IH = UP ? TL::TH + 2 : 2 * TL::TH + 2, IW = UP ? TL::TW + 2 : 2 * TL::TW + 2;
+    constexpr int ID = (ND == 3) ? (UP ? TL::TD + 1 : 2 * TL::TD + 2) : 1;
+    constexpr int IH = UP ? TL::TH + 1 : 2 * TL::TH + 2, IW = UP ? TL::TW + 1 : 2 * TL::TW + 2;
     constexpr int FB = 8 * sizeof(T);
     static_assert(IW >= 0, "");
     constexpr size_t LDS = (size_t)2 * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (size_t)2 * 4 * 2 * BN * FB;

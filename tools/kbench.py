@@ -36,6 +36,7 @@ def main():
     ap.add_argument("filters", nargs="*")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--mask", action="store_true", help="data kernels: fuse a ReLU mask of the output's shape (the backward-data form)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     esz = 2 if dt == torch.bfloat16 else 4
@@ -51,10 +52,10 @@ def main():
         bias_s, bias_l = torch.randn(Cs, device=dev), torch.randn(Cl, device=dev)
         if kind == "down":
             wp = ops.pack_weight(w, 3, False, dt)
-            fn = lambda: ops._conv_down(Lt, wp, bias_s, None, Cs, 3, "relu")
+            fn = (lambda: ops._conv_down(Lt, wp, None, S, Cs, 3, None)) if args.mask else (lambda: ops._conv_down(Lt, wp, bias_s, None, Cs, 3, "relu"))
         elif kind == "up":
             wp = ops.pack_weight(w, 3, True, dt)
-            fn = lambda: ops._conv_up(S, wp, bias_l, None, Cl, 3, "relu")
+            fn = (lambda: ops._conv_up(S, wp, None, Lt, Cl, 3, None)) if args.mask else (lambda: ops._conv_up(S, wp, bias_l, None, Cl, 3, "relu"))
         else:
             fn = lambda: ops._conv_wgrad(S, Lt, 3, w.shape, want_sbias=True)
         for _ in range(3):
