@@ -134,7 +134,9 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 // ---------------------------------------------------------------------------------------------- down / up
 // EPI: 0 = bias only, 1 = bias + ReLU, 2 = generic activation code
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI>
+// KH: 16-channel k-steps per staged halo (1, or 2 for `up` in bf16: its halo box is small enough to hold 32 channels, which halves
+// the stage / barrier count per MFMA and fetches 64 contiguous bytes per position instead of 32).
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1>
 __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                   const T* __restrict__ mask, T* __restrict__ out, ConvGeom g, int act,
                                                                   float* __restrict__ ws, int ksplit) {
@@ -155,12 +157,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     constexpr int RS = HaloPitch<ND, UP>::RS, NROWS = ID * IH;
     constexpr int PLANE = (UP ? 1 : 2) * NROWS * RS;     // slots of one k-half plane (down: even-x rows then odd-x rows)
     static_assert(RS >= (UP ? IW : IW / 2), "halo pitch too small");
-    constexpr int HALO_BYTES = 2 * PLANE * FB;
+    constexpr int HALO_BYTES = 2 * KH * PLANE * FB;           // planes: (k-step, k-half)
     // slot of halo position (z, y, x) inside a k-half plane
     auto hslot = [](int z, int y, int x) -> int {
         return UP ? (z * IH + y) * RS + x : ((x & 1) * NROWS + z * IH + y) * RS + (x >> 1);
     };
-    constexpr int BT_BYTES = 4 * 2 * BN * FB;            // one B buffer: [4 taps][2 halves][BN]
+    constexpr int BT_BYTES = 4 * KH * 2 * BN * FB;       // one B buffer: [4 taps][KH k-steps][2 halves][BN]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* bt = smem + HALO_BYTES;
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     const int in_d = UP ? g.sd : g.ld, in_h = UP ? g.sh : g.lh, in_w = UP ? g.sw : g.lw;
     const int g0d = (ND == 3) ? (UP ? o0d - 1 + prd : 2 * o0d - 1) : 0;
     const int g0h = UP ? o0h - 1 + prh : 2 * o0h - 1, g0w = UP ? o0w - 1 + prw : 2 * o0w - 1;
-    const int nchunks = Cin / 16;
+    const int nchunks = Cin / (16 * KH);                    // stages; the packed weights are indexed in 16-channel chunks (nch16)
+    const int nch16 = Cin / 16;
 
     // per-lane halo base position of each M sub-tile row
     // sub-tile ms of the workgroup tile covers d = ms / HB, h in [(ms % HB) * SH, +SH), all of w (SW == TW)
@@ -230,32 +233,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
         return (kd * 4 + kh) * 4 + kw;
     };
     // ---- halo staging plan: the (position, half) pieces this thread moves are the same for every channel chunk ----
-    constexpr int HN = (NPOS * 2 + NT - 1) / NT;
+    constexpr int PPP = 2 * KH;                            // 8-channel pieces per position per stage
+    constexpr int HN = (NPOS * PPP + NT - 1) / NT;
     int hoff[HN];                                          // element offset of the piece at chunk 0, or -1 (zero fill)
 #pragma unroll
     for (int i = 0; i < HN; ++i) {
-        const int it = t + i * NT, half = it & 1, pos = it >> 1;
+        const int it = t + i * NT, half = it % PPP, pos = it / PPP;
         const int x = pos % IW, y = (pos / IW) % IH, z = pos / (IW * IH);
         const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
-        const bool ok = (it < NPOS * 2) & (gz >= 0) & (gz < in_d) & (gy >= 0) & (gy < in_h) & (gx >= 0) & (gx < in_w);
+        const bool ok = (it < NPOS * PPP) & (gz >= 0) & (gz < in_d) & (gy >= 0) & (gy < in_h) & (gx >= 0) & (gx < in_w);
         hoff[i] = ok ? (((gz * in_h + gy) * in_w + gx) * Cin + 8 * half) : -1;
     }
     const T* in_b = in + (size_t)b * in_d * in_h * in_w * Cin;
-    constexpr int BP = (4 * 2 * BN) / NT;                  // weight pieces per thread per tap group
-    static_assert((4 * 2 * BN) % NT == 0, "weight panel must divide evenly over the workgroup");
+    constexpr int BP = (4 * KH * 2 * BN) / NT;             // weight pieces per thread per tap group
+    static_assert((4 * KH * 2 * BN) % NT == 0, "weight panel must divide evenly over the workgroup");
     auto load_b = [&](Piece<T> (&pb)[BP], int chunk, int grp) {
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const int it = t + i * NT, half = it & 1, n = (it >> 1) % BN, j = it / (2 * BN);
+            const int it = t + i * NT, half = it & 1, n = (it >> 1) % BN, kk = it / (2 * BN) % KH, j = it / (2 * BN * KH);
             const int wt = tap_weight_idx(grp, j);
-            piece_load<T>(pb[i], wp + (((size_t)wt * nchunks + chunk) * Cout + n0 + n) * 16 + 8 * half, true);
+            piece_load<T>(pb[i], wp + (((size_t)wt * nch16 + chunk * KH + kk) * Cout + n0 + n) * 16 + 8 * half, true);
         }
     };
     auto store_b = [&](const Piece<T> (&pb)[BP], int buf) {
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const int it = t + i * NT, half = it & 1, n = (it >> 1) % BN, j = it / (2 * BN);
-            piece_store<T>(pb[i], bt + buf * BT_BYTES + ((j * 2 + half) * BN + n) * FB);
+            const int it = t + i * NT, half = it & 1, n = (it >> 1) % BN, kk = it / (2 * BN) % KH, j = it / (2 * BN * KH);
+            piece_store<T>(pb[i], bt + buf * BT_BYTES + (((j * KH + kk) * 2 + half) * BN + n) * FB);
         }
     };
 
@@ -265,14 +269,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
         {
             Piece<T> hp[HN], pb0[BP];
 #pragma unroll
-            for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * 16, hoff[i] >= 0);
+            for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * (16 * KH), hoff[i] >= 0);
             load_b(pb0, chunk, 0);
             __syncthreads();                               // previous chunk's readers are done with halo + B buffers
             if (chunk - ks * chunk_per < 8) STAMP(2 + 3 * (chunk - ks * chunk_per));
 #pragma unroll
             for (int i = 0; i < HN; ++i) {
-                const int it = t + i * NT, pos = it >> 1;
-                if (it < NPOS * 2) piece_store<T>(hp[i], halo + ((size_t)(it & 1) * PLANE + hslot(pos / (IW * IH), (pos / IW) % IH, pos % IW)) * FB);
+                const int it = t + i * NT, pos = it / PPP;
+                if (it < NPOS * PPP) piece_store<T>(hp[i], halo + ((size_t)(it % PPP) * PLANE + hslot(pos / (IW * IH), (pos / IW) % IH, pos % IW)) * FB);
             }
             store_b(pb0, 0);
         }
@@ -285,15 +289,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int toff = tap_halo_off(grp, j);
-                Frag<T> a[MI], bf[NI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)h * PLANE + pbase[mi] + toff) * FB);
+                for (int kk = 0; kk < KH; ++kk) {
+                    Frag<T> a[MI], bf[NI];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) lds_load(bf[ni], btb + ((j * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
+                    for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                    for (int ni = 0; ni < NI; ++ni) lds_load(bf[ni], btb + (((j * KH + kk) * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
+                }
             }
         };
         Piece<T> pbA[BP], pbB[BP];
@@ -432,7 +439,7 @@ static int pick_ksplit(bool up, long long nwg, int nchunks) {
     return best;
 }
 
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI>
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1>
 int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
                     size_t workspace_bytes, hipStream_t stream) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -441,9 +448,9 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     constexpr int IH = UP ? TL::TH + 1 : 2 * TL::TH + 2, IW = UP ? TL::TW + 1 : 2 * TL::TW + 2;
     constexpr int FB = 8 * sizeof(T);
     static_assert(IW >= 0, "");
-    constexpr size_t LDS = (size_t)2 * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (size_t)2 * 4 * 2 * BN * FB;
+    constexpr size_t LDS = (size_t)2 * KH * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (size_t)2 * 4 * KH * 2 * BN * FB;
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
-    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI>;
+    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
@@ -456,7 +463,7 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     const long long tiles = (long long)g.tiles_d * g.tiles_h * g.tiles_w;
     long long gy = (long long)(Cout / BN) * npar;
     const int64_t total = (int64_t)g.B * (UP ? (int64_t)g.ld * g.lh * g.lw : (int64_t)g.sd * g.sh * g.sw) * Cout;
-    int ksplit = pick_ksplit(UP, tiles * gy * g.B, Cin / 16);
+    int ksplit = pick_ksplit(UP, tiles * gy * g.B, Cin / (16 * KH));
     if (!workspace || workspace_bytes < (size_t)ksplit * total * sizeof(float)) ksplit = 1;     // no (or too small a) workspace: unsplit
     gy *= ksplit;
     if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
@@ -473,6 +480,13 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
 
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
 int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* ws, size_t wsb, hipStream_t stream) {
+    // 32-channel stages pay where the K loop is long and the grid small (measured: Cin 256: -12 %, 128: -5 %, 64: +2 %)
+    if (UP && sizeof(T) == 2 && g.Cs >= 128 && (g.Cs % 32) == 0) {
+        constexpr int KH2 = (UP && sizeof(T) == 2) ? 2 : 1;
+        if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, KH2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+        if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, KH2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+        return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, KH2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+    }
     if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
     if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
     return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
