@@ -265,11 +265,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 
     STAMP(1);
     const int chunk_per = nchunks / ksplit;                 // host guarantees ksplit divides nchunks
+    // UP with 32-channel stages (long K loops on small grids): the NEXT stage's halo is requested right after this stage's LDS image is
+    // complete and lands under the tap loop (-5 %).  Elsewhere the prefetch loses: DOWN stages 14 pieces per thread (registers), and the
+    // Cin = 64 `up` launches fill the chip, where the co-resident workgroups already hide the stage (+4 % measured).
+    constexpr bool HPRE = UP && KH == 2;
+    Piece<T> hp[HN];
+    if (HPRE) {
+#pragma unroll
+        for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + ks * chunk_per * (16 * KH), hoff[i] >= 0);
+    }
     for (int chunk = ks * chunk_per; chunk < (ks + 1) * chunk_per; ++chunk) {
         {
-            Piece<T> hp[HN], pb0[BP];
+            Piece<T> pb0[BP];
+            if (!HPRE) {
 #pragma unroll
-            for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * (16 * KH), hoff[i] >= 0);
+                for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * (16 * KH), hoff[i] >= 0);
+            }
             load_b(pb0, chunk, 0);
             __syncthreads();                               // previous chunk's readers are done with halo + B buffers
             if (chunk - ks * chunk_per < 8) STAMP(2 + 3 * (chunk - ks * chunk_per));
@@ -282,6 +293,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
         }
         __syncthreads();
         if (chunk - ks * chunk_per < 8) STAMP(3 + 3 * (chunk - ks * chunk_per));
+        if (HPRE && chunk + 1 < (ks + 1) * chunk_per) {
+#pragma unroll
+            for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + (chunk + 1) * (16 * KH), hoff[i] >= 0);
+        }
         // Weight panels ride a 2-deep ring: the panel of group g+2 is loaded into registers at the start of group g and
         // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
         // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
