@@ -20,7 +20,7 @@ def load(d):
 fe, wr = load("pmc_fetch"), load("pmc_write")
 # (substring of the kernel name, grid size in threads) -> bench.py label, for the B=4, 128^3 bf16 workload
 WANT = {
-    ("4, 1, 2, 1, 0>", "1048576"): "conv_up nd3 B4 S32x32x32x64 -> L32",
+    ("4, 1, 2, 1, 0, 1>", "1048576"): "conv_up nd3 B4 S32x32x32x64 -> L32",
     ("conv_wgrad_kernelIDF16bLi3E", "131072"): "conv_wgrad nd3 B4 S32x32x32x64 L32",
     ("conv_data_kernelIDF16bLi3ELb0ELi2ELi2ELi2ELi1ELi1E", "262144"): "conv_down nd3 B4 L64x64x64x32 -> S64",
     ("adam_multi_kernel", None): "adam_multi (15.35 M params)",
