@@ -198,8 +198,12 @@ def main():
             per_step = {k: (n / args.roofline_steps, ms) for k, (n, ms) in summ.items()}
             # dominant kernel = the heaviest single-kernel conv launch (a conv_wgrad call is two kernels, main + slab reduction, so its
             # event time has no single row in the rocprof summary to agree with; it is listed under "kernels" like everything else)
+            # Among launches within 10 % of the heaviest, an `up` launch is preferred: enc2's backward-data is the only user of its
+            # template instance, so it has its own row in the rocprof summary, while the `down` rows average three layers.
             single = [k for k in summ if k.startswith(("conv_down", "conv_up"))] or list(summ)
-            dom = max(single, key=lambda k: summ[k][0] * summ[k][1])
+            cost = lambda k: summ[k][0] * summ[k][1]
+            top = max(cost(k) for k in single)
+            dom = max((k for k in single if cost(k) >= 0.9 * top), key=lambda k: (k.startswith("conv_up"), cost(k)))
             n, ms = summ[dom]
             fl = conv_flops(dom)
             peak = PEAK_BF16_FLOPS if args.dtype == "bf16" else PEAK_F32_FLOPS
