@@ -560,7 +560,7 @@ __device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads
 }
 
 // ------------------------------------------------------------------------------------------------ mulv_bwd
-// fc_mu / fc_logvar backward.  grid N2 / 64: workgroup b owns columns k in [64 b, 64 b + 64) of both weights: dWmu[:, k], dWlv[:, k]
+// fc_mu / fc_logvar backward.  grid N2 / 16: workgroup b owns columns k in [16 b, 16 b + 16) of both weights: dWmu[:, k], dWlv[:, k]
 // and dh2[:, k] = relu'(h2) (dmu . Wmu[:, k] + dlogvar . Wlv[:, k]); block 0 also writes the two bias gradients.
 // dmu = dz + g_mu, dlogvar = dz * eps * exp(logvar / 2) / 2 + g_logvar with dz = d(zm)[:, :Z] summed from the partials.
 __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p, TailGrads gr, TailSaved sv, const float* __restrict__ dzm_part,
@@ -571,23 +571,24 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
     float* dzs = lds;                    // [M][K4]
     float* dmu = dzs + M * K4;           // [M][Z]
     float* dlv = dmu + M * Z;            // [M][Z]
-    float* h2c = dlv + M * Z;            // [M][64]  this block's columns of h2
-    float* red = h2c + M * 64;           // [4][M][64]
-    // Everything this block reads from global memory is requested up front (first batch of weight rows, the element-wise operands of
-    // the first 256 (m, j) pairs, d(zm), this block's h2 columns): one round trip instead of four dependent ones.
-    const int k0 = blockIdx.x * 64;
-    const int kl = tid & 63, q = tid >> 6, k = k0 + kl, kk = min(k, d.N2 - 1);
-    constexpr int U = 8;
+    float* h2c = dlv + M * Z;            // [M][16]  this block's columns of h2
+    float* red = h2c + M * 16;           // [16][M][16]
+    // 16 columns per block (N2 / 16 blocks: 4 blocks of 64 columns left the launch to 4 CUs).  Everything this block reads from global
+    // memory is requested up front (its weight rows, the element-wise operands of the first 256 (m, j) pairs, d(zm), its h2 columns):
+    // one round trip instead of four dependent ones.
+    const int k0 = blockIdx.x * 16;
+    const int kl = tid & 15, q = tid >> 4, k = k0 + kl, kk = min(k, d.N2 - 1);
+    constexpr int U = 4;
     float wm0[U], wl0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int nn = min(q + 4 * u, Z - 1);
+        const int nn = min(q + 16 * u, Z - 1);
         wm0[u] = p.Wmu[(size_t)nn * d.N2 + kk]; wl0[u] = p.Wlv[(size_t)nn * d.N2 + kk];
     }
     const int ie = min(tid, M * Z - 1);
     const float e_eps = eps[ie], e_lv = sv.logvar[ie], e_gm = g_mu ? g_mu[ie] : 0.f, e_gl = g_logvar ? g_logvar[ie] : 0.f;
     load_dzm(dzm_part, dzs, M * K4);
-    for (int i = tid; i < M * 64; i += 256) h2c[i] = (k0 + (i & 63) < d.N2) ? sv.h2[(i >> 6) * d.N2 + k0 + (i & 63)] : 0.f;
+    for (int i = tid; i < M * 16; i += 256) h2c[i] = (k0 + (i & 15) < d.N2) ? sv.h2[(i >> 4) * d.N2 + k0 + (i & 15)] : 0.f;
     __syncthreads();
     for (int i = tid; i < M * Z; i += 256) {
         const int m = i / Z, j = i - m * Z;
@@ -603,27 +604,27 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m) acc[m] = 0.f;
     if (k < d.N2) {
-        for (int n0 = q; n0 < Z; n0 += 4 * U) {              // thread (k, q): rows n = q, q + 4, ..; loads of U rows first (see fc2_fwd)
+        for (int n0 = q; n0 < Z; n0 += 16 * U) {             // thread (k, q): rows n = q, q + 16, ..; loads of U rows first (see fc2_fwd)
             float wm[U], wl[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (n0 == q) { wm[u] = wm0[u]; wl[u] = wl0[u]; }
                 else {
-                    const int nn = min(n0 + 4 * u, Z - 1);
+                    const int nn = min(n0 + 16 * u, Z - 1);
                     wm[u] = p.Wmu[(size_t)nn * d.N2 + k]; wl[u] = p.Wlv[(size_t)nn * d.N2 + k];
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int n = n0 + 4 * u;
+                const int n = n0 + 16 * u;
                 if (n < Z) {
                     float gm = 0.f, gl = 0.f;
 #pragma unroll
                     for (int m = 0; m < BN_MAXM; ++m)
                         if (m < M) {
                             acc[m] += dmu[m * Z + n] * wm[u] + dlv[m * Z + n] * wl[u];
-                            gm += dmu[m * Z + n] * h2c[m * 64 + kl];
-                            gl += dlv[m * Z + n] * h2c[m * 64 + kl];
+                            gm += dmu[m * Z + n] * h2c[m * 16 + kl];
+                            gl += dlv[m * Z + n] * h2c[m * 16 + kl];
                         }
                     gr.dWmu[(size_t)n * d.N2 + k] = gm;
                     gr.dWlv[(size_t)n * d.N2 + k] = gl;
@@ -633,12 +634,14 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
     }
 #pragma unroll
     for (int m = 0; m < BN_MAXM; ++m)
-        if (m < M) red[(q * M + m) * 64 + kl] = acc[m];
+        if (m < M) red[(q * M + m) * 16 + kl] = acc[m];
     __syncthreads();
-    for (int i = tid; i < M * 64; i += 256) {
-        const int m = i >> 6, c = i & 63;
+    for (int i = tid; i < M * 16; i += 256) {
+        const int m = i >> 4, c = i & 15;
         if (k0 + c < d.N2) {
-            const float v = red[(0 * M + m) * 64 + c] + red[(1 * M + m) * 64 + c] + red[(2 * M + m) * 64 + c] + red[(3 * M + m) * 64 + c];
+            float v = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) v += red[(qq * M + m) * 16 + c];
             dh2[m * d.N2 + k0 + c] = h2c[i] > 0.f ? v : 0.f;
         }
     }
@@ -941,7 +944,7 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     const TailGrads g{gr->db1, gr->dW2, gr->db2, gr->dWmu, gr->dbmu, gr->dWlv, gr->dblv, gr->dWm0, gr->dbm0, gr->dgamma, gr->dbeta, gr->dWm3, gr->dbm3, gr->dWm5, gr->dbm5};
     const TailSaved s{sv->h1, sv->h2, sv->mu, sv->logvar, sv->xhat, sv->invstd, sv->a1n, sv->a2, sv->m_hat, sv->zm};
     float* dh2 = g1 + (size_t)M * q->N1;                     // second part of the g1 scratch
-    hipLaunchKernelGGL(mulv_bwd_kernel, dim3((unsigned)((q->N2 + 63) / 64)), dim3(256), sizeof(float) * ((size_t)M * K4 + 2 * (size_t)M * q->Z + 5 * (size_t)M * 64), st,
+    hipLaunchKernelGGL(mulv_bwd_kernel, dim3((unsigned)((q->N2 + 15) / 16)), dim3(256), sizeof(float) * ((size_t)M * K4 + 2 * (size_t)M * q->Z + 17 * (size_t)M * 16), st,
                        d, p, g, s, (const float*)dzm_partial, g_mu, g_logvar, eps, dh2);
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(fc2_bwd_kernel, dim3((unsigned)((q->N1 + 15) / 16)), dim3(256), sizeof(float) * ((size_t)M * q->N2 + 17 * (size_t)M * 16), st, d, p, g, s,
