@@ -413,6 +413,36 @@ def test_forward_elbo_equals_forward_plus_loss_function(cls, shape, dtype):
             grad_close(gb[k], ga[k].cpu(), k, l2=1e-3 if dtype == torch.float32 else 2e-2, linf=1e-2 if dtype == torch.float32 else 5e-2)
 
 
+def test_elbo_values_are_bit_reproducible_and_onehot_input_equals_label_input():
+    """(a) forward_elbo twice on the same inputs: loss / recon / m_loss are identical bit for bit (fixed-order partial sums, no atomics
+    on the loss path).  (b) ops.BioBottleneck fed the int64 labels (the one-hot is written by its first launch) == fed F.one_hot(t)."""
+    g = torch.Generator().manual_seed(9)
+    x, m = torch.randn(2, 1, 128, 128, 128, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (2,), generator=g).to(DEV)
+    eps = torch.randn(2, 64, generator=g).to(DEV)
+    torch.manual_seed(1)
+    model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    outs = []
+    for _ in range(2):
+        o = model.forward_elbo(x, m, t, eps=eps)
+        outs.append([v.detach().clone() for v in o])
+    for u, v in zip(*outs):
+        assert torch.equal(u, v), (float(u), float(v))
+    # (b) the bottleneck alone, both forms of t
+    h = torch.randn(2, 8, 8, 8, 256, generator=g).to(DEV).relu().to(torch.bfloat16)
+    bn = model.mechanism_net[1]
+    lin = [model.enc_fc[0], model.enc_fc[2], model.fc_mu, model.fc_logvar, model.mechanism_net[0]]
+    params = [p for l in lin for p in (l.weight, l.bias)] + [bn.weight, bn.bias]
+    params += [p for l in (model.mechanism_net[3], model.mechanism_net[5], model.dec_input) for p in (l.weight, l.bias)]
+    res = []
+    for tt in (t, ops_mod.one_hot(t, 19)):
+        rm, rv, nbt = bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()
+        with torch.no_grad():
+            res.append(ops_mod.BioBottleneck.apply(h, m, tt, eps, *[p.detach() for p in params], rm, rv, nbt, bn.momentum, bn.eps, (4, 4, 4)))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+
+
 def test_adam_overlapped_with_backward_gives_the_same_training():
     """FusedAdam.overlap_backward: the non-encoder update runs on a side stream under the encoder backward; same losses and
     parameters as the plain step (up to the atomic-order drift bounded in test_graphed_step_matches_eager_steps)."""
