@@ -259,9 +259,10 @@ def _conv_down(Lt, wp, bias, mask, Cs, nd, act):
     return S
 
 
-def _conv_up(St, wp, bias, mask, Cl, nd, act):
+def _conv_up(St, wp, bias, mask, Cl, nd, act, l_dims=None):
+    """l_dims: spatial extent (ld, lh, lw) of the result when it is not 2 s — the data gradient of a conv over an odd extent (l = 2 s + 1)."""
     B, sd, sh, sw, Cs = _cl_dims(St)
-    ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
+    ld, lh, lw = ((2 * sd if nd == 3 else 1), 2 * sh, 2 * sw) if l_dims is None else tuple(int(v) for v in l_dims)
     Lt = _empty((B, ld, lh, lw, Cl), St.dtype, St)
     ws, nbytes = _conv_data_workspace(St.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, 1)
     check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up, ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt),
@@ -335,7 +336,7 @@ class ConvDown(torch.autograd.Function):
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
             wp_up = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, True, g.dtype)
-            dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None)
+            dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None, l_dims=x.shape[1:4])
         fork.join(dw, db)
         return dx, dw, db, None, None, None, None, None
 

@@ -24,5 +24,5 @@ from .functional import (  # noqa: F401
     reparameterize, cascade_loss, vessel_loss, mnist_vae_losses, gaussian_nll, bio_decode, morph_decode, vessel_vae_forward,
 )
 from .steps import (  # noqa: F401
-    adam_init, adam_update, cascade_train_step, mnist_adversarial_step, clip_grad_norm,
+    adam_init, adam_update, cascade_train_step, cvae_train_step, mnist_adversarial_step, clip_grad_norm,
 )

@@ -188,6 +188,32 @@ def vessel_vae_forward(sd, x, m, t, eps, *, training=True, update_running=True):
     return dict(recon_x=recon_x, m_hat=m_mu, mu=mu, logvar=logvar, z=z, m_mu=m_mu, m_logvar=m_logvar)
 
 
+def cvae_forward(sd, x, t, eps):
+    """ConditionalVAE.forward (mnist_test/03_measurement_approach/cvae_models.py:51-85): q(z | x, t), p(x | z, t); t a float one-hot."""
+    h = F.relu(F.conv2d(x, sd["enc_conv.0.weight"], sd["enc_conv.0.bias"], stride=2, padding=1))          # :23-30, 28 -> 14 -> 7 -> 3
+    h = F.relu(F.conv2d(h, sd["enc_conv.2.weight"], sd["enc_conv.2.bias"], stride=2, padding=1))
+    h = F.relu(F.conv2d(h, sd["enc_conv.4.weight"], sd["enc_conv.4.bias"], stride=2, padding=1))
+    h_t = torch.cat([h.flatten(1), t], dim=1)                                                              # :54-58
+    mu, logvar = _lin(sd, "enc_fc_mu", h_t), _lin(sd, "enc_fc_logvar", h_t)                               # :60-61
+    z = reparameterize(mu, logvar, eps)                                                                    # :76-79
+    recon_x = cvae_decode(sd, z, t)
+    return dict(recon_x=recon_x, mu=mu, logvar=logvar, z=z)
+
+
+def cvae_decode(sd, z, t):
+    """ConditionalVAE.decode (cvae_models.py:64-74)."""
+    h = _lin(sd, "dec_fc", torch.cat([z, t], dim=1)).view(-1, 64, 7, 7)
+    h = F.relu(F.conv_transpose2d(h, sd["dec_conv.0.weight"], sd["dec_conv.0.bias"], stride=2, padding=1))
+    return torch.sigmoid(F.conv_transpose2d(h, sd["dec_conv.2.weight"], sd["dec_conv.2.bias"], stride=2, padding=1))
+
+
+def cvae_loss(recon_x, x, mu, logvar):
+    """BCE-sum + KLD (cvae_train.py:37-45) -> (loss, recon, kld)."""
+    recon = F.binary_cross_entropy(recon_x.reshape(-1, 784), x.reshape(-1, 784), reduction="sum")
+    kld = kld_sum(mu, logvar)
+    return recon + kld, recon, kld
+
+
 def discriminator_forward(sd, z):
     """LatentDiscriminator.forward (mnist_test/01_baseline_causal_vae/models.py:102-111)."""
     h = F.leaky_relu(_lin(sd, "net.0", z), 0.2)

@@ -22,7 +22,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-MODEL_KINDS = ("bio2d", "bio3d", "morph12", "morph12g", "disc", "vessel2d")
+MODEL_KINDS = ("bio2d", "bio3d", "morph12", "morph12g", "disc", "vessel2d", "cvae")
 
 
 def _file(sd, prefix, layer):
@@ -102,6 +102,20 @@ def _vessel2d(m_dim, t_dim, z_dim):
     return sd
 
 
+def _cvae(t_dim, z_dim):
+    """ConditionalVAE (mnist_test/03_measurement_approach/cvae_models.py:13-49), construction order = RNG order."""
+    sd = OrderedDict()
+    _file(sd, "enc_conv.0", nn.Conv2d(1, 32, 4, 2, 1))
+    _file(sd, "enc_conv.2", nn.Conv2d(32, 64, 4, 2, 1))
+    _file(sd, "enc_conv.4", nn.Conv2d(64, 64, 4, 2, 1))
+    _file(sd, "enc_fc_mu", nn.Linear(576 + t_dim, z_dim))
+    _file(sd, "enc_fc_logvar", nn.Linear(576 + t_dim, z_dim))
+    _file(sd, "dec_fc", nn.Linear(z_dim + t_dim, 64 * 7 * 7))
+    _file(sd, "dec_conv.0", nn.ConvTranspose2d(64, 32, 4, 2, 1))
+    _file(sd, "dec_conv.2", nn.ConvTranspose2d(32, 1, 4, 2, 1))
+    return sd
+
+
 def _disc(z_dim, t_dim):
     sd = OrderedDict()
     _file(sd, "net.0", nn.Linear(z_dim, 64))
@@ -126,6 +140,8 @@ def init_state_dict(kind, seed=None, *, img_channels=1, m_dim=12, t_dim=None,
         return _morph12(m_dim, 10 if t_dim is None else t_dim, z_dim, kind == "morph12g")
     if kind == "disc":
         return _disc(z_dim, 10 if t_dim is None else t_dim)
+    if kind == "cvae":
+        return _cvae(10 if t_dim is None else t_dim, z_dim)
     if kind == "vessel2d":
         return _vessel2d(m_dim, 19 if t_dim is None else t_dim, 128)
     raise ValueError(f"unknown model kind {kind!r}; expected one of {MODEL_KINDS}")

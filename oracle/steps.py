@@ -88,6 +88,21 @@ def cascade_train_step(sd, x, m, t, eps, adam_state=None, *, lr=1e-3, gamma=2000
                 grads=grads, outputs={k: v.detach() for k, v in out.items()}, adam_state=adam_state)
 
 
+def cvae_train_step(sd, x, t, eps, adam_state=None, *, lr=1e-3, apply_update=True):
+    """One iteration of the ConditionalVAE loop (mnist_test/03_measurement_approach/cvae_train.py:31-47)."""
+    leaves = _leaves(sd)
+    out = fn.cvae_forward(leaves, x, t, eps)
+    loss, recon, kld = fn.cvae_loss(out["recon_x"], x, out["mu"], out["logvar"])
+    keys = trainable_keys(sd)
+    grads = dict(zip(keys, torch.autograd.grad(loss, [leaves[k] for k in keys])))
+    if apply_update:
+        if adam_state is None:
+            adam_state = adam_init(sd)
+        adam_update(sd, grads, adam_state, lr=lr)
+    return dict(loss=loss.detach(), recon=recon.detach(), kld=kld.detach(), grads=grads,
+                outputs={k: v.detach() for k, v in out.items()}, adam_state=adam_state)
+
+
 def mnist_adversarial_step(sd_vae, sd_d, x, m, t, eps_d, eps_vae, eps_adv, adam_vae=None, adam_d=None,
                            *, lr=1e-3, beta=1.0, lambda_adv=10.0, apply_update=True, gaussian=False):
     """One iteration of train_model's inner loop (mnist_test/01_baseline_causal_vae/train.py:34-93).

@@ -112,6 +112,42 @@ def test_morph12_matches_reference_golden(golden):
         adam_close(v, g.t("sdd1/" + k), k)
 
 
+def test_conditional_vae_matches_reference_golden(golden):
+    """ConditionalVAE (mnist_test/03_measurement_approach/cvae_models.py + cvae_train.py:31-47): init, forward, BCE + KLD, every
+    gradient and one Adam step against the vectors captured from the reference; then the bf16 conv path against the fp32 one."""
+    from causal_vae_amd.mnist_cvae import ConditionalVAE, loss_function as cvae_loss, train_step as cvae_step
+    g = golden("mnist_cvae_b8")
+    torch.manual_seed(42)
+    vae = ConditionalVAE().to(DEV).train()
+    for k, v in vae.state_dict().items():
+        g.check("sd0", k, v, rtol=0, atol=0)
+    x, t, eps = g.t("in/x").to(DEV), g.t("in/t").to(DEV), g.t("fwd/eps").to(DEV)
+    recon_x, mu, logvar = vae(x, t, eps=eps)
+    for k, v in dict(recon_x=recon_x, mu=mu, logvar=logvar).items():
+        g.check("fwd", k, v, rtol=1e-4, atol=1e-5)
+    loss, recon, kld = cvae_loss(recon_x, x, mu, logvar)
+    for k, v in dict(loss=loss, recon=recon, kld=kld).items():
+        assert rel(v, g.t("fwd/" + k)) < 1e-5, (k, float(v), float(g.t("fwd/" + k)))
+    loss.backward()
+    for k, p in vae.named_parameters():
+        if g.has("grad/" + k):
+            grad_close(p.grad, g.t("grad/" + k), k)
+        else:                                                 # large tensors are pinned by their digest (sums, head, tail)
+            g.check("grad", k, p.grad, rtol=2e-3, atol=2e-4)
+    vae.zero_grad()
+    opt = FusedAdam(vae.parameters(), lr=1e-3)
+    r = cvae_step(vae, opt, x, t, eps=eps)
+    assert rel(r["loss"], g.t("fwd/loss")) < 1e-5
+    for k, v in vae.state_dict().items():
+        if g.has("sd1/" + k):
+            adam_close(v, g.t("sd1/" + k), k)
+    torch.manual_seed(42)
+    vb = ConditionalVAE().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    rb, mub, lvb = vb(x, t, eps=eps)
+    lb = cvae_loss(rb, x, mub, lvb)[0]
+    assert rel(lb, g.t("fwd/loss")) < 2e-3 and float((rb - g.t("fwd/recon_x").to(DEV)).abs().max()) < 2e-2
+
+
 def _oracle_step(kind, x, m, t, eps, nd):
     sd = oracle.init_state_dict(kind, seed=42)
     sd0 = {k: v.clone() for k, v in sd.items()}

@@ -77,8 +77,13 @@ def split_k(request):
     ops.SPLIT_K = old
 
 
+# odd input extents (l = 2 s + 1: the conv floors, its data gradient must come back with the odd extent): the 7 -> 3 layer of ConditionalVAE
+# (single-channel inputs are covered for even extents only: the image needs no data gradient, and `up_c1` says so loudly for odd ones)
+CONV_ODD_CASES = [(2, 3, 64, 64, (7, 7)), (3, 1, 32, 64, (9, 8, 11)), (2, 2, 32, 64, (13, 9))]
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("nd,B,Cl,Cs,size", CONV_CASES)
+@pytest.mark.parametrize("nd,B,Cl,Cs,size", CONV_CASES + CONV_ODD_CASES)
 def test_conv_forward_backward(nd, B, Cl, Cs, size, dtype, split_k):
     """nn.Conv{2,3}d(k4,s2,p1)+bias+ReLU: y, dx, dW, db (down / up / wgrad / channel_sum kernels)."""
     g = torch.Generator().manual_seed(1)

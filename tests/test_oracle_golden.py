@@ -175,3 +175,22 @@ def test_bio3d_oracle_shapes_and_keys():
     x = torch.randn(2, 1, 32, 32, 32)
     out = ofn.bio_vae_forward(sd3, x, torch.rand(2, 12), torch.tensor([3, 7]), torch.randn(2, 64))
     assert out["recon_x"].shape == x.shape and out["mu"].shape == (2, 64)
+
+
+def test_conditional_vae_init_forward_loss_grads_adam(golden):
+    """ConditionalVAE (mnist_test/03_measurement_approach): init order, forward, BCE + KLD, every gradient, one Adam step."""
+    g = golden("mnist_cvae_b8")
+    sd = oracle.init_state_dict("cvae", seed=42)
+    assert sorted(sd) == g.keys("sd0")
+    for k, v in sd.items():
+        g.check("sd0", k, v, rtol=0, atol=0)
+    x, t, eps = g.t("in/x"), g.t("in/t"), g.t("fwd/eps")
+    st = oracle.cvae_train_step(sd, x, t, eps)
+    for k in ("recon_x", "mu", "logvar", "z"):
+        g.check("fwd", k, st["outputs"][k], rtol=1e-6, atol=1e-6)
+    for k in ("loss", "recon", "kld"):
+        g.check("fwd", k, st[k], rtol=1e-6, atol=1e-4)
+    for k in g.keys("grad"):
+        g.check("grad", k, st["grads"][k], rtol=2e-5, atol=2e-5)
+    for k in g.keys("sd1"):
+        g.check("sd1", k, sd[k], rtol=2e-5, atol=2e-6)

@@ -56,7 +56,7 @@ def pack(prefix, named, store):
 
 def import_from(dirname, *modules):
     """Import bare-named modules (config, models, ...) from one reference directory."""
-    for name in ("config", "models", "train", "dataset"):
+    for name in ("config", "models", "train", "dataset", "cvae_models"):
         sys.modules.pop(name, None)
     sys.path.insert(0, dirname)
     try:
@@ -198,6 +198,39 @@ def morph_case(name, B, seed_data, gaussian_head):
     print(name, "loss", float(loss), "loss_d", float(loss_d), "keys", len(store))
 
 
+def cvae_case(name, B, seed_data):
+    """ConditionalVAE (mnist_test/03_measurement_approach/cvae_models.py:7-85) and one iteration of its loop (cvae_train.py:27-47)."""
+    config, models = import_from(os.path.join(REF, "mnist_test", "03_measurement_approach"), "config", "cvae_models")
+    CONFIG = config.CONFIG
+    torch.manual_seed(CONFIG["SEED"])
+    vae = models.ConditionalVAE()
+    vae.train()
+    store = {}
+    pack("sd0", vae.state_dict(), store)
+    g = torch.Generator().manual_seed(seed_data)
+    x = torch.rand(B, 1, 28, 28, generator=g)
+    t = F.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float()
+    store.update({"in/x": x.numpy(), "in/t": t.numpy()})
+    opt = torch.optim.Adam(vae.parameters(), lr=CONFIG["LR"])
+    opt.zero_grad()
+    torch.manual_seed(999)
+    recon_x, mu, logvar = vae(x, t)
+    torch.manual_seed(999)
+    eps = torch.randn(B, CONFIG["Z_DIM"])
+    store["fwd/eps"] = eps.numpy()
+    loss_recon = F.binary_cross_entropy(recon_x.view(-1, 784), x.view(-1, 784), reduction='sum')
+    loss_kld = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp()) * 1.0
+    loss = loss_recon + loss_kld
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in vae.named_parameters()}
+    opt.step()
+    pack("fwd", dict(recon_x=recon_x, mu=mu, logvar=logvar, z=mu + eps * torch.exp(0.5 * logvar), loss=loss, recon=loss_recon, kld=loss_kld), store)
+    pack("grad", grads, store)
+    pack("sd1", vae.state_dict(), store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print(name, "loss", float(loss), "keys", len(store))
+
+
 def vessel_loss_case(name):
     src = open(os.path.join(REF, "vessel_analysis", "01_train", "train.py")).read()
     fn_node = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "loss_function")
@@ -275,12 +308,17 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "vessel2d":
         vessel2d_case("vessel2d_b4")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "cvae":
+        sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+        cvae_case("mnist_cvae_b8", 8, 1234)
+        return
     sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))   # unused import in some ref files
     bio2d_case("bio2d_b4_64x96", 4, 64, 96, 1234)       # non-identity bilinear + non-divisible adaptive pool (6 -> 4)
     bio2d_case("bio2d_b2_64x64", 2, 64, 64, 1235)       # identity resize, identity pool
     bio2d_case("bio2d_b3_128x160", 3, 128, 160, 1236)   # 8x10 -> 4x4 pool (mixed window sizes), 2x/2.5x upsample
     morph_case("morph12_b8", 8, 1234, gaussian_head=False)
     morph_case("morph12g_b8", 8, 1234, gaussian_head=True)
+    cvae_case("mnist_cvae_b8", 8, 1234)
     vessel_loss_case("vessel_loss")
     vessel2d_case("vessel2d_b4")          # B = 4: at B = 2 a train-mode BatchNorm1d backward is (g1 - g2)(1 - xhat^2) ~ eps/var, pure cancellation
 
