@@ -180,6 +180,27 @@ def test_bio3d_fp32_matches_oracle(B, size):
         torch.testing.assert_close(model.state_dict()[k].cpu(), sd1[k], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("H,W", [(100, 100), (72, 90)])
+def test_bio2d_odd_intermediate_extents_match_oracle(H, W):
+    """2D model on sizes that are not multiples of 16: the encoder floors (100 -> 50 -> 25 -> 12 -> 6), the decoder emits 64 x 64 and the
+    bilinear resize is a non-integer ratio; forward, ELBO, gradients and one Adam step against the CPU oracle (layer-by-layer path)."""
+    g = torch.Generator().manual_seed(77)
+    B = 3
+    x, m = torch.randn(B, 1, H, W, generator=g), torch.rand(B, 12, generator=g)
+    t, eps = torch.randint(0, 19, (B,), generator=g), torch.randn(B, 64, generator=g)
+    sd0, sd1, st = _oracle_step("bio2d", x, m, t, eps, 2)
+    torch.manual_seed(42)
+    model = CausalBioVAE().to(DEV).train()
+    assert all(torch.equal(model.state_dict()[k].cpu(), sd0[k]) for k in sd0)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    loss, l_recon, l_m = train_step(model, opt, x.to(DEV), m.to(DEV), t.to(DEV), eps=eps.to(DEV))
+    assert rel(loss, st["loss"]) < 1e-4 and rel(l_recon, st["recon"]) < 1e-4 and rel(l_m, st["m_loss"]) < 1e-4
+    for k, p in model.named_parameters():
+        if k != NOISE_KEY:
+            grad_close(p.grad, st["grads"][k], k)
+            adam_close(p, sd1[k], k)
+
+
 def test_bio3d_bf16_elbo_vs_fp32_oracle():
     """bf16 conv path (fp32 accumulate, fp32 heads and losses): ELBO relative error vs the fp32 CPU oracle, stated."""
     g = torch.Generator().manual_seed(1234)
