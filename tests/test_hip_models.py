@@ -155,7 +155,7 @@ def _oracle_step(kind, x, m, t, eps, nd):
     return sd0, sd, st
 
 
-@pytest.mark.parametrize("B,size", [(2, 32), (2, 64), (2, 48), (16, 64)])          # (16, 64): BASELINE.json configs[2], 64^3 fp32 patches, batch 16
+@pytest.mark.parametrize("B,size", [(2, 32), (2, 64), (2, 48), (2, 40), (16, 64)])   # (16, 64): BASELINE.json configs[2], 64^3 fp32 patches, batch 16; 40: 5 -> 2 floors
 def test_bio3d_fp32_matches_oracle(B, size):
     """3D lift vs the CPU oracle: forward, ELBO (<= 1e-4 rel), gradients, one Adam step."""
     g = torch.Generator().manual_seed(1234)
