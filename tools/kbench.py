@@ -36,8 +36,11 @@ def main():
     ap.add_argument("filters", nargs="*")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--no-splitk", action="store_true", help="data kernels: no split-K scratch (unsplit launches)")
     ap.add_argument("--mask", action="store_true", help="data kernels: fuse a ReLU mask of the output's shape (the backward-data form)")
     args = ap.parse_args()
+    if args.no_splitk:
+        ops.SPLIT_K = False
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     esz = 2 if dt == torch.bfloat16 else 4
     dev = "cuda"
