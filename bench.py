@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--overlap-adam", action="store_true", help="run the non-encoder part of the Adam update on a side stream under the encoder backward")
     ap.add_argument("--fork", action="store_true", help="run weight-gradient kernels on a side stream (overlap with data-gradient kernels)")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")
+    ap.add_argument("--force-overlap-exchange", action="store_true", help="take the split-backward capture also at N = 1 (no exchange happens)")
     ap.add_argument("--roofline-steps", type=int, default=5, help="eager steps with per-launch HIP events after the timed region")
     args = ap.parse_args()
 
@@ -136,10 +138,19 @@ def main():
         return train_step(model, opt, x, m, t, grad_hook=reducer)
 
     use_graph = not args.no_graph
-    n_pre = 0
+    n_pre, want_split = 0, False
     if use_graph:
         from causal_vae_amd.graph import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3)      # None: model.forward_elbo, as train_step
+        # N > 1: the backward is split at the encoder output so the decoder + bottleneck gradients are exchanged under the encoder's backward
+        want_split = (world > 1 and not args.no_overlap_exchange) or args.force_overlap_exchange
+        try:
+            gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3, overlap_exchange=want_split)   # None: model.forward_elbo, as train_step
+        except Exception as e:                                       # noqa: BLE001 - the plain two-graph exchange is always available
+            if not want_split:
+                raise
+            print(f"[bench] split-backward capture failed ({e!r}); falling back to one exchange after the backward", file=sys.stderr)
+            want_split = False
+            gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3)
         n_pre = 3                                                    # the capture warm-up runs 3 real steps
         step = lambda: gstep()
     else:
@@ -191,6 +202,8 @@ def main():
                                    f"Adam lr {args.lr:g}, ELBO = MSE-sum + 2000*MSE-sum(m) + KLD", "global_batch": world * args.batch,
                        "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}",
                        "params": sum(p.numel() for p in model.parameters())},
+            "exchange": ("split backward: decoder + bottleneck bucket all-reduced under the encoder backward" if (use_graph and want_split) else
+                         ("one all-reduce after the backward" if world > 1 else "none (1 rank)")),
             "final_loss": final_loss, "loss_trajectory": traj if len(traj) <= 6 else traj[:4] + traj[-2:], "lr": args.lr, "hip_graph": use_graph, "side_stream_fork": args.fork,
         }
         if timer is not None:

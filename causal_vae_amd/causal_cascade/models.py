@@ -96,6 +96,7 @@ class CausalBioVAE(nn.Module):
         we, wd = self.enc_conv.conv_weights(), self.dec_conv.conv_weights()
         packed = ops.pack_weights(we + wd, nd, self.enc_conv.compute_dtype)          # every conv weight of the model, one launch
         h, rest, last_act = self.enc_conv.features_cl(x, packed=packed[:len(we)])
+        self._enc_out = h                                    # graph.GraphedTrainStep splits the backward here (exchange overlap)
         if not ops.BioBottleneck.supported(h, out_size, True) or last_act != "relu":
             raise ops.L.CvaeError("fused bottleneck: unexpected encoder output " + str(tuple(h.shape)))
         if eps is None:
@@ -154,6 +155,8 @@ class CausalBioVAE(nn.Module):
         return loss, recon, m_loss
 
     fuse_recon_loss = True
+
+    _enc_out = None
 
     def early_gradient_parameters(self):
         """Parameters whose gradients are complete before the encoder's backward starts (everything but enc_conv): candidates for

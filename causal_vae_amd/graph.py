@@ -7,6 +7,9 @@ capturable with torch.cuda.graph (HIP graphs underneath) — no tracing compiler
 
 With a GradAllReducer (N > 1 ranks) the step is captured as two graphs around the eager RCCL all-reduce:
 graph A = zero_grad..backward + pack of the flat gradient bucket, graph B = unpack + Adam.
+overlap_exchange=True (models that expose their encoder output, `model._enc_out`) splits the backward there instead: graph A1 = forward +
+the backward of decoder and bottleneck + pack of their bucket (~80 % of the gradient bytes), whose all-reduce then travels over xGMI
+while graph A2 = the encoder's backward + pack of its bucket runs; graph B waits for both exchanges.
 """
 import torch
 
@@ -17,7 +20,7 @@ from .optim import FusedAdam
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, batch, loss_fn=None, reducer=None, warmup=3):
+    def __init__(self, model, optimizer, batch, loss_fn=None, reducer=None, warmup=3, overlap_exchange=False):
         """batch: (x, m, t) example tensors on the GPU (their storage becomes the static input buffers).
         loss_fn(model_outputs, x, m) -> (loss, *others): 0-dim tensors; `loss` is back-propagated.  None: the model's own
         forward_elbo(x, m, t) (what causal_cascade.train.train_step runs)."""
@@ -36,8 +39,10 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g1 = torch.cuda.CUDAGraph()
-        self.g2 = None
-        if reducer is None or reducer.world_size() == 1:
+        self.g2 = self.g1b = None
+        if overlap_exchange:
+            self._capture_split()
+        elif reducer is None or reducer.world_size() == 1:
             with torch.cuda.graph(self.g1):
                 self.out = self._fwd_bwd()
                 self.opt.step()
@@ -59,6 +64,44 @@ class GraphedTrainStep:
         ops.backward_from(res[0])
         return tuple(r.detach() for r in res)
 
+    def _capture_split(self):
+        from .parallel import GradAllReducer
+        if self.loss_fn is not None or not hasattr(self.model, "early_gradient_parameters"):
+            raise CvaeError("overlap_exchange needs the model's own forward_elbo and early_gradient_parameters()")
+        params_a = [p for p in self.model.early_gradient_parameters() if p.requires_grad]
+        ids_a = {id(p) for p in params_a}
+        params_b = [p for p in self.model.parameters() if p.requires_grad and id(p) not in ids_a]
+        group = self.reducer.group if self.reducer is not None else None
+        self.red_a, self.red_b = GradAllReducer(params_a, group), GradAllReducer(params_b, group)
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # the warm-up ran on another side stream: harmless here
+        cap = torch.cuda.Stream()                            # ONE capture stream: the autograd nodes built in A1 run again in A2
+        with torch.cuda.graph(self.g1, stream=cap):
+            self.opt.zero_grad(set_to_none=True)
+            res = self.model.forward_elbo(self.x, self.m, self.t)
+            h = self.model._enc_out
+            if h is None or not h.requires_grad:
+                raise CvaeError("overlap_exchange: the model did not take the fused path that exposes its encoder output")
+            ga = torch.autograd.grad(res[0], params_a + [h], grad_outputs=ops.cached_one(res[0]), retain_graph=True, allow_unused=True)
+            for p, g in zip(params_a, ga[:-1]):
+                p.grad = g
+            gh = ga[-1]
+            self.out = tuple(r.detach() for r in res)
+            self.red_a.pack()
+        self.g1b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1b, pool=self.g1.pool(), stream=cap):
+            gb = torch.autograd.grad(h, params_b, grad_outputs=gh, allow_unused=True)
+            for p, g in zip(params_b, gb):
+                p.grad = g
+            self.red_b.pack()
+        self.model._enc_out = None
+        del h, gh, ga, gb, res
+        self.g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g2, pool=self.g1.pool(), stream=cap):
+            self.red_a.unpack()
+            self.red_b.unpack()
+            self.opt.step()
+
     def _reduce_eager(self):
         if self.reducer is not None:
             self.reducer()
@@ -72,7 +115,15 @@ class GraphedTrainStep:
         if t is not None:
             self.t.copy_(t, non_blocking=True)
         self.g1.replay()
-        if self.g2 is not None:
+        if self.g1b is not None:                             # split backward: bucket A is on the wire while the encoder's backward runs
+            wa = self.red_a.all_reduce_async()
+            self.g1b.replay()
+            wb = self.red_b.all_reduce_async()
+            for w in (wa, wb):
+                if w is not None:
+                    w.wait()
+            self.g2.replay()
+        elif self.g2 is not None:
             self.reducer.all_reduce()
             self.g2.replay()
         return self.out

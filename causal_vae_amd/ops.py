@@ -68,15 +68,20 @@ def _scalar(like):
 _ONES = {}
 
 
-def backward_from(loss):
-    """loss.backward() without the fill kernel autograd launches for the implicit d(loss) = 1: the ones scalar is kept per device."""
+def cached_one(loss):
+    """A ones scalar like `loss`, kept per (device, dtype): seeds a backward without the fill kernel autograd launches for the implicit 1."""
     key = (loss.device, loss.dtype)
     one = _ONES.get(key)
     if one is None:
         one = torch.ones((), dtype=loss.dtype, device=loss.device)
         if not (loss.is_cuda and torch.cuda.is_current_stream_capturing()):      # a tensor born inside a capture lives in that graph's pool
             _ONES[key] = one
-    loss.backward(one)
+    return one
+
+
+def backward_from(loss):
+    """loss.backward() seeded with cached_one(loss)."""
+    loss.backward(cached_one(loss))
 
 
 # ------------------------------------------------------------------------------------------------ layout plumbing

@@ -83,6 +83,13 @@ class GradAllReducer:
     def all_reduce(self):
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_async(self):
+        """Start the exchange of the packed bucket and return its Work handle (None without a process group): on RCCL it runs on the
+        communicator's stream, ordered after what the current stream holds so far, and `.wait()` orders the current stream after it."""
+        if not dist.is_initialized() or self.world_size() == 1 or self._flat is None:
+            return None
+        return dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def unpack(self):
         self._copy(False)
 

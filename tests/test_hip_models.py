@@ -330,6 +330,35 @@ def test_graphed_step_matches_eager_steps():
             assert float(dlt.mean()) <= 5e-5, k
 
 
+def test_split_backward_capture_matches_eager_steps():
+    """GraphedTrainStep(overlap_exchange=True): the backward captured in two graphs around the encoder output (the multi-GPU exchange
+    overlap; no process group here, so no exchange happens) == the eager step: losses and weights after 3 + 3 steps, every gradient
+    present and finite."""
+    from causal_vae_amd.graph import GraphedTrainStep
+    g = torch.Generator().manual_seed(12)
+    x, m = torch.randn(2, 1, 64, 64, 64, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (2,), generator=g).to(DEV)
+    torch.manual_seed(42)
+    m_e = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    o_e = FusedAdam(m_e.parameters(), lr=1e-4, device_step=True)
+    eager = [float(train_step(m_e, o_e, x, m, t)[0]) for _ in range(6)]
+    torch.manual_seed(42)
+    m_g = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    o_g = FusedAdam(m_g.parameters(), lr=1e-4, device_step=True)
+    gs = GraphedTrainStep(m_g, o_g, (x, m, t), None, warmup=3, overlap_exchange=True)
+    graphed = [float(gs()[0]) for _ in range(3)]
+    for a, b in zip(eager[3:], graphed):
+        assert rel(b, a) < 2e-4, (eager, graphed)
+    assert len(set(graphed)) == 3
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m_g.parameters())
+    assert len(gs.red_a.params) + len(gs.red_b.params) == len(list(m_g.parameters())) and len(gs.red_b.params) == 8
+    for (k, p), q in zip(m_e.named_parameters(), m_g.parameters()):
+        if k != NOISE_KEY:
+            dlt = (p.detach() - q.detach()).abs()
+            assert float(dlt.max()) <= 2 * 1e-4 * 6 + 1e-6, k
+            assert float(dlt.mean()) <= 5e-5, k
+
+
 def test_gaussian_head_variant_matches_reference_golden(golden):
     """mnist_test/06_model_experiment CausalMorphVAE12 (6-tuple, decoder on the real m) vs tensors from the reference class."""
     from causal_vae_amd.mnist_gaussian import CausalMorphVAE12 as GaussVAE
