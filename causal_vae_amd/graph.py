@@ -73,6 +73,8 @@ class GraphedTrainStep:
         params_b = [p for p in self.model.parameters() if p.requires_grad and id(p) not in ids_a]
         group = self.reducer.group if self.reducer is not None else None
         self.red_a, self.red_b = GradAllReducer(params_a, group), GradAllReducer(params_b, group)
+        self.red_a.pack(); self.red_b.pack()                 # the warm-up left every .grad in place: the flat buckets are allocated here,
+        torch.cuda.synchronize()                             # in the ordinary pool, because RCCL touches them outside the graphs
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # the warm-up ran on another side stream: harmless here
         cap = torch.cuda.Stream()                            # ONE capture stream: the autograd nodes built in A1 run again in A2
