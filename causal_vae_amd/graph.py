@@ -100,8 +100,8 @@ class GraphedTrainStep:
         del h, gh, ga, gb, res
         self.g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g2, pool=self.g1.pool(), stream=cap):
-            self.red_a.unpack()
-            self.red_b.unpack()
+            self.red_a.bind_views()                          # Adam reads the reduced buckets in place: no copy back
+            self.red_b.bind_views()
             self.opt.step()
 
     def _reduce_eager(self):

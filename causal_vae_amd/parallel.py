@@ -93,6 +93,17 @@ class GradAllReducer:
     def unpack(self):
         self._copy(False)
 
+    def bind_views(self):
+        """Instead of copying the reduced bucket back: make every `.grad` a view of its slice of the bucket (no launch; the optimizer
+        then reads the bucket directly).  The views stay valid until the next zero_grad(set_to_none=True)."""
+        off = 0
+        for p in self.params:
+            if p.grad is None:
+                continue
+            n = p.grad.numel()
+            p.grad = self._flat[off:off + n].view_as(p.grad)
+            off += n
+
     def __call__(self):
         if self.world_size() == 1 or not self._grads():
             return

@@ -56,6 +56,50 @@ def test_sum_allreduce_equals_global_batch_gradient():
     assert abs(r0["total"] - float(loss)) < 1e-3 * abs(float(loss))
 
 
+def _worker_split(rank, world, port, ret):
+    """Two buckets exchanged asynchronously, gradients bound as views of the buckets (the GraphedTrainStep(overlap_exchange=True) recipe)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters, init_distributed
+    init_distributed("gloo")
+    torch.manual_seed(7)
+    lin = torch.nn.Sequential(torch.nn.Linear(12, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    broadcast_parameters(lin)
+    g = torch.Generator().manual_seed(5)
+    xs, ys = torch.randn(world * 4, 12, generator=g), torch.randn(world * 4, 3, generator=g)
+    loss = ((lin(xs[rank * 4:(rank + 1) * 4]) - ys[rank * 4:(rank + 1) * 4]) ** 2).sum()
+    late, early = list(lin[0].parameters()), list(lin[2].parameters())          # backward reaches lin[2] first
+    ge = torch.autograd.grad(loss, early + [lin[0].weight], retain_graph=True)   # stand-in for "split at an interior tensor"
+    for p, gr in zip(early, ge):
+        p.grad = gr
+    ra, rb = GradAllReducer(early), GradAllReducer(late)
+    ra.pack()
+    wa = ra.all_reduce_async()
+    gl = torch.autograd.grad(loss, late)
+    for p, gr in zip(late, gl):
+        p.grad = gr
+    rb.pack()
+    wb = rb.all_reduce_async()
+    wa.wait(); wb.wait()
+    ra.bind_views(); rb.bind_views()
+    assert all(p.grad.data_ptr() >= r._flat.data_ptr() for r in (ra, rb) for p in r.params)
+    ret[rank] = [p.grad.clone() for p in lin.parameters()]
+    dist.destroy_process_group()
+
+
+def test_two_async_buckets_bound_as_views_equal_the_single_exchange():
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_split, args=(world, port, ret), nprocs=world, join=True)
+    torch.manual_seed(7)
+    lin = torch.nn.Sequential(torch.nn.Linear(12, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    g = torch.Generator().manual_seed(5)
+    xs, ys = torch.randn(world * 4, 12, generator=g), torch.randn(world * 4, 3, generator=g)
+    ((lin(xs) - ys) ** 2).sum().backward()
+    for a, b, p in zip(ret[0], ret[1], lin.parameters()):
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-6)
+
+
 def test_oracle_two_microbatches_sum_equals_dp_definition():
     """The DP parity definition (parallel.py docstring) stated on the oracle: summing per-micro-batch gradients (BN per
     micro-batch) is what N ranks compute; it differs from one global-batch step only through BatchNorm1d statistics."""
