@@ -66,6 +66,7 @@ CONV_CASES = [
     (3, 2, 64, 128, (16, 16, 16)),  # several tiles per workgroup in the weight-gradient slabs
     (3, 3, 32, 64, (16, 24, 16)),
     (2, 5, 32, 64, (64, 48)),
+    (2, 3, 1, 32, (24, 40)),        # 2D single-channel ends (bf16: the MFMA form of up_c1 with 4 parities, 3^2 neighbours)
 ]
 
 
