@@ -318,7 +318,6 @@ __global__ __launch_bounds__(256) void fc2_fwd_kernel(TailDims d, TailParams p, 
                 if (m < M) acc[m] += wpre[j] * h1s[m * d.N1 + k];
         }
     }
-#pragma unroll 8
     for (int k = lane + 64 * HO; k < d.N1; k += 64) {
         const float w = p.W2[(size_t)n * d.N1 + k];
 #pragma unroll
@@ -364,7 +363,6 @@ __global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p,
                 if (m < M) { am[m] += wmp[u] * h2s[m * d.N2 + k]; al[m] += wlp[u] * h2s[m * d.N2 + k]; }
         }
     }
-#pragma unroll 4
     for (int k = lane + 64 * HO; k < d.N2; k += 64) {
         const float wm = p.Wmu[(size_t)j * d.N2 + k], wl = p.Wlv[(size_t)j * d.N2 + k];
 #pragma unroll
