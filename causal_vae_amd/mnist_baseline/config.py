@@ -2,18 +2,8 @@
 construction time exactly like the reference."""
 import torch
 
-CONFIG = {
-    "BATCH_SIZE": 128,
-    "EPOCHS": 100,
-    "LR": 1e-3,
-    "Z_DIM": 10,
-    "M_DIM": 12,
-    "T_DIM": 10,
-    "DEVICE": torch.device("cuda" if torch.cuda.is_available() else "cpu"),
-    "SEED": 42,
-    "BETA": 1.0,
-    "LAMBDA_ADV": 10.0,
-}
+CONFIG = dict(BATCH_SIZE=128, EPOCHS=100, LR=1e-3, Z_DIM=10, M_DIM=12, T_DIM=10, SEED=42, BETA=1.0, LAMBDA_ADV=10.0,
+              DEVICE=torch.device("cuda" if torch.cuda.is_available() else "cpu"))
 
-FEATURE_NAMES = ["Area", "Perimeter", "Thickness", "MajorAxis", "Eccentricity", "Orientation", "Solidity", "Extent",
-                 "AspectRatio", "Euler", "H_Symmetry", "V_Symmetry"]
+FEATURE_NAMES = ("Area Perimeter Thickness MajorAxis Eccentricity Orientation Solidity Extent AspectRatio Euler "
+                 "H_Symmetry V_Symmetry").split()
