@@ -155,7 +155,7 @@ def _oracle_step(kind, x, m, t, eps, nd):
     return sd0, sd, st
 
 
-@pytest.mark.parametrize("B,size", [(2, 32), (2, 64), (2, 48), (2, 40), (16, 64)])   # (16, 64): BASELINE.json configs[2], 64^3 fp32 patches, batch 16; 40: 5 -> 2 floors
+@pytest.mark.parametrize("B,size", [(2, 32), (2, 64), (2, 48), (2, 40), (16, 64), (2, 128)])   # (16, 64): BASELINE.json configs[2]; 40: 5 -> 2 floors; 128: the bench volume
 def test_bio3d_fp32_matches_oracle(B, size):
     """3D lift vs the CPU oracle: forward, ELBO (<= 1e-4 rel), gradients, one Adam step."""
     g = torch.Generator().manual_seed(1234)
