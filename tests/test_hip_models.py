@@ -201,10 +201,11 @@ def test_bio2d_odd_intermediate_extents_match_oracle(H, W):
             adam_close(p, sd1[k], k)
 
 
-def test_bio3d_bf16_elbo_vs_fp32_oracle():
-    """bf16 conv path (fp32 accumulate, fp32 heads and losses): ELBO relative error vs the fp32 CPU oracle, stated."""
+@pytest.mark.parametrize("B,size", [(2, 64), (4, 128)])          # (4, 128): the bench workload itself (BASELINE.json north_star)
+def test_bio3d_bf16_elbo_vs_fp32_oracle(B, size):
+    """bf16 conv path (fp32 accumulate, fp32 heads and losses): ELBO relative error vs the fp32 CPU oracle, stated; every conv / linear
+    weight gradient points the way the fp32 one does."""
     g = torch.Generator().manual_seed(1234)
-    B, size = 2, 64
     x = torch.randn(B, 1, size, size, size, generator=g)
     m, t, eps = torch.rand(B, 12, generator=g), torch.randint(0, 19, (B,), generator=g), torch.randn(B, 64, generator=g)
     _, _, st = _oracle_step("bio3d", x, m, t, eps, 3)
@@ -216,10 +217,13 @@ def test_bio3d_bf16_elbo_vs_fp32_oracle():
     print(f"bf16 ELBO rel err vs fp32 oracle: {err:.3e} (loss {float(loss):.4f} vs {float(st['loss']):.4f})")
     assert err < 1e-3
     # direction of the update agrees with the fp32 gradients
-    for k in ("enc_conv.2.weight", "dec_conv.2.weight", "enc_fc.0.weight", "dec_input.weight"):
-        a, b = dict(model.named_parameters())[k].grad.cpu().flatten(), st["grads"][k].flatten()
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-        assert cos > 0.99, (k, cos)
+    for k, p in model.named_parameters():
+        if k.endswith(".weight") and p.dim() > 1 and k != "mechanism_net.1.weight":
+            a, b = p.grad.cpu().flatten(), st["grads"][k].flatten()
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+            print(f"  cos(bf16 grad, fp32 oracle grad) {k}: {cos:.5f}")
+            # the first encoder layer sits at the end of the whole bf16 backward chain: 0.989 at 4 x 128^3, > 0.995 everywhere else
+            assert cos > (0.98 if k == "enc_conv.0.weight" else 0.99), (k, cos)
 
 
 def test_consumer_access_patterns_and_checkpoint_interchange():
