@@ -359,8 +359,13 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
     constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, IW = 2 * TW + 2, NPOS = ID * IH * IW;
     constexpr int TAPS = (ND == 3) ? 64 : 16, NTS = (TAPS + 31) / 32;
     constexpr int NU = (8 * sizeof(T)) / 16, HN = (NPOS + 255) / 256;
+    // bf16: the 1-channel halo is kept as four planes — x parity (the taps step by 2 in x) times a copy shifted by one slot — so that
+    // the 8 stride-2 elements a lane gathers for one B fragment (tap kw, positions w0 .. w0 + 7) are ONE aligned 16-byte read from plane
+    // (kw & 1, kw >> 1) instead of eight 2-byte reads.  fp32 keeps the linear image (one element per lane per MFMA there).
+    constexpr int LROWS = ID * IH, LPITCH = ((IW / 2 + 1 + 7) / 8) * 8, LPLANE = LROWS * LPITCH;
+    constexpr int L_ELEMS = sizeof(T) == 2 ? 4 * LPLANE : NPOS + 8;
     __shared__ __attribute__((aligned(16))) T s_lds[128 * 32];
-    __shared__ __attribute__((aligned(16))) T l_lds[NPOS + 8];
+    __shared__ __attribute__((aligned(16))) T l_lds[L_ELEMS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hk = lane >> 5;
     const int cs0 = blockIdx.y * 32;
     const int total = B * tiles_d * tiles_h * tiles_w;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
         const int tap = s * 32 + r;
         tvalid[s] = tap < TAPS;
         const int kd = (ND == 3) ? (tap >> 4) & 3 : 0, kh = (tap >> 2) & 3, kw = tap & 3;
-        toff[s] = tvalid[s] ? (kd * IH + kh) * IW + kw : 0;
+        toff[s] = tvalid[s] ? (sizeof(T) == 2 ? ((kw & 1) * 2 + (kw >> 1)) * LPLANE + (kd * IH + kh) * LPITCH : (kd * IH + kh) * IW + kw) : 0;
     }
     // Software pipeline over the workgroup's tiles: the global loads of tile i+1 are in flight (in registers) while tile i
     // is consumed from LDS, so the HBM latency hides under the barriers, LDS traffic and MFMAs of the previous tile.
@@ -427,7 +432,19 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
             for (int u = 0; u < NU; ++u) ((uint4*)(s_lds + it * 8))[u] = sv[i][u];       // row-major [pos][32 cs], 16-byte stores
         }
 #pragma unroll
-        for (int i = 0; i < HN; ++i) if (t + i * 256 < NPOS) l_lds[t + i * 256] = hv[i];
+        for (int i = 0; i < HN; ++i) {
+            const int pos = t + i * 256;
+            if (pos < NPOS) {
+                if constexpr (sizeof(T) == 2) {
+                    const int x = pos % IW, row = pos / IW, xi = x >> 1;
+                    T* pl = l_lds + (x & 1) * 2 * LPLANE + row * LPITCH;
+                    pl[xi] = hv[i];                                          // copy 0: slot xi
+                    if (xi > 0) pl[LPLANE + xi - 1] = hv[i];                 // copy 1: shifted left by one slot
+                } else {
+                    l_lds[pos] = hv[i];
+                }
+            }
+        }
         __syncthreads();
         if (tile + n_split < total) issue(tile + n_split);
         if constexpr (sizeof(T) == 2) {
@@ -447,13 +464,13 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
                 }
                 if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);
                 const int w = m0 % TW, hh = m0 / TW % TH, d = m0 / (TW * TH);
-                const int pb = ((2 * d) * IH + 2 * hh) * IW + 2 * w;
+                const int pb = ((2 * d) * IH + 2 * hh) * LPITCH + w;            // w is a multiple of 8: 16-byte aligned in every plane
 #pragma unroll
                 for (int s = 0; s < NTS; ++s) {
-                    bf16x8 bv;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bv[j] = tvalid[s] ? l_lds[pb + toff[s] + 2 * j] : (bf16)0.0f;
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[s], 0, 0, 0);
+                    union { uint4 u; bf16x8 v; } bv;
+                    bv.u = *(const uint4*)(l_lds + pb + toff[s]);
+                    if (!tvalid[s]) bv.u = make_uint4(0u, 0u, 0u, 0u);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv.v, acc[s], 0, 0, 0);
                 }
             }
         } else {
