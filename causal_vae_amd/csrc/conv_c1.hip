@@ -596,7 +596,7 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
 
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd) {
     const int rw = ((nd == 3) ? 64 : 32) + 1;
-    return ((size_t)1024 * 32 * rw + 1024) * sizeof(float);  // (Cs/32) * n_split <= 1024 slabs of [32][rw], then <= 1024 partial sums of L
+    return ((size_t)2048 * 32 * rw + 2048) * sizeof(float);  // (Cs/32) * n_split <= 2048 slabs of [32][rw], then <= 2048 partial sums of L
 }
 
 int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
@@ -609,13 +609,16 @@ int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, fl
     const int td = (nd == 3) ? 4 : 1, th = (nd == 3) ? 4 : 8, tw = (nd == 3) ? 8 : 16;
     const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
     const long long total = (long long)B * tiles_d * tiles_h * tiles_w;
-    long long n_split = 1024 / (Cs / 32);                   // ~4 workgroups per CU; slabs leave with plain stores
+    // 2 workgroups per CU (256 CUs): measured in the step at 256 / 384 / 512 / 640 / 768 / 1024 / 2048 workgroups: 58 / 45 / 36 / 49 / 43 / 39 / 44 us
+    // for enc1 — whole multiples of the CU count, and as few slabs as keep the loads in flight; slabs leave with plain stores
+    static const int c1_wgs = getenv("CVAE_TUNE_C1_SLABS") ? atoi(getenv("CVAE_TUNE_C1_SLABS")) : 512;
+    long long n_split = c1_wgs / (Cs / 32);
     if (n_split > total) n_split = total;
     if (n_split < 1) n_split = 1;
     dim3 grid((unsigned)n_split, (unsigned)(Cs / 32), 1);
     float* ws = (float*)workspace;
     const int rw = ((nd == 3) ? 64 : 32) + 1;
-    float* lsum_ws = dbias_l ? ws + (size_t)1024 * 32 * rw : nullptr;
+    float* lsum_ws = dbias_l ? ws + (size_t)2048 * 32 * rw : nullptr;
 #define LAUNCH_WG_C1(T, ND)                                                                                                           \
     if (lsum_ws) LAUNCH_WG_C1_(T, ND, true); else LAUNCH_WG_C1_(T, ND, false)
 #define LAUNCH_WG_C1_(T, ND, LS)                                                                                                      \
