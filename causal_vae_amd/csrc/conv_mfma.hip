@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
 // Only `down` splits: an `up` launch already has 8 (4) parity classes per tile and its output is 8x (4x) its input, so the fp32 slabs
 // cost more than the shorter K loop saves (measured: enc4 backward-data 23 -> 34 us, dec2 forward 12 -> 22 us with split-K).
 static int pick_ksplit(bool up, long long nwg, int nchunks) {
-    if (up || nwg >= 384 || nwg < 1 || nchunks < 2) return 1;
+    // a launch that already has one workgroup per CU stays whole: enc3's forward (256 workgroups) took 39 us unsplit against 34 + 8 (finish) split
+    if (up || nwg >= 256 || nwg < 1 || nchunks < 2) return 1;
     long long target = (512 + nwg - 1) / nwg;
     if (target > 16) target = 16;
     int best = 1;
@@ -910,7 +911,7 @@ int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbia
     const long long total_tiles = (long long)g.B * g.tiles_d * g.tiles_h * g.tiles_w;
     const int cb = (g.Cs / 64) * (g.Cl / 32), tg = (ND == 3) ? 4 : 1;
     // each workgroup ends with a 128 KB slab: ~2 workgroups per CU at most, and >= 4 tiles of work per slab
-    long long n_split = WGRAD_MAX_WG / ((long long)cb * tg);
+    long long n_split = WGRAD_MAX_WG / ((long long)cb * tg);   // in-step scan of 256 / 512 / 768 / 1024: 234 / 231 / 248 / 253 us for the six launches + reductions
     if (n_split > total_tiles / 4) n_split = total_tiles / 4;
     if (const char* e = getenv("CVAE_TUNE_WGRAD_NSPLIT")) n_split = atoll(e);      // tuning knob (tools/kbench.py)
     if (n_split < 1) n_split = 1;
