@@ -912,7 +912,13 @@ int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbia
     const int cb = (g.Cs / 64) * (g.Cl / 32), tg = (ND == 3) ? 4 : 1;
     // each workgroup ends with a 128 KB slab: ~2 workgroups per CU at most, and >= 4 tiles of work per slab
     long long n_split = WGRAD_MAX_WG / ((long long)cb * tg);   // in-step scan of 256 / 512 / 768 / 1024: 234 / 231 / 248 / 253 us for the six launches + reductions
-    if (n_split > total_tiles / 4) n_split = total_tiles / 4;
+    // >= 4 tiles per slab, except that a small layer may go down to one tile per slab until it has one workgroup per CU (in-step scan:
+    // dec1 29 -> 22 us, dec2 26 -> 20 us incl. their reductions; more slabs than that only lengthen the reduction)
+    long long floor_split = 256 / ((long long)cb * tg);
+    if (floor_split > total_tiles) floor_split = total_tiles;
+    long long by_tiles = total_tiles / 4;
+    if (by_tiles < floor_split) by_tiles = floor_split;
+    if (n_split > by_tiles) n_split = by_tiles;
     if (const char* e = getenv("CVAE_TUNE_WGRAD_NSPLIT")) n_split = atoll(e);      // tuning knob (tools/kbench.py)
     if (n_split < 1) n_split = 1;
     if (n_split > total_tiles) n_split = total_tiles;
