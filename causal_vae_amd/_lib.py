@@ -46,42 +46,49 @@ SIGNATURES = {
     "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
     "cvae_conv_wgrad_workspace_bytes": [_i64, _i64, _i],
     "cvae_conv_wgrad": [_p, _p, _p, _p, _i, _p, _sz] + [_i64] * 9 + [_i, _i, _p],
-    "cvae_channel_sum": [_p, _p, _i64, _i64, _i, _p],
+    "cvae_channel_sum_workspace_bytes": [_i64, _i64, _i],
+    "cvae_channel_sum": [_p, _p, _i64, _i64, _i, _p, _sz, _p],
     "cvae_act_fwd": [_p, _p, _i64, _i, _i, _p],
     "cvae_act_bwd": [_p, _p, _p, _i64, _i, _i, _p],
     "cvae_adaptive_avgpool_fwd": [_p, _p] + [_i64] * 9 + [_i, _p],
     "cvae_adaptive_avgpool_bwd": [_p, _p, _p] + [_i64] * 9 + [_i, _p],
     "cvae_upsample_linear_fwd": [_p, _p] + [_i64] * 8 + [_i, _p],
     "cvae_upsample_linear_bwd": [_p, _p] + [_i64] * 8 + [_i, _p],
-    "cvae_linear_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p],
-    "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p],
-    "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p],
+    "cvae_linear_workspace_bytes": [_i64, _i64, _i64, _i],
+    "cvae_linear_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
+    "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
+    "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
     "cvae_bn1d_train_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _p],
     "cvae_bn1d_train_bwd": [_p] * 8 + [_i64, _i64, _p],
     "cvae_bn1d_eval_fwd": [_p] * 6 + [_i64, _i64, _f, _p],
-    "cvae_philox_normal": [_p, _i64, _u64, _u64, _p, _p],
-    "cvae_philox_normal_advance": [_p, _i64, _u64, _u64, _p, _p],
-    "cvae_reparam_kld_fwd": [_p, _p, _p, _p, _p, _i64, _p],
+    "cvae_bn1d_stats": [_p, _p, _f, _p, _i64, _i64, _p],
+    "cvae_bn1d_apply_stats": [_p] * 5 + [_f] + [_p] * 5 + [_i64, _i64, _f, _f, _p],
+    "cvae_bn1d_bwd_sums": [_p] * 5 + [_i64, _i64, _p],
+    "cvae_bn1d_bwd_apply": [_p] * 6 + [_f, _p, _i64, _i64, _p],
+    "cvae_philox_normal": [_p, _i64, _u64, _u64, _u64, _p, _p],
+    "cvae_philox_normal_advance": [_p, _i64, _u64, _u64, _u64, _p, _p],
+    "cvae_reduce_workspace_bytes": [],
+    "cvae_reparam_kld_fwd": [_p, _p, _p, _p, _p, _i64, _p, _sz, _p],
     "cvae_reparam_kld_bwd": [_p, _p, _f] + [_p] * 5 + [_i64, _p],
-    "cvae_sse_fwd": [_p, _p, _p, _i64, _p],
+    "cvae_sse_fwd": [_p, _p, _p, _i64, _p, _sz, _p],
     "cvae_sse_bwd": [_p, _p, _p, _f, _p, _i64, _p],
     "cvae_combine3": [_p, _f, _f, _p],
-    "cvae_bce_fwd": [_p, _p, _p, _i64, _p],
+    "cvae_bce_fwd": [_p, _p, _p, _i64, _p, _sz, _p],
     "cvae_bce_bwd": [_p, _p, _p, _p, _i64, _p],
-    "cvae_sum_fwd": [_p, _p, _i64, _p],
-    "cvae_wmse_sparsity_fwd": [_p, _p, _p, _p, _i64, _p],
-    "cvae_wmse_sparsity_bwd": [_p] * 6 + [_i64, _p],
-    "cvae_gauss_nll_fwd": [_p, _p, _p, _p, _i64, _p],
+    "cvae_sum_fwd": [_p, _p, _i64, _p, _sz, _p],
+    "cvae_wmse_sparsity_fwd": [_p, _p, _p, _p, _i64, _i64, _p, _sz, _p],
+    "cvae_wmse_sparsity_bwd": [_p] * 6 + [_i64, _i64, _p],
+    "cvae_gauss_nll_fwd": [_p, _p, _p, _p, _i64, _p, _sz, _p],
     "cvae_gauss_nll_bwd": [_p] * 6 + [_i64, _p],
-    "cvae_softmax_ce_fwd": [_p, _p, _p, _i64, _i64, _p],
+    "cvae_softmax_ce_fwd": [_p, _p, _p, _i64, _i64, _p, _sz, _p],
     "cvae_softmax_ce_bwd": [_p, _p, _p, _p, _i64, _i64, _p],
-    "cvae_uniform_kl_fwd": [_p, _p, _i64, _i64, _p],
+    "cvae_uniform_kl_fwd": [_p, _p, _i64, _i64, _p, _sz, _p],
     "cvae_uniform_kl_bwd": [_p, _p, _p, _i64, _i64, _p],
     "cvae_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
     "cvae_adam_multi": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p],
     "cvae_multi_copy": [_p, _p, _p, _i, _p],
     "cvae_counter_add": [_p, _i, _p],
-    "cvae_sqnorm": [_p, _p, _i64, _p],
+    "cvae_sqnorm": [_p, _p, _i64, _p, _sz, _p],
     "cvae_scale": [_p, _i64, _p, _p],
     "cvae_clip_coef": [_p, _p, _f, _p],
     "cvae_up2x_supported": [_i64] * 7,
@@ -93,14 +100,16 @@ SIGNATURES = {
     "cvae_k4_to_conv3_grad": [_p, _p, _i64, _i64, _p],
     "cvae_clamp_fwd": [_p, _p, _f, _f, _i64, _p],
     "cvae_clamp_bwd": [_p, _p, _p, _f, _f, _i64, _p],
-    "cvae_bn2d_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _i, _i, _i, _p],
-    "cvae_bn2d_bwd": [_p] * 9 + [_i64, _i64, _i, _i, _p],
+    "cvae_bn2d_workspace_bytes": [_i64, _i64],
+    "cvae_bn2d_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _i, _i, _i, _p, _sz, _p],
+    "cvae_bn2d_bwd": [_p] * 9 + [_i64, _i64, _i, _i, _p, _sz, _p],
     "cvae_bottleneck_sizes": [_p, _p, _p, _p, _p, _p],
     "cvae_bottleneck_fwd": [_p] * 10 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p],
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
-            "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64}
+            "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64, "cvae_channel_sum_workspace_bytes": _sz,
+            "cvae_linear_workspace_bytes": _sz, "cvae_reduce_workspace_bytes": _sz, "cvae_bn2d_workspace_bytes": _sz}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library disagree: fail at import

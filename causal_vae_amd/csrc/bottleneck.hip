@@ -27,7 +27,7 @@
 
 namespace {
 
-struct TailDims { int M, N1, N2, Z, T, HM, DM, KS, P; };     // N1 = 512, N2 = 256, Z = latent, T = t_dim, HM = 64, DM = m_dim
+struct TailDims { int M, N1, N2, Z, T, HM, DM, KS, P, NZ; }; // N1 = 512, N2 = 256, Z = latent, T = t_dim, HM = 64, DM = m_dim, NZ = d(zm) partial slots
 struct TailParams {
     const float *b1, *W2, *b2, *Wmu, *bmu, *Wlv, *blv, *Wm0, *bm0, *gamma, *beta, *Wm3, *bm3, *Wm5, *bm5;
 };
@@ -37,7 +37,6 @@ struct TailGrads {
 // saved activations (global), all [M][dim] row-major
 struct TailSaved { float *h1, *h2, *mu, *logvar, *xhat, *invstd, *a1n, *a2, *m_hat, *zm; };
 struct MechFwdArgs { const float* t_onehot; float *running_mean, *running_var; long long* num_batches_tracked; float momentum, bn_eps; int bn_training; };
-#define DZM_GROUPS 16           // copies of the d(zm) accumulator (dec_input_bwd)
 struct MechBwdArgs { const float *dzm_part, *g_mhat, *t_onehot; };
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };       // float4 at dword alignment
 
@@ -334,11 +333,9 @@ __global__ __launch_bounds__(256) void fc2_fwd_kernel(TailDims d, TailParams p, 
 
 // ------------------------------------------------------------------------------------------------ mulv_fwd
 // One wave per latent j: mu[:, j] = Wmu[j] . h2 + bmu[j], logvar likewise, z = mu + eps * exp(logvar / 2) -> zm[:, j].  grid Z / 4.
-__global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p, TailSaved sv, const float* __restrict__ eps, float* __restrict__ dzm_acc) {
+__global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p, TailSaved sv, const float* __restrict__ eps) {
     extern __shared__ float lds[];
     const int M = d.M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K4 = d.Z + d.DM;
-    if (blockIdx.x == 0 && dzm_acc)                          // the backward accumulates d(zm) here with atomics: leave it zeroed
-        for (int i = tid; i < DZM_GROUPS * M * K4; i += 256) dzm_acc[i] = 0.f;
     float* h2s = lds;                                        // [M][N2]
     constexpr int HO = 4;                                    // this wave's first HO * 64 elements of both weight rows travel with the h2 loads
     const int j = blockIdx.x * 4 + wave;
@@ -433,11 +430,10 @@ __global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------ dec_input_bwd
 // g[b][n] = gcl[b][s][c] (n = c * S + s).  dWd[n][k] = sum_b g[b][n] zm[b][k]; dbd[n] = sum_b g[b][n];
-// dzm[b][k] += sum_{n in block} g[b][n] Wd[n][k].  A block owns R = 64 CONSECUTIVE rows n (C % 64 == 0), so its slice of Wd and
-// dWd is one contiguous run of R * K4 floats (float4 when K4 % 4 == 0).  The d(zm) partial sums go with fp32 atomics
-// onto DZM_GROUPS copies of the M x K4 accumulator (block -> copy round robin: 16x fewer adds per address; a tree over the blocks
-// would cost an extra dependent launch); the consumers add the copies up (load_dzm).  The forward leaves the copies zeroed and
-// pool_bwd zeroes them again.
+// dzm[b][k] = sum over blocks of sum_{n in block} g[b][n] Wd[n][k].  A block owns R = 64 CONSECUTIVE rows n (C % 64 == 0), so its slice
+// of Wd and dWd is one contiguous run of R * K4 floats (float4 when K4 % 4 == 0).  Each block leaves its M x K4 partial of d(zm) in its OWN
+// slot of the scratch with plain stores (no float atomics: the gradients are bit-reproducible); the consumers add the slots in index
+// order (load_dzm: 16-byte loads, the slots of one launch are L2-resident).
 template <typename T>
 __global__ __launch_bounds__(256) void dec_input_bwd_kernel(const T* __restrict__ gcl, const float* __restrict__ zm, const float* __restrict__ Wd,
                                                             float* __restrict__ dWd, float* __restrict__ dbd, float* __restrict__ dzm_acc,
@@ -493,22 +489,39 @@ __global__ __launch_bounds__(256) void dec_input_bwd_kernel(const T* __restrict_
         for (int m = 0; m < M; ++m) acc += gs[m * R + r];
         dbd[row0 + r] = acc;
     }
-    float* dz = dzm_acc + (size_t)(blockIdx.x % DZM_GROUPS) * M * K4;
+    float* dz = dzm_acc + (size_t)blockIdx.x * M * K4;
     for (int i = tid; i < M * K4; i += 256) {
         const int m = i / K4, k = i - m * K4;
         float acc = 0.f;
 #pragma unroll 8
         for (int r = 0; r < R; ++r) acc += gs[m * R + r] * ws[r * KP + k];
-        atomicAdd(&dz[i], acc);
+        dz[i] = acc;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ d(zm) -> LDS
-__device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n) {
+// dzs[i] = sum_q slot[q][i], q in index order; `n` floats per slot.  Threads take 4 consecutive elements (one 16-byte load per slot; n % 4 == 0
+// whenever K4 % 4 == 0, else element-wise) and keep 8 slots in flight.
+__device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n, int nslots) {
+    if ((n & 3) == 0) {
+        for (int i4 = threadIdx.x; i4 < n / 4; i4 += blockDim.x) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int q = 0;
+            for (; q + 8 <= nslots; q += 8) {
+                float4 u[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u[j] = *(const float4*)(dzm_acc + (size_t)(q + j) * n + 4 * i4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
+            }
+            for (; q < nslots; ++q) { const float4 u = *(const float4*)(dzm_acc + (size_t)q * n + 4 * i4); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            dzs[4 * i4] = v.x; dzs[4 * i4 + 1] = v.y; dzs[4 * i4 + 2] = v.z; dzs[4 * i4 + 3] = v.w;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < DZM_GROUPS; ++q) v += dzm_acc[(size_t)q * n + i];
+        for (int q = 0; q < nslots; ++q) v += dzm_acc[(size_t)q * n + i];
         dzs[i] = v;
     }
 }
@@ -526,7 +539,7 @@ __device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads
     float* dy = da2 + M * HM;            // [M][HM]
     float* xh = dy + M * HM;             // [M][HM]
     float* ts = xh + M * HM;             // [M][T]
-    load_dzm(dzm_part, dzs, M * K4);
+    load_dzm(dzm_part, dzs, M * K4, d.NZ);
     for (int i = tid; i < M * HM; i += T) { a2s[i] = sv.a2[i]; a1n[i] = sv.a1n[i]; xh[i] = sv.xhat[i]; }
     for (int i = tid; i < M * d.T; i += T) ts[i] = t_onehot[i];
     __syncthreads();
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
     }
     const int ie = min(tid, M * Z - 1);
     const float e_eps = eps[ie], e_lv = sv.logvar[ie], e_gm = g_mu ? g_mu[ie] : 0.f, e_gl = g_logvar ? g_logvar[ie] : 0.f;
-    load_dzm(dzm_part, dzs, M * K4);
+    load_dzm(dzm_part, dzs, M * K4, d.NZ);
     for (int i = tid; i < M * 16; i += 256) h2c[i] = (k0 + (i & 15) < d.N2) ? sv.h2[(i >> 4) * d.N2 + k0 + (i & 15)] : 0.f;
     __syncthreads();
     for (int i = tid; i < M * Z; i += 256) {
@@ -786,10 +799,8 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
 // window (windows must not overlap: D % OD == H % OH == W % OW == 0), zeroed where the pooled activation was not positive.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dxp, const T* __restrict__ y, T* __restrict__ dy, int NS, int M,
-                                                       int D, int H, int W, int C, int OD, int OH, int OW, int relu_mask, float* __restrict__ dzm_acc, int n_dzm) {
+                                                       int D, int H, int W, int C, int OD, int OH, int OW, int relu_mask) {
     const int S = OD * OH * OW, b = blockIdx.y, s = blockIdx.x;
-    if (blockIdx.x == 0 && blockIdx.y == 0)                  // last launch of the backward: re-arm the d(zm) accumulator (all its readers are done)
-        for (int i = threadIdx.x; i < n_dzm; i += 256) dzm_acc[i] = 0.f;
     const int ow = s % OW, oh = (s / OW) % OH, od = s / (OW * OH);
     const int d0 = pool_lo(od, D, OD), d1 = pool_hi(od, D, OD), h0 = pool_lo(oh, H, OH), h1 = pool_hi(oh, H, OH), w0 = pool_lo(ow, W, OW), w1 = pool_hi(ow, W, OW);
     const int nh = h1 - h0, nw = w1 - w0, nvox = (d1 - d0) * nh * nw;
@@ -847,7 +858,7 @@ static bool dims_ok(const cvae_bottleneck_dims* q) {
     return true;
 }
 static TailDims tail_dims(const cvae_bottleneck_dims* q, int KS, int P) {
-    return TailDims{(int)q->M, (int)q->N1, (int)q->N2, (int)q->Z, (int)q->t_dim, (int)q->HM, (int)q->m_dim, KS, P};
+    return TailDims{(int)q->M, (int)q->N1, (int)q->N2, (int)q->Z, (int)q->t_dim, (int)q->HM, (int)q->m_dim, KS, P, (int)(q->C * q->OD * q->OH * q->OW / 64)};
 }
 static int fwd_ksplit(int64_t K1) { int ks = (int)(K1 / 4096); return ks < 1 ? 1 : (ks > 8 ? 8 : ks); }
 static int bwd_nsplit(int64_t N1) { int ns = (int)(N1 / 16); return ns < 1 ? 1 : (ns > 32 ? 32 : ns); }
@@ -859,7 +870,7 @@ extern "C" int cvae_bottleneck_sizes(const cvae_bottleneck_dims* q, int64_t* K1,
     if (K1) *K1 = k1;
     if (K4) *K4 = k4;
     if (fwd_partial_floats) *fwd_partial_floats = (int64_t)fwd_ksplit(k1) * q->M * q->N1;
-    if (dzm_partial_floats) *dzm_partial_floats = DZM_GROUPS * q->M * k4;
+    if (dzm_partial_floats) *dzm_partial_floats = (F / 64) * q->M * k4;       // one slot per dec_input_bwd workgroup
     if (dx_partial_floats) *dx_partial_floats = (int64_t)bwd_nsplit(q->N1) * q->M * F;
     return CVAE_OK;
 }
@@ -908,7 +919,7 @@ extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bot
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(fc2_fwd_kernel, dim3((unsigned)((q->N2 + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N1, st, d, p, s, (const float*)partial);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mulv_fwd_kernel, dim3((unsigned)((q->Z + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N2, st, d, p, s, eps, dzm_acc);
+    hipLaunchKernelGGL(mulv_fwd_kernel, dim3((unsigned)((q->Z + 3) / 4)), dim3(256), sizeof(float) * (size_t)M * q->N2, st, d, p, s, eps);
     CVAE_CHECK_LAUNCH();
     const size_t lds_d = sizeof(float) * ((size_t)64 * (K4 | 1) + (size_t)M * K4 + (size_t)4 * M * 64);
     if (dtype == CVAE_BF16)
@@ -955,10 +966,10 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     CVAE_CHECK_LAUNCH();
     if (dtype == CVAE_BF16)
         hipLaunchKernelGGL(pool_bwd_kernel<bf16>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const bf16*)y_cl, (bf16*)dy_cl, NS, M, (int)q->D, (int)q->H,
-                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, DZM_GROUPS * M * K4);
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask);
     else
         hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(S, M), dim3(256), 0, st, (const float*)dx_partial, (const float*)y_cl, (float*)dy_cl, NS, M, (int)q->D, (int)q->H,
-                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask, dzm_partial, DZM_GROUPS * M * K4);
+                           (int)q->W, C, (int)q->OD, (int)q->OH, (int)q->OW, relu_mask);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

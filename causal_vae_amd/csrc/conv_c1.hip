@@ -573,7 +573,7 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream) {
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
     const int64_t n = B * sd * sh * sw;                     // one thread per (source voxel, channel half)
-    if (n >= ((int64_t)1 << 30) || ld != 2 * sd && nd == 3 || lh != 2 * sh || lw != 2 * sw) return CVAE_E_UNSUPPORTED;
+    if (n >= ((int64_t)1 << 30) || (nd == 3 && ld != 2 * sd) || lh != 2 * sh || lw != 2 * sw) return CVAE_E_UNSUPPORTED;   // exact 2x only (depth counts in 3D)
     if (dtype == CVAE_BF16) {                               // MFMA form
         const int td = (nd == 3) ? 4 : 1, th = (nd == 3) ? 8 : 16, tw = (nd == 3) ? 8 : 16;
         const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
@@ -611,7 +611,11 @@ int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, fl
     const long long total = (long long)B * tiles_d * tiles_h * tiles_w;
     // 2 workgroups per CU (256 CUs): measured in the step at 256 / 384 / 512 / 640 / 768 / 1024 / 2048 workgroups: 58 / 45 / 36 / 49 / 43 / 39 / 44 us
     // for enc1 — whole multiples of the CU count, and as few slabs as keep the loads in flight; slabs leave with plain stores
-    static const int c1_wgs = getenv("CVAE_TUNE_C1_SLABS") ? atoi(getenv("CVAE_TUNE_C1_SLABS")) : 512;
+#ifdef CVAE_TUNE                                             // tuning builds only (make EXTRA=-DCVAE_TUNE); clamped to the validated workspace
+    static const int c1_wgs = getenv("CVAE_TUNE_C1_SLABS") ? (atoi(getenv("CVAE_TUNE_C1_SLABS")) > 2048 ? 2048 : atoi(getenv("CVAE_TUNE_C1_SLABS"))) : 512;
+#else
+    constexpr int c1_wgs = 512;
+#endif
     long long n_split = c1_wgs / (Cs / 32);
     if (n_split > total) n_split = total;
     if (n_split < 1) n_split = 1;

@@ -17,8 +17,8 @@
 //   * epilogue fuses bias + ReLU/Sigmoid (forward use) or the ReLU mask of the saved activation (backward use).
 // wgrad — M = Cs, N = Cl, K = positions.  Both operands are [position][channel] in memory, i.e. K-strided: bf16 uses
 //   the gfx950 transposing LDS read (ds_read_b64_tr_b16) to build K-contiguous fragments; fp32's 32x32x2 MFMA takes
-//   one element per lane and needs no transpose.  Partial sums leave as 128-byte-row fp32 atomics into a
-//   [tap][Cs][Cl] workspace, then one pass rewrites them in the reference [Cs][Cl][taps] layout.
+//   one element per lane and needs no transpose.  Every workgroup leaves ONE fp32 slab [kh][kw][64 cs][32 cl] of partial sums with
+//   plain stores; wgrad_reduce_kernel adds the slabs in index order and writes the reference [Cs][Cl][taps] layout (no atomics).
 #include "common.h"
 #include <cstdlib>
 
@@ -832,7 +832,6 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
             bias_ws[(((size_t)(blockIdx.y % cl_blocks) * nhalf + half) * n_split + blockIdx.x) * 32 + t] = v;
         }
     }
-    if (!ws) return;                                          // tuning only: measure the accumulate phase alone
     const int col = lane & 31, hq = lane >> 5;
     float* slab = ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * n_split + blockIdx.x) * 32768;
 #pragma unroll
@@ -919,7 +918,10 @@ int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbia
     long long by_tiles = total_tiles / 4;
     if (by_tiles < floor_split) by_tiles = floor_split;
     if (n_split > by_tiles) n_split = by_tiles;
-    if (const char* e = getenv("CVAE_TUNE_WGRAD_NSPLIT")) n_split = atoll(e);      // tuning knob (tools/kbench.py)
+#ifdef CVAE_TUNE                                             // tuning builds only (make EXTRA=-DCVAE_TUNE, tools/kbench.py): never in the shipped library
+    if (const char* e = getenv("CVAE_TUNE_WGRAD_NSPLIT")) n_split = atoll(e);
+    if (n_split * cb * tg > WGRAD_MAX_WG && n_split > 1) n_split = WGRAD_MAX_WG / ((long long)cb * tg) > 0 ? WGRAD_MAX_WG / ((long long)cb * tg) : 1;   // stay inside the validated workspace
+#endif
     if (n_split < 1) n_split = 1;
     if (n_split > total_tiles) n_split = total_tiles;
     if (cb > 65535) return CVAE_E_BADSHAPE;
@@ -929,9 +931,8 @@ int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbia
     const long long wgs = (long long)cb * tg * n_split;
     float* bias_ws = ws + (size_t)(wgs > WGRAD_MAX_WG ? wgs : WGRAD_MAX_WG) * 32768;
     if (!dbias) bias_mode = 0;
-    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, (const T*)S, (const T*)L, getenv("CVAE_TUNE_WGRAD_NOREDUCE") ? nullptr : ws, g, (int)n_split, bias_ws, bias_mode);
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, (const T*)S, (const T*)L, ws, g, (int)n_split, bias_ws, bias_mode);
     CVAE_CHECK_LAUNCH();
-    if (getenv("CVAE_TUNE_WGRAD_NOREDUCE")) return CVAE_OK;
     const int dw_blocks = cb * tg * 4 * 32;
     const int bias_n = bias_mode == 1 ? g.Cs : (bias_mode == 2 ? g.Cl : 0), bias_width = bias_mode == 1 ? 64 : 32;
     const int bias_rows = (int)n_split * ((bias_mode == 2 && ND == 3) ? 2 : 1);
@@ -1138,7 +1139,7 @@ extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* d
         if (dbias && dbias_side == 1) {                      // ConvTranspose to one channel: its bias gradient is the plain sum of L
             if (lh == 2 * sh && lw == 2 * sw && (nd != 3 || ld == 2 * sd)) dbias_l = dbias;     // fused: the kernel reads all of L anyway
             else {
-                const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, 1, dtype, stream);
+                const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, 1, dtype, workspace, workspace_bytes, stream);   // scratch shared in stream order
                 if (rcb != CVAE_OK) return rcb;
             }
             dbias = nullptr;
@@ -1149,7 +1150,7 @@ extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* d
     int bias_mode = dbias ? (dbias_side ? 2 : 1) : 0;
     if (bias_mode == 2 && (lh != 2 * sh || lw != 2 * sw || (nd == 3 && ld != 2 * sd))) {
         // an odd L extent leaves a plane / row outside every tile's non-halo part: sum L separately
-        const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, Cl, dtype, stream);
+        const int rcb = cvae_channel_sum(L, dbias, B * ld * lh * lw, Cl, dtype, workspace, workspace_bytes, stream);   // scratch shared in stream order
         if (rcb != CVAE_OK) return rcb;
         bias_mode = 0;
     }

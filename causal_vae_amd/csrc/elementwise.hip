@@ -159,11 +159,12 @@ extern "C" int cvae_act_fwd(const void* x, void* y, int64_t n, int act, int dtyp
 // ------------------------------------------------------------------------------------- channel sum
 // x [P, C] channels-last -> out[c] = sum_p x[p, c].  Each thread owns one 16-byte group of channels (8 bf16 / 4 fp32) and
 // strides the rows, so every load is a full 16 B per lane and a block row covers whole 128-byte lines; block partials
-// meet in LDS.  A single-block-per-chunk launch (small inputs) writes the result directly — no memset, no atomics;
-// larger inputs spread rows over blockIdx.x and finish with one atomic per (block, channel) into a zeroed `out`.
-// C == 1 is the plain sum of all elements (rows of VEC "pseudo-channels" folded into out[0]).
+// meet in LDS.  A single-block-per-chunk launch (small inputs, or no scratch) writes the result directly; larger inputs spread
+// rows over blockIdx.x, every block leaves its partial row in the caller's scratch [gx][C] with plain stores and a finish
+// launch adds the rows in index order — no memset, no float atomics: the sums are bit-reproducible.
+// C == 1 is the plain sum of all elements (rows of VEC "pseudo-channels" folded into one value).
 template <typename T>
-__global__ __launch_bounds__(256) void channel_sum_vec_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t P, int64_t C, int fold, int direct) {
+__global__ __launch_bounds__(256) void channel_sum_vec_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t P, int64_t C, int fold) {
     constexpr int VEC = 16 / sizeof(T);
     __shared__ float red[256 * VEC];
     const int groups = (int)(C / VEC);                      // 16-byte groups per row (C % VEC == 0)
@@ -211,14 +212,16 @@ __global__ __launch_bounds__(256) void channel_sum_vec_kernel(const T* __restric
     if (ri == 0 && grp < groups) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = red[threadIdx.x * VEC + e];
+        // `out` is the result itself (gridDim.x == 1) or this block's row of the scratch (the host passes row 0's address)
+        float* o = out + (size_t)blockIdx.x * (fold ? 1 : C);
         if (fold) {                                         // C == 1 viewed as [P / VEC, VEC]
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) s += acc[e];
-            if (direct) out[0] = s; else atomicAdd(&out[0], s);
+            o[0] = s;
         } else {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { if (direct) out[grp * VEC + e] = acc[e]; else atomicAdd(&out[grp * VEC + e], acc[e]); }
+            for (int e = 0; e < VEC; ++e) o[grp * VEC + e] = acc[e];
         }
     }
 }
@@ -238,47 +241,89 @@ __global__ void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ 
     if (r_in == 0 && c < C) {
         float s = 0.f;
         for (int r = 0; r < rows; ++r) s += red[r * cl + c_in];
-        atomicAdd(&out[c], s);
+        out[(size_t)blockIdx.x * C + c] = s;
     }
 }
+// out[c] = sum_r part[r][c], r in index order
+__global__ __launch_bounds__(256) void channel_sum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int rows, int64_t C) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += part[(size_t)r * C + c];
+    out[c] = s;
+}
+// Row blocks (gx) a launch over [P][C] would use when scratch is available
 template <typename T>
-static int channel_sum_launch(const T* x, float* out, int64_t P, int64_t C, hipStream_t st) {
+static int64_t channel_sum_gx(const T* x, int64_t P, int64_t C, bool* vec_path, int64_t* Cv_out, int64_t* Pv_out, int* fold_out) {
     constexpr int VEC = 16 / sizeof(T);
     int64_t Pv = P, Cv = C;
     int fold = 0;
     if (C == 1 && P % VEC == 0 && P >= VEC) { Pv = P / VEC; Cv = VEC; fold = 1; }
-    if (Cv % VEC == 0 && (((uintptr_t)x) & 15) == 0) {
+    const bool vec = Cv % VEC == 0 && (((uintptr_t)x) & 15) == 0;
+    if (vec_path) *vec_path = vec;
+    if (Cv_out) *Cv_out = Cv;
+    if (Pv_out) *Pv_out = Pv;
+    if (fold_out) *fold_out = fold;
+    if (vec) {
         const int groups = (int)(Cv / VEC), gpb = groups < 256 ? groups : 256, rows = 256 / gpb;
         const int64_t gy = (groups + gpb - 1) / gpb;
-        if (gy > 65535) return CVAE_E_BADSHAPE;
         const int64_t passes = (Pv + rows - 1) / rows;       // row passes if one block did everything
         int64_t gx = 1;
-        // every block ends with atomics onto the same C words: few blocks (<= 128 adders per word), 32+ row passes each
-        if (passes > 64) { gx = (passes + 31) / 32; const int64_t cap = (128 + gy - 1) / gy; if (gx > cap) gx = cap; }
-        const int direct = gx == 1;
-        if (!direct && hipMemsetAsync(out, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
-        hipLaunchKernelGGL(channel_sum_vec_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, out, Pv, Cv, fold, direct);
-        return CVAE_OK;
+        if (passes > 64) { gx = (passes + 31) / 32; const int64_t cap = (1024 + gy - 1) / gy; if (gx > cap) gx = cap; }
+        return gx;
     }
-    if (hipMemsetAsync(out, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
     const int cl = (C >= 256) ? 256 : (int)C, rows = 256 / cl;
     const int64_t gy = (C + cl - 1) / cl;
-    if (gy > 65535) return CVAE_E_BADSHAPE;
     int64_t gx = (P + (int64_t)rows * 64 - 1) / ((int64_t)rows * 64);
     const int64_t cap = (2048 + gy - 1) / gy;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(channel_sum_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, out, P, C);
+    return gx;
+}
+template <typename T>
+static int channel_sum_launch(const T* x, float* out, int64_t P, int64_t C, float* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int VEC = 16 / sizeof(T);
+    bool vec;
+    int64_t Cv, Pv;
+    int fold;
+    int64_t gx = channel_sum_gx<T>(x, P, C, &vec, &Cv, &Pv, &fold);
+    const int64_t row = fold ? 1 : C;                        // floats per partial row
+    if (gx > 1 && (!ws || ws_bytes < (size_t)gx * row * sizeof(float))) gx = 1;      // no scratch: one row block (still no atomics)
+    float* dst = gx > 1 ? ws : out;
+    if (vec) {
+        const int groups = (int)(Cv / VEC), gpb = groups < 256 ? groups : 256;
+        const int64_t gy = (groups + gpb - 1) / gpb;
+        if (gy > 65535) return CVAE_E_BADSHAPE;
+        hipLaunchKernelGGL(channel_sum_vec_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, dst, Pv, Cv, fold);
+    } else {
+        const int cl = (C >= 256) ? 256 : (int)C;
+        const int64_t gy = (C + cl - 1) / cl;
+        if (gy > 65535) return CVAE_E_BADSHAPE;
+        hipLaunchKernelGGL(channel_sum_kernel<T>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, x, dst, P, C);
+    }
+    if (gx > 1) hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((unsigned)((row + 255) / 256)), dim3(256), 0, st, (const float*)ws, out, (int)gx, row);
     return CVAE_OK;
 }
-extern "C" int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* stream) {
+extern "C" size_t cvae_channel_sum_workspace_bytes(int64_t P, int64_t C, int dtype) {
+    if (P <= 0 || C <= 0) return 0;
+    // the 16-byte-aligned geometry (the misaligned fallback never needs more rows than 2048 / gy)
+    const int64_t gx_v = dtype == CVAE_BF16 ? channel_sum_gx<bf16>((const bf16*)nullptr, P, C, nullptr, nullptr, nullptr, nullptr)
+                                            : channel_sum_gx<float>((const float*)nullptr, P, C, nullptr, nullptr, nullptr, nullptr);
+    const int cl = (C >= 256) ? 256 : (int)C, rows = 256 / cl;
+    int64_t gx_s = (P + (int64_t)rows * 64 - 1) / ((int64_t)rows * 64);
+    const int64_t cap = (2048 + (C + cl - 1) / cl - 1) / ((C + cl - 1) / cl);
+    if (gx_s > cap) gx_s = cap;
+    const int64_t gx = gx_v > gx_s ? gx_v : gx_s;
+    return gx > 1 ? (size_t)gx * C * sizeof(float) : 0;
+}
+extern "C" int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (P < 0 || C <= 0) return CVAE_E_BADSHAPE;
     if (!out) return CVAE_E_NULLPTR;
     if (P == 0) return hipMemsetAsync(out, 0, C * sizeof(float), (hipStream_t)stream) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
     if (!x) return CVAE_E_NULLPTR;
     int rc;
-    if (dtype == CVAE_F32) rc = channel_sum_launch<float>((const float*)x, out, P, C, (hipStream_t)stream);
-    else if (dtype == CVAE_BF16) rc = channel_sum_launch<bf16>((const bf16*)x, out, P, C, (hipStream_t)stream);
+    if (dtype == CVAE_F32) rc = channel_sum_launch<float>((const float*)x, out, P, C, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    else if (dtype == CVAE_BF16) rc = channel_sum_launch<bf16>((const bf16*)x, out, P, C, (float*)workspace, workspace_bytes, (hipStream_t)stream);
     else return CVAE_E_DTYPE;
     if (rc != CVAE_OK) return rc;
     CVAE_CHECK_LAUNCH();

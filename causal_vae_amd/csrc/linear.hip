@@ -8,7 +8,9 @@
 //   bwd-weight  : A = dy^T (sam = 1, sak = ldy), B = x  (sbk = ldx, sbn = 1)  -> dW [N, K]
 // Workgroup = 256 threads = 2x2 waves, tile 64x64x16, each wave 32x32 as 2x2 MFMA tiles.  The 3D model's
 // enc_fc[0] is a 16415x512 weight read by a batch of 4: pure weight streaming, so K is split across
-// workgroups (fp32 atomics into a zeroed C) until the grid covers the chip, and bias/activation run after.
+// workgroups until the grid covers the chip: every split leaves its partial tile in a slab of the caller's workspace
+// ([split][M][N], plain stores) and one finish launch adds the slabs in index order, then bias and activation — no float
+// atomics, so results are bit-reproducible.  Without (enough) workspace the same kernels run unsplit.
 #include "common.h"
 
 #define LT 64
@@ -19,7 +21,7 @@
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                        const float* __restrict__ bias, int64_t M, int64_t N, int64_t K,
                                                        int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
-                                                       int64_t k_per_split, int act, int use_atomic) {
+                                                       int64_t k_per_split, int act, float* __restrict__ slabs) {
     __shared__ float As[LT * AS_STRIDE];
     __shared__ float Bs[LK * BS_STRIDE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -72,28 +74,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 const int64_t gm = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, gn = n0 + wn * 32 + j * 16 + (lane & 15);
                 if (gm < M && gn < N) {
                     float v = acc[i][j][r];
-                    if (use_atomic) atomicAdd(&C[gm * ldc + gn], v);
+                    if (slabs) slabs[((size_t)blockIdx.z * M + gm) * N + gn] = v;          // split-K partial: slab blockIdx.z
                     else C[gm * ldc + gn] = apply_act(v + (bias ? bias[gn] : 0.f), act);
                 }
             }
 }
 
-__global__ void bias_act_kernel(float* __restrict__ C, const float* __restrict__ bias, int64_t M, int64_t N, int64_t ldc, int act) {
+// C[m][c] = act(sum_s slabs[s][m][c] + bias[c]), s in index order
+__global__ void slab_sum_bias_act_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C, const float* __restrict__ bias, int64_t M, int64_t N,
+                                         int64_t ldc, int act) {
     const int64_t n = M * N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / N, c = i - m * N;
-        C[m * ldc + c] = apply_act(C[m * ldc + c] + (bias ? bias[c] : 0.f), act);
+        float v = 0.f;
+        for (int sp = 0; sp < splits; ++sp) v += slabs[(size_t)sp * n + i];
+        C[m * ldc + c] = apply_act(v + (bias ? bias[c] : 0.f), act);
     }
 }
 
-static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias, int64_t M, int64_t N, int64_t K,
-                    int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int act, hipStream_t stream) {
-    if (M < 0 || N <= 0 || K <= 0 || ldc < N) return CVAE_E_BADSHAPE;
-    if (M == 0) return CVAE_OK;
-    if (!A || !Bm || !C) return CVAE_E_NULLPTR;
+// split-K factor of gemm_f32 for an [M][N] result over K: long reductions only, until ~2 workgroups per CU exist, keeping >= 8 K-steps
+// (128 k) per split
+static int64_t gemm_splits(int64_t M, int64_t N, int64_t K, int64_t* k_per_split_out) {
     const int64_t tm = (M + LT - 1) / LT, tn = (N + LT - 1) / LT;
-    if (tm > 65535) return CVAE_E_BADSHAPE;
-    // long reductions only: split K until ~2 workgroups per CU exist, keeping >= 8 K-steps (128 k) per split
     int64_t splits = 1;
     const int64_t ksteps = (K + LK - 1) / LK;
     if (tm * tn < 512 && K >= 2048) {
@@ -102,18 +104,26 @@ static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias
         if (splits < 1) splits = 1;
         if (splits > 1024) splits = 1024;
     }
-    int64_t k_per_split = ((ksteps + splits - 1) / splits) * LK;
-    splits = (K + k_per_split - 1) / k_per_split;
-    const int use_atomic = splits > 1;
-    if (use_atomic) {
-        if (ldc == N) { if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) return CVAE_E_LAUNCH; }
-        else if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, stream) != hipSuccess) return CVAE_E_LAUNCH;
-    }
+    const int64_t k_per_split = ((ksteps + splits - 1) / splits) * LK;
+    if (k_per_split_out) *k_per_split_out = k_per_split;
+    return (K + k_per_split - 1) / k_per_split;
+}
+static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias, int64_t M, int64_t N, int64_t K,
+                    int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int act, float* ws, size_t ws_bytes, hipStream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || ldc < N) return CVAE_E_BADSHAPE;
+    if (M == 0) return CVAE_OK;
+    if (!A || !Bm || !C) return CVAE_E_NULLPTR;
+    const int64_t tm = (M + LT - 1) / LT, tn = (N + LT - 1) / LT;
+    if (tm > 65535) return CVAE_E_BADSHAPE;
+    int64_t k_per_split;
+    int64_t splits = gemm_splits(M, N, K, &k_per_split);
+    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float))) { splits = 1; k_per_split = ((K + LK - 1) / LK) * LK; }
+    float* slabs = splits > 1 ? ws : nullptr;
     dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, k_per_split, act, use_atomic);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, k_per_split, act, slabs);
     CVAE_CHECK_LAUNCH();
-    if (use_atomic && (bias || act != CVAE_ACT_NONE)) {
-        hipLaunchKernelGGL(bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, C, bias, M, N, ldc, act);
+    if (slabs) {
+        hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, (const float*)slabs, (int)splits, C, bias, M, N, ldc, act);
         CVAE_CHECK_LAUNCH();
     }
     return CVAE_OK;
@@ -128,7 +138,7 @@ static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias
 // y[m][n] (+)= sum_{k in chunk} x[m][k] W[n][k].  One wave per (row n, k-chunk); lanes stride k.
 __global__ __launch_bounds__(256) void linear_fwd_skinny_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                                                 float* __restrict__ y, int M, int64_t K, int64_t N, int64_t ldx, int64_t ldy,
-                                                                int64_t kchunk, int act, int use_atomic) {
+                                                                int64_t kchunk, int act, float* __restrict__ slabs) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -157,15 +167,16 @@ __global__ __launch_bounds__(256) void linear_fwd_skinny_kernel(const float* __r
         if (m >= M) break;
         const float s = wave_sum(acc[m]);
         if (lane == 0) {
-            if (use_atomic) atomicAdd(&y[m * ldy + n], s);
+            if (slabs) slabs[((size_t)blockIdx.y * M + m) * N + n] = s;                   // k-chunk partial: slab blockIdx.y
             else y[m * ldy + n] = apply_act(s + (bias ? bias[n] : 0.f), act);
         }
     }
 }
-// dx[m][k] += sum_{n in chunk} dy[m][n] W[n][k].  One thread per k (coalesced W rows), blockIdx.y walks n-chunks.
+// dx[m][k] = sum_{n in chunk} dy[m][n] W[n][k] (one n-chunk: straight into dx; several: slab blockIdx.y of [chunk][M][K], summed by
+// slab_sum_bias_act_kernel).  One thread per k (coalesced W rows), blockIdx.y walks n-chunks.
 __global__ __launch_bounds__(256) void linear_bwd_data_skinny_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
                                                                      int M, int64_t K, int64_t N, int64_t ldy, int64_t ldx, int64_t nchunk,
-                                                                     const float* __restrict__ yact, int act) {
+                                                                     const float* __restrict__ yact, int act, float* __restrict__ slabs) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.y * nchunk, n1 = min(N, n0 + nchunk);
     __shared__ float gs[SK_M][64];                          // g = dy * act'(y) of one 64-wide n sub-chunk
@@ -193,7 +204,11 @@ __global__ __launch_bounds__(256) void linear_bwd_data_skinny_kernel(const float
     }
     if (k < K) {
 #pragma unroll
-        for (int m = 0; m < SK_M; ++m) if (m < M) atomicAdd(&dx[m * ldx + k], acc[m]);
+        for (int m = 0; m < SK_M; ++m)
+            if (m < M) {
+                if (slabs) slabs[((size_t)blockIdx.y * M + m) * K + k] = acc[m];
+                else dx[m * ldx + k] = acc[m];
+            }
     }
 }
 // dW[n][k] = sum_m dy[m][n] x[m][k]: one thread per element of the flattened [N*K] weight (coalesced stores).
@@ -236,65 +251,97 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_rows_kernel(const float
     if (db && blockIdx.x == 0 && threadIdx.x == 0) db[n] = bsum;
 }
 
+// k-chunks of the skinny forward: enough waves in flight to cover HBM latency
+static int64_t skinny_fwd_chunks(int64_t K, int64_t N, int64_t* kchunk_out) {
+    int64_t chunks = (4096 + N - 1) / N;
+    if (chunks > K / 512) chunks = K / 512;
+    if (chunks < 1) chunks = 1;
+    const int64_t kchunk = ((K + chunks - 1) / chunks + 63) / 64 * 64;
+    if (kchunk_out) *kchunk_out = kchunk;
+    return (K + kchunk - 1) / kchunk;
+}
+// n-chunks of the skinny backward-data
+static int64_t skinny_bwd_chunks(int64_t K, int64_t N, bool wide, int64_t* nchunk_out) {
+    const int64_t kb = (K + 255) / 256;
+    int64_t chunks;
+    if (wide) {
+        chunks = (2048 + kb - 1) / kb;                        // >= 8 waves per SIMD worth of blocks: the W stream is latency-bound per wave
+        if (chunks > N / 16) chunks = N / 16;
+    } else {
+        chunks = N / 8; if (chunks > 256) chunks = 256;       // tiny W: spread the n reduction over many blocks
+    }
+    if (chunks < 1) chunks = 1;
+    const int64_t nchunk = (N + chunks - 1) / chunks;
+    if (nchunk_out) *nchunk_out = nchunk;
+    return (N + nchunk - 1) / nchunk;
+}
+extern "C" size_t cvae_linear_workspace_bytes(int64_t M, int64_t K, int64_t N, int op) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    int64_t splits = 1, elems = 0;
+    if (op == 0) {                                           // forward: y [M][N] over K
+        if (M <= SK_M && K >= 64) splits = skinny_fwd_chunks(K, N, nullptr); else splits = gemm_splits(M, N, K, nullptr);
+        elems = M * N;
+    } else if (op == 1) {                                    // backward-data: dx [M][K] over N
+        if (M <= SK_M) splits = skinny_bwd_chunks(K, N, K >= 1024, nullptr); else splits = gemm_splits(M, K, N, nullptr);
+        elems = M * K;
+    } else if (op == 2) {                                    // backward-weight: dW [N][K] over M (+ the bias column sums)
+        if (M > SK_M) {
+            splits = gemm_splits(N, K, M, nullptr);
+            const size_t cs = cvae_channel_sum_workspace_bytes(M, N, CVAE_F32);
+            const size_t sl = splits > 1 ? (size_t)splits * N * K * sizeof(float) : 0;
+            return sl > cs ? sl : cs;
+        }
+        return 0;
+    }
+    return splits > 1 ? (size_t)splits * elems * sizeof(float) : 0;
+}
 extern "C" int cvae_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N,
-                               int64_t x_stride, int64_t y_stride, int act, void* stream) {
+                               int64_t x_stride, int64_t y_stride, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (x_stride < K) return CVAE_E_BADSHAPE;
     if (M > 0 && M <= SK_M && N > 0 && K >= 64 && y_stride >= N) {
         if (!x || !W || !y) return CVAE_E_NULLPTR;
         hipStream_t st = (hipStream_t)stream;
-        int64_t chunks = (4096 + N - 1) / N;                    // enough waves in flight to cover HBM latency
-        if (chunks > K / 512) chunks = K / 512;
-        if (chunks < 1) chunks = 1;
-        const int64_t kchunk = ((K + chunks - 1) / chunks + 63) / 64 * 64;
-        chunks = (K + kchunk - 1) / kchunk;
-        const int use_atomic = chunks > 1;
-        if (use_atomic && hipMemset2DAsync(y, (size_t)y_stride * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
+        int64_t kchunk;
+        int64_t chunks = skinny_fwd_chunks(K, N, &kchunk);
+        if (chunks > 1 && (!workspace || workspace_bytes < (size_t)chunks * M * N * sizeof(float))) { chunks = 1; kchunk = (K + 63) / 64 * 64; }
+        float* slabs = chunks > 1 ? (float*)workspace : nullptr;
         dim3 grid((unsigned)((N + 3) / 4), (unsigned)chunks);
-        hipLaunchKernelGGL(linear_fwd_skinny_kernel, grid, dim3(256), 0, st, x, W, b, y, (int)M, K, N, x_stride, y_stride, kchunk, act, use_atomic);
+        hipLaunchKernelGGL(linear_fwd_skinny_kernel, grid, dim3(256), 0, st, x, W, b, y, (int)M, K, N, x_stride, y_stride, kchunk, act, slabs);
         CVAE_CHECK_LAUNCH();
-        if (use_atomic && (b || act != CVAE_ACT_NONE)) {
-            hipLaunchKernelGGL(bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, st, y, b, M, N, y_stride, act);
+        if (slabs) {
+            hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, st, (const float*)slabs, (int)chunks, y, b, M, N, y_stride, act);
             CVAE_CHECK_LAUNCH();
         }
         return CVAE_OK;
     }
-    return gemm_f32(x, W, y, b, M, N, K, x_stride, 1, 1, K, y_stride, act, (hipStream_t)stream);
+    return gemm_f32(x, W, y, b, M, N, K, x_stride, 1, 1, K, y_stride, act, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 extern "C" int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N,
-                                    int64_t dy_stride, int64_t dx_stride, const float* y_act, int act, void* stream) {
+                                    int64_t dy_stride, int64_t dx_stride, const float* y_act, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (dy_stride < N) return CVAE_E_BADSHAPE;
     if (act == CVAE_ACT_NONE) y_act = nullptr;
     if (y_act && !(M > 0 && M <= SK_M)) return CVAE_E_UNSUPPORTED;      // fused activation gradient: skinny path only
-    if (M > 0 && M <= SK_M && K >= 1024 && N > 0 && dx_stride >= K) {
+    // skinny path: wide layers (K >= 1024) always; narrow ones when the activation gradient is fused (materialise-free)
+    if (M > 0 && M <= SK_M && N > 0 && dx_stride >= K && (K >= 1024 || y_act)) {
         if (!dy || !W || !dx) return CVAE_E_NULLPTR;
         hipStream_t st = (hipStream_t)stream;
-        if (hipMemset2DAsync(dx, (size_t)dx_stride * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
         const int64_t kb = (K + 255) / 256;
-        int64_t chunks = (2048 + kb - 1) / kb;                // >= 8 waves per SIMD worth of blocks: the W stream is latency-bound per wave
-        if (chunks > N / 16) chunks = N / 16;
-        if (chunks < 1) chunks = 1;
-        const int64_t nchunk = (N + chunks - 1) / chunks;
-        chunks = (N + nchunk - 1) / nchunk;
-        hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk, y_act, act);
+        int64_t nchunk;
+        int64_t chunks = skinny_bwd_chunks(K, N, K >= 1024, &nchunk);
+        if (chunks > 1 && (!workspace || workspace_bytes < (size_t)chunks * M * K * sizeof(float))) { chunks = 1; nchunk = N; }
+        float* slabs = chunks > 1 ? (float*)workspace : nullptr;
+        hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk, y_act, act, slabs);
         CVAE_CHECK_LAUNCH();
+        if (slabs) {
+            hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * K, 256)), dim3(256), 0, st, (const float*)slabs, (int)chunks, dx, (const float*)nullptr, M, K, dx_stride, CVAE_ACT_NONE);
+            CVAE_CHECK_LAUNCH();
+        }
         return CVAE_OK;
     }
-    if (y_act) {                                            // M <= 16 but K < 1024: materialise-free path = one block row per k-chunk of the generic grid
-        if (!dy || !W || !dx) return CVAE_E_NULLPTR;
-        hipStream_t st = (hipStream_t)stream;
-        if (hipMemset2DAsync(dx, (size_t)dx_stride * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, st) != hipSuccess) return CVAE_E_LAUNCH;
-        const int64_t kb = (K + 255) / 256;
-        int64_t chunks = N / 8; if (chunks < 1) chunks = 1; if (chunks > 256) chunks = 256;     // tiny W: spread the n reduction over many blocks
-        const int64_t nchunk = (N + chunks - 1) / chunks;
-        chunks = (N + nchunk - 1) / nchunk;
-        hipLaunchKernelGGL(linear_bwd_data_skinny_kernel, dim3((unsigned)kb, (unsigned)chunks), dim3(256), 0, st, dy, W, dx, (int)M, K, N, dy_stride, dx_stride, nchunk, y_act, act);
-        CVAE_CHECK_LAUNCH();
-        return CVAE_OK;
-    }
-    return gemm_f32(dy, W, dx, nullptr, M, K, N, dy_stride, 1, K, 1, dx_stride, CVAE_ACT_NONE, (hipStream_t)stream);
+    return gemm_f32(dy, W, dx, nullptr, M, K, N, dy_stride, 1, K, 1, dx_stride, CVAE_ACT_NONE, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 extern "C" int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N,
-                                      int64_t dy_stride, int64_t x_stride, const float* y_act, int act, void* stream) {
+                                      int64_t dy_stride, int64_t x_stride, const float* y_act, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (dy_stride < N || x_stride < K || M <= 0) return CVAE_E_BADSHAPE;
     if (act == CVAE_ACT_NONE) y_act = nullptr;
     if (y_act && M > SK_M) return CVAE_E_UNSUPPORTED;
@@ -310,12 +357,12 @@ extern "C" int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW
         CVAE_CHECK_LAUNCH();
         return CVAE_OK;
     } else {
-        rc = gemm_f32(dy, x, dW, nullptr, N, K, M, 1, dy_stride, x_stride, 1, K, CVAE_ACT_NONE, (hipStream_t)stream);
+        rc = gemm_f32(dy, x, dW, nullptr, N, K, M, 1, dy_stride, x_stride, 1, K, CVAE_ACT_NONE, (float*)workspace, workspace_bytes, (hipStream_t)stream);
     }
     if (rc != CVAE_OK) return rc;
     if (db) {
         if (dy_stride != N) return CVAE_E_UNSUPPORTED;
-        return cvae_channel_sum(dy, db, M, N, CVAE_F32, stream);
+        return cvae_channel_sum(dy, db, M, N, CVAE_F32, workspace, workspace_bytes, stream);    // stream order: the GEMM's slabs are consumed by then
     }
     return CVAE_OK;
 }

@@ -1,15 +1,49 @@
 // losses.hip — fp32 reductions and small per-row kernels of the ELBO: reparameterise + KLD, SSE / BCE / weighted-MSE
 // reconstruction terms, Gaussian NLL, softmax CE, uniform-KL, BatchNorm1d, Philox sampling, fused Adam, grad norm.
 // Reduction pattern everywhere: float4 grid-stride loads -> per-thread partial -> wave64 xor-shuffle -> LDS across
-// the 4 waves -> ONE atomicAdd per block (cdna_hip_programming.md Guideline 12, Appendix B "Reduction").
+// the 4 waves -> ONE plain store per block into the caller's scratch; a single-block finish launch adds the block sums in
+// index order (cdna_hip_programming.md Guideline 12: "use the slab form when results must be bitwise reproducible").
+// No float atomics anywhere: two runs on the same inputs give the same bits.
 #include "common.h"
 
 #define RED_BLOCK 256
-static inline int red_grid(int64_t n) { return cvae_grid_1d((n + 3) / 4, RED_BLOCK, 1024); }
+#define RED_MAX_BLOCKS 1024
+#define RED_MAX_OUT 2
+extern "C" size_t cvae_reduce_workspace_bytes(void) { return (size_t)RED_MAX_BLOCKS * RED_MAX_OUT * sizeof(float); }
+// Grid of a reduction over `items` work items: capped, and a single block when the caller gave no (or too little) scratch.
+static inline int red_grid_ws(int64_t items, int block, int cap, int nout, const void* ws, size_t ws_bytes) {
+    int g = cvae_grid_1d(items, block, cap < RED_MAX_BLOCKS ? cap : RED_MAX_BLOCKS);
+    if (g > 1 && (!ws || ws_bytes < (size_t)g * nout * sizeof(float))) g = 1;
+    return g;
+}
+// thread 0 of a block hands over its block sum: straight into *out when the launch is one block, else into slot blockIdx.x of row o
+__device__ __forceinline__ void red_emit(float s, float* __restrict__ out, float* __restrict__ ws, int o) {
+    if (gridDim.x == 1) out[o] += s;
+    else ws[(size_t)o * gridDim.x + blockIdx.x] = s;
+}
+// out[o] += sum_b ws[o][b], b in index order (one block; NOUT rows)
+template <int NOUT>
+__global__ __launch_bounds__(RED_BLOCK) void red_finish_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ out) {
+    __shared__ float red[RED_BLOCK / 64];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < nblocks; i += RED_BLOCK) acc += ws[(size_t)o * nblocks + i];
+        const float s = block_sum(acc, red);
+        if (threadIdx.x == 0) out[o] += s;
+    }
+}
+#define RED_FINISH(NOUT, grid, ws, out, stream)                                                                      \
+    do {                                                                                                              \
+        if ((grid) > 1) {                                                                                             \
+            hipLaunchKernelGGL((red_finish_kernel<NOUT>), dim3(1), dim3(RED_BLOCK), 0, (hipStream_t)(stream), (const float*)(ws), (int)(grid), out); \
+            CVAE_CHECK_LAUNCH();                                                                                      \
+        }                                                                                                             \
+    } while (0)
 
 // Generic two-input streaming reduction: F(a, b) -> float, summed.
 template <typename F>
-__global__ void reduce2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n, F f) {
+__global__ void reduce2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, float* __restrict__ ws, int64_t n, F f) {
     __shared__ float red[RED_BLOCK / 64];
     float acc = 0.f;
     const int64_t n4 = n >> 2;
@@ -26,7 +60,7 @@ __global__ void reduce2_kernel(const float* __restrict__ a, const float* __restr
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += f(a[i], b[i]);
     }
     const float s = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) red_emit(s, out, ws, 0);
 }
 
 struct SseF { __device__ float operator()(float a, float b) const { const float d = a - b; return d * d; } };
@@ -39,20 +73,22 @@ struct BceF {   // -(x*max(log p, -100) + (1-x)*max(log(1-p), -100))  — aten b
     }
 };
 
-#define LAUNCH_RED2(F, a, b, out, n, stream)                                                                         \
+#define LAUNCH_RED2(F, a, b, out, n, ws, wsb, stream)                                                                \
     do {                                                                                                              \
         if ((n) < 0) return CVAE_E_BADSHAPE;                                                                          \
         if ((n) == 0) return CVAE_OK;                                                                                 \
         if (!(a) || !(b) || !(out)) return CVAE_E_NULLPTR;                                                            \
-        hipLaunchKernelGGL((reduce2_kernel<F>), dim3(red_grid(n)), dim3(RED_BLOCK), 0, (hipStream_t)(stream), a, b, out, n, F()); \
+        const int grid__ = red_grid_ws(((n) + 3) / 4, RED_BLOCK, RED_MAX_BLOCKS, 1, ws, wsb);                          \
+        hipLaunchKernelGGL((reduce2_kernel<F>), dim3(grid__), dim3(RED_BLOCK), 0, (hipStream_t)(stream), a, b, out, (float*)(ws), n, F()); \
         CVAE_CHECK_LAUNCH();                                                                                          \
+        RED_FINISH(1, grid__, ws, out, stream);                                                                       \
         return CVAE_OK;                                                                                               \
     } while (0)
 
-extern "C" int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* stream) { LAUNCH_RED2(SseF, a, b, out, n, stream); }
-extern "C" int cvae_sum_fwd(const float* x, float* out, int64_t n, void* stream) { LAUNCH_RED2(SumF, x, x, out, n, stream); }
-extern "C" int cvae_sqnorm(const float* g, float* out, int64_t n, void* stream) { LAUNCH_RED2(SqF, g, g, out, n, stream); }
-extern "C" int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* stream) { LAUNCH_RED2(BceF, p, x, out, n, stream); }
+extern "C" int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(SseF, a, b, out, n, ws, wsb, stream); }
+extern "C" int cvae_sum_fwd(const float* x, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(SumF, x, x, out, n, ws, wsb, stream); }
+extern "C" int cvae_sqnorm(const float* g, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(SqF, g, g, out, n, ws, wsb, stream); }
+extern "C" int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(BceF, p, x, out, n, ws, wsb, stream); }
 
 // Elementwise two-input map with a device-scalar upstream gradient.
 template <typename F>
@@ -82,9 +118,9 @@ __device__ __forceinline__ float vessel_pos_weight(float sum_x, int64_t n) {
     return fminf(fmaxf((1.f - pf) / (pf + 1e-6f), 1.f), 50.f);
 }
 __global__ void wmse_sparsity_fwd_kernel(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ sum_x,
-                                         float* __restrict__ out2, int64_t n) {
+                                         float* __restrict__ out2, float* __restrict__ ws, int64_t n, int64_t n_pos) {
     __shared__ float red[RED_BLOCK / 64];
-    const float pw = vessel_pos_weight(*sum_x, n);
+    const float pw = vessel_pos_weight(*sum_x, n_pos);
     float a0 = 0.f, a1 = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float rv = r[i], xv = x[i], d = rv - xv;
@@ -93,19 +129,21 @@ __global__ void wmse_sparsity_fwd_kernel(const float* __restrict__ r, const floa
     }
     const float s0 = block_sum(a0, red);
     const float s1 = block_sum(a1, red);
-    if (threadIdx.x == 0) { atomicAdd(&out2[0], s0); atomicAdd(&out2[1], s1); }
+    if (threadIdx.x == 0) { red_emit(s0, out2, ws, 0); red_emit(s1, out2, ws, 1); }
 }
-extern "C" int cvae_wmse_sparsity_fwd(const float* r, const float* x, const float* sum_x, float* out2, int64_t n, void* stream) {
-    if (n < 0) return CVAE_E_BADSHAPE;
+extern "C" int cvae_wmse_sparsity_fwd(const float* r, const float* x, const float* sum_x, float* out2, int64_t n, int64_t n_pos, void* ws, size_t wsb, void* stream) {
+    if (n < 0 || n_pos < n) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!r || !x || !sum_x || !out2) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(wmse_sparsity_fwd_kernel, dim3(cvae_grid_1d(n, RED_BLOCK, 1024)), dim3(RED_BLOCK), 0, (hipStream_t)stream, r, x, sum_x, out2, n);
+    const int grid = red_grid_ws(n, RED_BLOCK, RED_MAX_BLOCKS, 2, ws, wsb);
+    hipLaunchKernelGGL(wmse_sparsity_fwd_kernel, dim3(grid), dim3(RED_BLOCK), 0, (hipStream_t)stream, r, x, sum_x, out2, (float*)ws, n, n_pos);
     CVAE_CHECK_LAUNCH();
+    RED_FINISH(2, grid, ws, out2, stream);
     return CVAE_OK;
 }
 __global__ void wmse_sparsity_bwd_kernel(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ sum_x,
-                                         const float* __restrict__ g_recon, const float* __restrict__ g_sp, float* __restrict__ dr, int64_t n) {
-    const float pw = vessel_pos_weight(*sum_x, n);
+                                         const float* __restrict__ g_recon, const float* __restrict__ g_sp, float* __restrict__ dr, int64_t n, int64_t n_pos) {
+    const float pw = vessel_pos_weight(*sum_x, n_pos);
     const float gr = g_recon ? *g_recon : 0.f, gs = g_sp ? *g_sp : 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float rv = r[i], xv = x[i];
@@ -114,18 +152,18 @@ __global__ void wmse_sparsity_bwd_kernel(const float* __restrict__ r, const floa
         dr[i] = g;
     }
 }
-extern "C" int cvae_wmse_sparsity_bwd(const float* r, const float* x, const float* sum_x, const float* g_recon, const float* g_sp, float* dr, int64_t n, void* stream) {
-    if (n < 0) return CVAE_E_BADSHAPE;
+extern "C" int cvae_wmse_sparsity_bwd(const float* r, const float* x, const float* sum_x, const float* g_recon, const float* g_sp, float* dr, int64_t n, int64_t n_pos, void* stream) {
+    if (n < 0 || n_pos < n) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!r || !x || !sum_x || !dr) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(wmse_sparsity_bwd_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, r, x, sum_x, g_recon, g_sp, dr, n);
+    hipLaunchKernelGGL(wmse_sparsity_bwd_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, r, x, sum_x, g_recon, g_sp, dr, n, n_pos);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
 
 // ------------------------------------------------------------------------------------- reparameterise + KLD
 __global__ void reparam_kld_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
-                                       float* __restrict__ z, float* __restrict__ kld, int64_t n) {
+                                       float* __restrict__ z, float* __restrict__ kld, float* __restrict__ ws, int64_t n) {
     __shared__ float red[RED_BLOCK / 64];
     float acc = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -135,15 +173,18 @@ __global__ void reparam_kld_fwd_kernel(const float* __restrict__ mu, const float
     }
     if (kld) {
         const float s = block_sum(acc, red);
-        if (threadIdx.x == 0) atomicAdd(kld, -0.5f * s);
+        if (threadIdx.x == 0) red_emit(-0.5f * s, kld, ws, 0);
     }
 }
-extern "C" int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* stream) {
+extern "C" int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* ws, size_t wsb, void* stream) {
     if (n < 0) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!mu || !logvar || (z && !eps) || (!z && !kld)) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(reparam_kld_fwd_kernel, dim3(cvae_grid_1d(n, RED_BLOCK, 256)), dim3(RED_BLOCK), 0, (hipStream_t)stream, mu, logvar, eps, z, kld, n);
+    // without a KLD output nothing is reduced: any grid; with one, the block sums need scratch (or a single block)
+    const int grid = kld ? red_grid_ws(n, RED_BLOCK, 256, 1, ws, wsb) : cvae_grid_1d(n, RED_BLOCK, 256);
+    hipLaunchKernelGGL(reparam_kld_fwd_kernel, dim3(grid), dim3(RED_BLOCK), 0, (hipStream_t)stream, mu, logvar, eps, z, kld, (float*)ws, n);
     CVAE_CHECK_LAUNCH();
+    if (kld) RED_FINISH(1, grid, ws, kld, stream);
     return CVAE_OK;
 }
 __global__ void reparam_kld_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ gkld, float gk_scale, const float* __restrict__ mu,
@@ -180,7 +221,7 @@ extern "C" int cvae_combine3(float* out4, float wb, float wc, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------- Gaussian NLL
-__global__ void gauss_nll_fwd_kernel(const float* __restrict__ m, const float* __restrict__ mu, const float* __restrict__ lv, float* __restrict__ out, int64_t n) {
+__global__ void gauss_nll_fwd_kernel(const float* __restrict__ m, const float* __restrict__ mu, const float* __restrict__ lv, float* __restrict__ out, float* __restrict__ ws, int64_t n) {
     __shared__ float red[RED_BLOCK / 64];
     float acc = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -188,14 +229,16 @@ __global__ void gauss_nll_fwd_kernel(const float* __restrict__ m, const float* _
         acc += lv[i] + d * d / expf(lv[i]);
     }
     const float s = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, 0.5f * s);
+    if (threadIdx.x == 0) red_emit(0.5f * s, out, ws, 0);
 }
-extern "C" int cvae_gauss_nll_fwd(const float* m, const float* mu, const float* lv, float* out, int64_t n, void* stream) {
+extern "C" int cvae_gauss_nll_fwd(const float* m, const float* mu, const float* lv, float* out, int64_t n, void* ws, size_t wsb, void* stream) {
     if (n < 0) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!m || !mu || !lv || !out) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(gauss_nll_fwd_kernel, dim3(cvae_grid_1d(n, RED_BLOCK, 256)), dim3(RED_BLOCK), 0, (hipStream_t)stream, m, mu, lv, out, n);
+    const int grid = red_grid_ws(n, RED_BLOCK, 256, 1, ws, wsb);
+    hipLaunchKernelGGL(gauss_nll_fwd_kernel, dim3(grid), dim3(RED_BLOCK), 0, (hipStream_t)stream, m, mu, lv, out, (float*)ws, n);
     CVAE_CHECK_LAUNCH();
+    RED_FINISH(1, grid, ws, out, stream);
     return CVAE_OK;
 }
 __global__ void gauss_nll_bwd_kernel(const float* __restrict__ m, const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ gout,
@@ -220,7 +263,8 @@ extern "C" int cvae_gauss_nll_bwd(const float* m, const float* mu, const float* 
 // One wave per row, lane = class: max and sum by xor-shuffle.
 template <int MODE>   // 0: cross-entropy vs target; 1: KL(uniform || softmax)
 __global__ void row_softmax_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ gout,
-                                        float* __restrict__ out, float* __restrict__ dlogits, int64_t B, int64_t C) {
+                                        float* __restrict__ out, float* __restrict__ dlogits, float* __restrict__ ws, int64_t B, int64_t C) {
+    __shared__ float red[4];
     const int lane = threadIdx.x & 63;
     const int64_t row0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nrow = ((int64_t)gridDim.x * blockDim.x) >> 6;
     float acc = 0.f;
@@ -243,25 +287,26 @@ __global__ void row_softmax_loss_kernel(const float* __restrict__ logits, const 
             else if (lane < C) acc += u * (logf(u) - logp) / (float)B;   // kl_div(input=logp, target=u): u*(log u - logp), batchmean
         }
     }
-    if (!dlogits) {
-        acc = wave_sum(acc);
-        if (lane == 0) atomicAdd(out, acc);
+    if (!dlogits) {                                          // wave sums -> block sum in wave order -> scratch slot (no atomics)
+        const float s = block_sum(acc, red);
+        if (threadIdx.x == 0) red_emit(s, out, ws, 0);
     }
 }
-static int row_loss(int mode, const float* logits, const int64_t* target, const float* gout, float* out, float* dl, int64_t B, int64_t C, void* stream) {
+static int row_loss(int mode, const float* logits, const int64_t* target, const float* gout, float* out, float* dl, int64_t B, int64_t C, void* ws, size_t wsb, void* stream) {
     if (B < 0 || C <= 0 || C > 64) return (C > 64) ? CVAE_E_UNSUPPORTED : CVAE_E_BADSHAPE;
     if (B == 0) return CVAE_OK;
     if (!logits || (mode == 0 && !target) || (!out && !dl)) return CVAE_E_NULLPTR;
-    const int grid = cvae_grid_1d(B * 64, 256, 256);
-    if (mode == 0) hipLaunchKernelGGL(row_softmax_loss_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, gout, out, dl, B, C);
-    else hipLaunchKernelGGL(row_softmax_loss_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, gout, out, dl, B, C);
+    const int grid = dl ? cvae_grid_1d(B * 64, 256, 256) : red_grid_ws(B * 64, 256, 256, 1, ws, wsb);
+    if (mode == 0) hipLaunchKernelGGL(row_softmax_loss_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, gout, out, dl, (float*)ws, B, C);
+    else hipLaunchKernelGGL(row_softmax_loss_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, gout, out, dl, (float*)ws, B, C);
     CVAE_CHECK_LAUNCH();
+    if (!dl) RED_FINISH(1, grid, ws, out, stream);
     return CVAE_OK;
 }
-extern "C" int cvae_softmax_ce_fwd(const float* logits, const int64_t* target, float* out, int64_t B, int64_t C, void* stream) { return row_loss(0, logits, target, nullptr, out, nullptr, B, C, stream); }
-extern "C" int cvae_softmax_ce_bwd(const float* logits, const int64_t* target, const float* gout, float* dl, int64_t B, int64_t C, void* stream) { return row_loss(0, logits, target, gout, nullptr, dl, B, C, stream); }
-extern "C" int cvae_uniform_kl_fwd(const float* logits, float* out, int64_t B, int64_t C, void* stream) { return row_loss(1, logits, nullptr, nullptr, out, nullptr, B, C, stream); }
-extern "C" int cvae_uniform_kl_bwd(const float* logits, const float* gout, float* dl, int64_t B, int64_t C, void* stream) { return row_loss(1, logits, nullptr, gout, nullptr, dl, B, C, stream); }
+extern "C" int cvae_softmax_ce_fwd(const float* logits, const int64_t* target, float* out, int64_t B, int64_t C, void* ws, size_t wsb, void* stream) { return row_loss(0, logits, target, nullptr, out, nullptr, B, C, ws, wsb, stream); }
+extern "C" int cvae_softmax_ce_bwd(const float* logits, const int64_t* target, const float* gout, float* dl, int64_t B, int64_t C, void* stream) { return row_loss(0, logits, target, gout, nullptr, dl, B, C, nullptr, 0, stream); }
+extern "C" int cvae_uniform_kl_fwd(const float* logits, float* out, int64_t B, int64_t C, void* ws, size_t wsb, void* stream) { return row_loss(1, logits, nullptr, nullptr, out, nullptr, B, C, ws, wsb, stream); }
+extern "C" int cvae_uniform_kl_bwd(const float* logits, const float* gout, float* dl, int64_t B, int64_t C, void* stream) { return row_loss(1, logits, nullptr, gout, nullptr, dl, B, C, nullptr, 0, stream); }
 
 // ------------------------------------------------------------------------------------- BatchNorm1d  (x [B, F], F <= a few hundred)
 // One wave per feature, lanes stride the batch: two shuffle reductions (mean, then centred sum of squares — the
@@ -320,6 +365,94 @@ extern "C" int cvae_bn1d_train_bwd(const float* dy, const float* x, const float*
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
+// ---- BatchNorm1d with statistics that span data-parallel ranks (SyncBN): the same arithmetic cut at the two points where the batch
+// sums are needed, so the host side can all-reduce them (2 x F floats forward, 2 x F backward) — a rank-local batch of 4 then
+// normalises exactly like the reference's single-process batch of 32.  One wave per feature, as above.
+// out[f] = sum_b x[b][f]                       (mean_sum == NULL)
+// out[f] = sum_b (x[b][f] - mean_sum[f] * inv_n)^2   (mean_sum = the all-reduced sum, inv_n = 1 / global batch)
+__global__ void bn1d_stats_kernel(const float* __restrict__ x, const float* __restrict__ mean_sum, float inv_n, float* __restrict__ out, int64_t B, int64_t F) {
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (f >= F) return;
+    const float mean = mean_sum ? mean_sum[f] * inv_n : 0.f;
+    float s = 0.f;
+    for (int64_t i = lane; i < B; i += 64) { const float d = x[i * F + f] - mean; s += mean_sum ? d * d : d; }
+    s = wave_sum(s);
+    if (lane == 0) out[f] = s;
+}
+extern "C" int cvae_bn1d_stats(const float* x, const float* mean_sum, float inv_n, float* out, int64_t B, int64_t F, void* stream) {
+    if (B < 1 || F <= 0) return CVAE_E_BADSHAPE;
+    if (!x || !out) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(bn1d_stats_kernel, dim3((unsigned)((F * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mean_sum, inv_n, out, B, F);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+// y = (x - mean) * rstd * w + b with mean = mean_sum * inv_n, var = sqdev_sum * inv_n (both sums already reduced over ranks);
+// running stats take the unbiased variance of the GLOBAL batch (n_global = 1 / inv_n).
+__global__ void bn1d_apply_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean_sum,
+                                        const float* __restrict__ sqdev_sum, float inv_n, float* __restrict__ y, float* __restrict__ save_mean,
+                                        float* __restrict__ save_rstd, float* __restrict__ rmean, float* __restrict__ rvar, int64_t B, int64_t F, float momentum,
+                                        float eps, int update_running) {
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (f >= F) return;
+    const float mean = mean_sum[f] * inv_n, var = sqdev_sum[f] * inv_n, rstd = rsqrtf(var + eps);
+    const float ww = w ? w[f] : 1.f, bb = b ? b[f] : 0.f;
+    for (int64_t i = lane; i < B; i += 64) y[i * F + f] = (x[i * F + f] - mean) * rstd * ww + bb;
+    if (lane == 0) {
+        save_mean[f] = mean;
+        save_rstd[f] = rstd;
+        if (update_running && rmean) rmean[f] = (1.f - momentum) * rmean[f] + momentum * mean;
+        const float n = 1.f / inv_n;
+        if (update_running && rvar) rvar[f] = (1.f - momentum) * rvar[f] + momentum * (sqdev_sum[f] / (n - 1.f));
+    }
+}
+extern "C" int cvae_bn1d_apply_stats(const float* x, const float* w, const float* b, const float* mean_sum, const float* sqdev_sum, float inv_n, float* y,
+                                     float* save_mean, float* save_rstd, float* running_mean, float* running_var, int64_t B, int64_t F, float momentum,
+                                     float eps, void* stream) {
+    if (B < 1 || F <= 0 || !(inv_n > 0.f) || inv_n > 0.5f) return CVAE_E_BADSHAPE;       // a global batch of >= 2 samples
+    if (!x || !mean_sum || !sqdev_sum || !y || !save_mean || !save_rstd) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(bn1d_apply_stats_kernel, dim3((unsigned)((F * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, mean_sum, sqdev_sum, inv_n, y,
+                       save_mean, save_rstd, running_mean, running_var, B, F, momentum, eps, 1);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+// sums[f] = sum_b dy[b][f] (this rank's d beta), sums[F + f] = sum_b dy[b][f] * xhat[b][f] (this rank's d gamma)
+__global__ void bn1d_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ save_mean,
+                                     const float* __restrict__ save_rstd, float* __restrict__ sums, int64_t B, int64_t F) {
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (f >= F) return;
+    const float mean = save_mean[f], rstd = save_rstd[f];
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = lane; i < B; i += 64) { const float g = dy[i * F + f]; s1 += g; s2 += g * (x[i * F + f] - mean) * rstd; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { sums[f] = s1; sums[F + f] = s2; }
+}
+extern "C" int cvae_bn1d_bwd_sums(const float* dy, const float* x, const float* save_mean, const float* save_rstd, float* sums, int64_t B, int64_t F, void* stream) {
+    if (B < 1 || F <= 0) return CVAE_E_BADSHAPE;
+    if (!dy || !x || !save_mean || !save_rstd || !sums) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(bn1d_bwd_sums_kernel, dim3((unsigned)((F * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd, sums, B, F);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+// dx = w * rstd * (dy - S1 / N - xhat * S2 / N) with S1, S2 the all-reduced sums and N the global batch
+__global__ void bn1d_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ save_mean,
+                                      const float* __restrict__ save_rstd, const float* __restrict__ sums, float inv_n, float* __restrict__ dx, int64_t B, int64_t F) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B * F; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i % F;
+        const float rstd = save_rstd[f], xh = (x[i] - save_mean[f]) * rstd;
+        dx[i] = (w ? w[f] : 1.f) * rstd * (dy[i] - sums[f] * inv_n - xh * sums[F + f] * inv_n);
+    }
+}
+extern "C" int cvae_bn1d_bwd_apply(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_rstd, const float* sums, float inv_n,
+                                   float* dx, int64_t B, int64_t F, void* stream) {
+    if (B < 1 || F <= 0 || !(inv_n > 0.f)) return CVAE_E_BADSHAPE;
+    if (!dy || !x || !save_mean || !save_rstd || !sums || !dx) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(bn1d_bwd_apply_kernel, dim3(cvae_grid_1d(B * F, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, w, save_mean, save_rstd, sums, inv_n, dx, B, F);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
 __global__ void bn1d_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ rm,
                                      const float* __restrict__ rv, float* __restrict__ y, int64_t n, int64_t F, float eps) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -344,8 +477,10 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 }
 // ADVANCE (single-block launches only): after every thread has read the call counter, thread 0 increments it — the draw and the
 // "next call draws fresh numbers" bookkeeping in one launch instead of two.
+// `subseq` selects one of 2^64 independent streams of the same key (Philox counter words 2 and 3): the Python side passes
+// (rank << 32) | instance, so data-parallel ranks and the models of one process never share a stream.
 template <bool ADVANCE>
-__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, int* __restrict__ call_dev) {
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, uint64_t subseq, int* __restrict__ call_dev) {
     if (call_dev) offset += ((uint64_t)(unsigned)(*call_dev)) << 24;       // device-side call counter: advances under graph replay
     if (ADVANCE) {
         __syncthreads();
@@ -354,7 +489,7 @@ __global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_
     const int64_t n4 = (n + 3) >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t ctr = offset + (uint64_t)i;
-        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)subseq, c3 = (uint32_t)(subseq >> 32);
         uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
         for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
@@ -368,23 +503,23 @@ __global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_
         for (int j = 0; j < 4; ++j) if (i * 4 + j < n) out[i * 4 + j] = v[j];
     }
 }
-extern "C" int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const int* call_counter, void* stream) {
+extern "C" int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, uint64_t subsequence, const int* call_counter, void* stream) {
     if (n < 0) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
     if (!out) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(philox_normal_kernel<false>, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, (int*)call_counter);
+    hipLaunchKernelGGL(philox_normal_kernel<false>, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, subsequence, (int*)call_counter);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
 __global__ void add_int_kernel(int* c, int delta);
-extern "C" int cvae_philox_normal_advance(float* out, int64_t n, uint64_t seed, uint64_t offset, int* call_counter, void* stream) {
+extern "C" int cvae_philox_normal_advance(float* out, int64_t n, uint64_t seed, uint64_t offset, uint64_t subsequence, int* call_counter, void* stream) {
     if (n < 0) return CVAE_E_BADSHAPE;
     if (!call_counter) return CVAE_E_NULLPTR;
     if (n > 0 && !out) return CVAE_E_NULLPTR;
     if (n > 0 && n <= 16384) {                               // small draws (the latent noise): one block does both
-        hipLaunchKernelGGL(philox_normal_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, call_counter);
+        hipLaunchKernelGGL(philox_normal_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, subsequence, call_counter);
     } else {
-        if (n > 0) hipLaunchKernelGGL(philox_normal_kernel<false>, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, call_counter);
+        if (n > 0) hipLaunchKernelGGL(philox_normal_kernel<false>, dim3(cvae_grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, subsequence, call_counter);
         hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, call_counter, 1);
     }
     CVAE_CHECK_LAUNCH();

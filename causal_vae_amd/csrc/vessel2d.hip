@@ -70,8 +70,9 @@ __global__ void clamp_bwd_kernel(const float* __restrict__ x, const float* __res
 
 // ------------------------------------------------------------------------------------------------ BatchNorm2d, channels-last [P][C]
 // A lane owns 8 consecutive channels (one 16-byte bf16 / two 16-byte fp32 loads per position); a 256-thread block covers
-// R = 256 / (C / 8) positions per pass.  Partial sums are combined in LDS and leave as one fp32 atomic per channel and block
-// (<= 1024 blocks; the outputs are zeroed by the caller).
+// R = 256 / (C / 8) positions per pass.  Partial sums are combined in LDS and leave as one plain store per channel and block into
+// row blockIdx.x of the caller's scratch ([gb][C] per output, gb <= 1024); the finalize launches add the rows in index order
+// (no float atomics: bit-reproducible statistics and gradients).
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
     __attribute__((aligned(16))) T raw[8];
     constexpr int NU = (8 * sizeof(T)) / 16;
@@ -89,8 +90,8 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
     for (int u = 0; u < NU; ++u) ((uint4*)p)[u] = ((const uint4*)raw)[u];
 }
 
-// MODE 0: o0 += sum x.   MODE 1: o0 += sum (x - mean)^2.
-// MODE 2: with g = dy * act'(y): o0 += sum g, o1 += sum g * (x - mean) * rstd     (dbeta, dgamma)
+// MODE 0: o0[blk] = sum x.   MODE 1: o0[blk] = sum (x - mean)^2.
+// MODE 2: with g = dy * act'(y): o0[blk] = sum g, o1[blk] = sum g * (x - mean) * rstd     (dbeta, dgamma)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn2d_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ o0,
@@ -130,27 +131,39 @@ __global__ __launch_bounds__(256) void bn2d_reduce_kernel(const T* __restrict__ 
         const int l = c >> 3, e = c & 7;
         float s0 = 0.f, s1 = 0.f;
         for (int q = 0; q < R; ++q) { s0 += red[0][q * lanes + l][e]; s1 += red[1][q * lanes + l][e]; }
-        atomicAdd(&o0[c], s0);
-        if (MODE == 2) atomicAdd(&o1[c], s1);
+        o0[(size_t)blockIdx.x * C + c] = s0;
+        if (MODE == 2) o1[(size_t)blockIdx.x * C + c] = s1;
     }
 }
 
 // y = act((x - mean) * rstd * gamma + beta); block 0 also turns the two sums into mean / rstd bookkeeping when `finalize` is set:
 // mean = sum / P (MODE stats pass 1), rstd = 1 / sqrt(sqdev / P + eps), running stats with the unbiased variance.
-__global__ void bn2d_finalize_mean_kernel(float* __restrict__ sum_to_mean, int C, float invP) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) sum_to_mean[c] *= invP;
+__device__ __forceinline__ float bn2d_row_sum(const float* __restrict__ part, int rows, int C, int c) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += part[(size_t)r * C + c];
+    return s;
 }
-__global__ void bn2d_finalize_rstd_kernel(const float* __restrict__ mean, float* __restrict__ sqdev_to_rstd, float* __restrict__ running_mean,
-                                          float* __restrict__ running_var, int C, float P, float eps, float momentum) {
+__global__ void bn2d_finalize_mean_kernel(const float* __restrict__ part, int rows, float* __restrict__ mean, int C, float invP) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) mean[c] = bn2d_row_sum(part, rows, C, c) * invP;
+}
+__global__ void bn2d_finalize_rstd_kernel(const float* __restrict__ part, int rows, const float* __restrict__ mean, float* __restrict__ rstd,
+                                          float* __restrict__ running_mean, float* __restrict__ running_var, int C, float P, float eps, float momentum) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const float var = sqdev_to_rstd[c] / P;
+    const float var = bn2d_row_sum(part, rows, C, c) / P;
     if (running_mean) {
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (P / (P - 1.f));
     }
-    sqdev_to_rstd[c] = 1.f / sqrtf(var + eps);
+    rstd[c] = 1.f / sqrtf(var + eps);
+}
+__global__ void bn2d_finalize_grads_kernel(const float* __restrict__ part_b, const float* __restrict__ part_g, int rows, float* __restrict__ dbeta,
+                                           float* __restrict__ dgamma, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = bn2d_row_sum(part_b, rows, C, c);
+    dgamma[c] = bn2d_row_sum(part_g, rows, C, c);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -191,22 +204,26 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T* __restrict
     }
 }
 
-template <typename T>
-int bn2d_fwd_t(const T* x, const float* gamma, const float* beta, T* y, float* mean, float* rstd, float* running_mean, float* running_var, int64_t P, int C,
-               float momentum, float eps, int training, int act, hipStream_t st) {
+static int64_t bn2d_blocks(int64_t P, int C) {
     const int lanes = C >> 3, R = 256 / lanes;
     int64_t gb = (P + (int64_t)R * 16 - 1) / ((int64_t)R * 16);
     if (gb > 1024) gb = 1024;
     if (gb < 1) gb = 1;
+    return gb;
+}
+template <typename T>
+int bn2d_fwd_t(const T* x, const float* gamma, const float* beta, T* y, float* mean, float* rstd, float* running_mean, float* running_var, int64_t P, int C,
+               float momentum, float eps, int training, int act, float* ws, hipStream_t st) {
+    const int lanes = C >> 3;
+    const int64_t gb = bn2d_blocks(P, C);
     if (training) {
-        if (hipMemsetAsync(mean, 0, C * sizeof(float), st) != hipSuccess || hipMemsetAsync(rstd, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
         hipLaunchKernelGGL((bn2d_reduce_kernel<T, 0>), dim3((unsigned)gb), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, mean, (float*)nullptr, P, C, 0);
-        hipLaunchKernelGGL(bn2d_finalize_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, C, 1.f / (float)P);
+                           (const float*)nullptr, ws, (float*)nullptr, P, C, 0);
+        hipLaunchKernelGGL(bn2d_finalize_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)gb, mean, C, 1.f / (float)P);
         hipLaunchKernelGGL((bn2d_reduce_kernel<T, 1>), dim3((unsigned)gb), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr, (const float*)mean,
-                           (const float*)nullptr, rstd, (float*)nullptr, P, C, 0);
-        hipLaunchKernelGGL(bn2d_finalize_rstd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)mean, rstd, running_mean, running_var, C, (float)P, eps,
-                           momentum);
+                           (const float*)nullptr, ws, (float*)nullptr, P, C, 0);
+        hipLaunchKernelGGL(bn2d_finalize_rstd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)gb, (const float*)mean, rstd, running_mean,
+                           running_var, C, (float)P, eps, momentum);
     }
     hipLaunchKernelGGL(bn2d_apply_kernel<T>, dim3(cvae_grid_1d(P * lanes, 256, 8192)), dim3(256), 0, st, x, (const float*)mean, (const float*)rstd, gamma, beta, y, P, C,
                        act);
@@ -215,13 +232,13 @@ int bn2d_fwd_t(const T* x, const float* gamma, const float* beta, T* y, float* m
 }
 template <typename T>
 int bn2d_bwd_t(const T* x, const T* dy, const T* y, const float* gamma, const float* mean, const float* rstd, T* dx, float* dgamma, float* dbeta, int64_t P, int C,
-               int act, hipStream_t st) {
-    const int lanes = C >> 3, R = 256 / lanes;
-    int64_t gb = (P + (int64_t)R * 16 - 1) / ((int64_t)R * 16);
-    if (gb > 1024) gb = 1024;
-    if (gb < 1) gb = 1;
-    if (hipMemsetAsync(dgamma, 0, C * sizeof(float), st) != hipSuccess || hipMemsetAsync(dbeta, 0, C * sizeof(float), st) != hipSuccess) return CVAE_E_LAUNCH;
-    hipLaunchKernelGGL((bn2d_reduce_kernel<T, 2>), dim3((unsigned)gb), dim3(256), 0, st, x, dy, y, mean, rstd, dbeta, dgamma, P, C, act);
+               int act, float* ws, hipStream_t st) {
+    const int lanes = C >> 3;
+    const int64_t gb = bn2d_blocks(P, C);
+    float* part_b = ws;
+    float* part_g = ws + (size_t)gb * C;
+    hipLaunchKernelGGL((bn2d_reduce_kernel<T, 2>), dim3((unsigned)gb), dim3(256), 0, st, x, dy, y, mean, rstd, part_b, part_g, P, C, act);
+    hipLaunchKernelGGL(bn2d_finalize_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)part_b, (const float*)part_g, (int)gb, dbeta, dgamma, C);
     hipLaunchKernelGGL(bn2d_bwd_apply_kernel<T>, dim3(cvae_grid_1d(P * lanes, 256, 8192)), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, (const float*)dgamma,
                        (const float*)dbeta, dx, P, C, act);
     CVAE_CHECK_LAUNCH();
@@ -260,19 +277,30 @@ extern "C" int cvae_clamp_bwd(const float* x, const float* g, float* dx, float l
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
+extern "C" size_t cvae_bn2d_workspace_bytes(int64_t P, int64_t C) {
+    if (P <= 0 || C < 8 || C % 8 || C > 2048) return 0;
+    return (size_t)2 * bn2d_blocks(P, (int)C) * C * sizeof(float);
+}
 extern "C" int cvae_bn2d_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean, float* running_var,
-                             int64_t P, int64_t C, float momentum, float eps, int training, int act, int dtype, void* stream) {
+                             int64_t P, int64_t C, float momentum, float eps, int training, int act, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (P <= 0 || C < 8 || C % 8 || C > 2048 || (training && P < 2)) return CVAE_E_BADSHAPE;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return CVAE_E_NULLPTR;
-    if (dtype == CVAE_BF16) return bn2d_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, running_mean, running_var, P, (int)C, momentum, eps, training, act, (hipStream_t)stream);
-    if (dtype == CVAE_F32) return bn2d_fwd_t<float>((const float*)x, gamma, beta, (float*)y, mean, rstd, running_mean, running_var, P, (int)C, momentum, eps, training, act, (hipStream_t)stream);
+    if (training) {
+        if (!workspace) return CVAE_E_NULLPTR;
+        if (workspace_bytes < cvae_bn2d_workspace_bytes(P, C) / 2) return CVAE_E_WORKSPACE;
+    }
+    float* ws = (float*)workspace;
+    if (dtype == CVAE_BF16) return bn2d_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, running_mean, running_var, P, (int)C, momentum, eps, training, act, ws, (hipStream_t)stream);
+    if (dtype == CVAE_F32) return bn2d_fwd_t<float>((const float*)x, gamma, beta, (float*)y, mean, rstd, running_mean, running_var, P, (int)C, momentum, eps, training, act, ws, (hipStream_t)stream);
     return CVAE_E_DTYPE;
 }
 extern "C" int cvae_bn2d_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
-                             float* dbeta, int64_t P, int64_t C, int act, int dtype, void* stream) {
+                             float* dbeta, int64_t P, int64_t C, int act, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (P <= 0 || C < 8 || C % 8 || C > 2048) return CVAE_E_BADSHAPE;
-    if (!x || !dy || !y || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return CVAE_E_NULLPTR;
-    if (dtype == CVAE_BF16) return bn2d_bwd_t<bf16>((const bf16*)x, (const bf16*)dy, (const bf16*)y, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, P, (int)C, act, (hipStream_t)stream);
-    if (dtype == CVAE_F32) return bn2d_bwd_t<float>((const float*)x, (const float*)dy, (const float*)y, gamma, mean, rstd, (float*)dx, dgamma, dbeta, P, (int)C, act, (hipStream_t)stream);
+    if (!x || !dy || !y || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return CVAE_E_NULLPTR;
+    if (workspace_bytes < cvae_bn2d_workspace_bytes(P, C)) return CVAE_E_WORKSPACE;
+    float* ws = (float*)workspace;
+    if (dtype == CVAE_BF16) return bn2d_bwd_t<bf16>((const bf16*)x, (const bf16*)dy, (const bf16*)y, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, P, (int)C, act, ws, (hipStream_t)stream);
+    if (dtype == CVAE_F32) return bn2d_bwd_t<float>((const float*)x, (const float*)dy, (const float*)y, gamma, mean, rstd, (float*)dx, dgamma, dbeta, P, (int)C, act, ws, (hipStream_t)stream);
     return CVAE_E_DTYPE;
 }

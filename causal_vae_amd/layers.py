@@ -77,6 +77,9 @@ class Linear(nn.Linear):
 
 
 class BatchNorm1d(nn.BatchNorm1d):
+    sync = False            # True (parallel.convert_sync_batchnorm): train-mode batch statistics span the ranks of `sync_group`
+    sync_group = None
+
     def forward(self, x):
         require_gpu(x)
         if x.dim() != 2:
@@ -90,6 +93,8 @@ class BatchNorm1d(nn.BatchNorm1d):
                 self.num_batches_tracked.add_(1)
             rm = self.running_mean if self.track_running_stats else None
             rv = self.running_var if self.track_running_stats else None
+            if self.sync:
+                return ops.SyncBatchNorm1dTrain.apply(x, self.weight, self.bias, rm, rv, float(self.momentum), float(self.eps), self.sync_group)
             return ops.BatchNorm1dTrain.apply(x, self.weight, self.bias, rm, rv, float(self.momentum), float(self.eps))
         if x.requires_grad and torch.is_grad_enabled():
             raise CvaeError("BatchNorm1d in eval mode is forward-only here (the reference consumers run it under no_grad)")

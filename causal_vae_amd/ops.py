@@ -65,6 +65,27 @@ def _scalar(like):
     return torch.zeros((), dtype=torch.float32, device=like.device)
 
 
+def _scratch(nbytes, like):
+    """(pointer, bytes) of `nbytes` of device scratch for one call (None, 0 when nbytes == 0).  Reductions leave their per-workgroup partial
+    sums here and add them in a fixed order (no float atomics).  A fresh block per call: safe on any stream, and inside a capture it
+    comes from the graph's pool."""
+    if not nbytes:
+        return None, None, 0
+    t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=like.device)
+    return t, t.data_ptr(), nbytes
+
+
+_RED_WS = None
+
+
+def _red_ws(like):
+    """Scratch of cvae_reduce_workspace_bytes() for the scalar loss reductions."""
+    global _RED_WS
+    if _RED_WS is None:
+        _RED_WS = int(lib.cvae_reduce_workspace_bytes())
+    return _scratch(_RED_WS, like)
+
+
 _ONES = {}
 
 
@@ -291,7 +312,9 @@ def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False):
 def _channel_sum(x):
     Cc = x.shape[-1]
     out = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    check(lib.cvae_channel_sum(ptr(x), ptr(out), x.numel() // Cc, Cc, L.dtype_code(x.dtype), stream()), "channel_sum")
+    P = x.numel() // Cc
+    _t, wp, wb = _scratch(lib.cvae_channel_sum_workspace_bytes(P, Cc, L.dtype_code(x.dtype)), x)
+    check(lib.cvae_channel_sum(ptr(x), ptr(out), P, Cc, L.dtype_code(x.dtype), wp, wb, stream()), "channel_sum")
     return out
 
 
@@ -472,7 +495,8 @@ class Linear(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         y = _empty((M, N), torch.float32, x)
-        check(lib.cvae_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), stream()), "linear_fwd")
+        _t, wp, wb = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 0), x)
+        check(lib.cvae_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()), "linear_fwd")
         ctx.save_for_backward(x, weight, y)
         ctx.cfg = (act, bias is not None)
         return y
@@ -495,12 +519,14 @@ class Linear(torch.autograd.Function):
                 dw = torch.empty_like(weight)
                 if has_bias and ctx.needs_input_grad[2]:
                     db = _empty((N,), torch.float32, g)
-                check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, ya, ac, stream()), "linear_bwd_weight")
+                _t, wp, wb = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 2), g)
+                check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, ya, ac, wp, wb, stream()), "linear_bwd_weight")
             elif has_bias and ctx.needs_input_grad[2]:
                 db = _channel_sum(_act_bwd(g, y, act) if fused else g)
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), torch.float32, g)
-            check(lib.cvae_linear_bwd_data(ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, stream()), "linear_bwd_data")
+            _t2, wp2, wb2 = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 1), g)
+            check(lib.cvae_linear_bwd_data(ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, wp2, wb2, stream()), "linear_bwd_data")
         fork.join(dw, db)
         return dx, dw, db, None
 
@@ -531,6 +557,59 @@ class BatchNorm1dTrain(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+def _group_size(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _all_reduce_sum(t, group):
+    import torch.distributed as dist
+    if _group_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class SyncBatchNorm1dTrain(torch.autograd.Function):
+    """Train-mode BatchNorm1d whose batch statistics span the data-parallel ranks of `group` (SURVEY.md §8(e) "optional tiny collectives"):
+    two all-reduces of F floats forward (sum, then sum of squared deviations: the two-pass form of the single-rank kernel) and one of 2 F
+    floats backward.  Every rank must hold the same per-rank batch size.  The weight / bias gradients returned are this rank's PARTIAL sums
+    — the gradient all-reduce of the step adds them up, like every other parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, group):
+        L.require_gpu(x)
+        x = x.contiguous()
+        B, F = x.shape
+        inv_n = 1.0 / float(B * _group_size(group))
+        s1 = _empty((F,), torch.float32, x)
+        check(lib.cvae_bn1d_stats(ptr(x), None, 0.0, ptr(s1), B, F, stream()), "bn1d_stats")
+        _all_reduce_sum(s1, group)
+        s2 = _empty((F,), torch.float32, x)
+        check(lib.cvae_bn1d_stats(ptr(x), ptr(s1), inv_n, ptr(s2), B, F, stream()), "bn1d_stats")
+        _all_reduce_sum(s2, group)
+        y = torch.empty_like(x)
+        mean, rstd = _empty((F,), torch.float32, x), _empty((F,), torch.float32, x)
+        check(lib.cvae_bn1d_apply_stats(ptr(x), ptr(weight), ptr(bias), ptr(s1), ptr(s2), inv_n, ptr(y), ptr(mean), ptr(rstd), ptr(running_mean),
+                                        ptr(running_var), B, F, momentum, eps, stream()), "bn1d_apply_stats")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.cfg = (inv_n, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, rstd = ctx.saved_tensors
+        inv_n, group = ctx.cfg
+        g = g.contiguous()
+        B, F = x.shape
+        local = _empty((2 * F,), torch.float32, x)
+        check(lib.cvae_bn1d_bwd_sums(ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(local), B, F, stream()), "bn1d_bwd_sums")
+        db, dw = local[:F].clone(), local[F:].clone()           # this rank's share of d beta / d gamma
+        _all_reduce_sum(local, group)
+        dx = torch.empty_like(x)
+        check(lib.cvae_bn1d_bwd_apply(ptr(g), ptr(x), ptr(weight), ptr(mean), ptr(rstd), ptr(local), inv_n, ptr(dx), B, F, stream()), "bn1d_bwd_apply")
+        return dx, dw, db, None, None, None, None, None
+
+
 def bn1d_eval(x, weight, bias, running_mean, running_var, eps):
     L.require_gpu(x)
     x = x.contiguous()
@@ -541,25 +620,64 @@ def bn1d_eval(x, weight, bias, running_mean, running_var, eps):
 
 
 # ------------------------------------------------------------------------------------------------ sampling + losses
-def philox_normal(shape, seed, offset, device, call_counter=None):
+def philox_normal(shape, seed, offset, device, call_counter=None, subsequence=0):
     """N(0,1) draws.  call_counter: optional device int32 tensor added (<< 24) to the offset and incremented afterwards —
-    the device-side call count that keeps a captured HIP graph drawing fresh numbers on every replay."""
+    the device-side call count that keeps a captured HIP graph drawing fresh numbers on every replay.  subsequence: which of the
+    2^64 independent streams of `seed` (Philox counter words 2-3)."""
     out = torch.empty(shape, dtype=torch.float32, device=device)
     fn = lib.cvae_philox_normal if call_counter is None else lib.cvae_philox_normal_advance
-    check(fn(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, ptr(call_counter), stream()), "philox_normal")
+    check(fn(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, subsequence & 0xFFFFFFFFFFFFFFFF, ptr(call_counter), stream()),
+          "philox_normal")
     return out
 
 
+def dist_rank():
+    """Rank of this process in the default process group (the torchrun RANK before the group exists, 0 for a single process)."""
+    import os
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    return int(os.environ.get("RANK", "0"))
+
+
 class EpsSource:
-    """Per-model device Philox stream for `reparameterize(mu, logvar)` (the reference draws torch.randn_like there)."""
+    """Per-model device Philox stream for `reparameterize(mu, logvar)` (the reference draws torch.randn_like there).
+
+    Key = torch.initial_seed() (the reference seeds everything with 42, causal_cascade/main.py:28); subsequence = (rank << 32) | instance,
+    so the ranks of a data-parallel job — which all call torch.manual_seed(42) — and the models of one process draw independent noise;
+    the call counter lives on the device (it advances under HIP-graph replay) and is part of `state()` / `load_state()` so that a resumed
+    run continues the stream instead of replaying it (causal_vae_amd.checkpoint)."""
+    _instances = 0
 
     def __init__(self):
         self.counter = None
+        self.instance = EpsSource._instances
+        EpsSource._instances += 1
+        self._pending = None
+
+    def subsequence(self, rank=None):
+        return ((dist_rank() if rank is None else int(rank)) << 32) | (self.instance & 0xFFFFFFFF)
+
+    def _ensure(self, device):
+        if self.counter is None or self.counter.device != torch.device(device):
+            start = 0 if self._pending is None else int(self._pending)
+            self.counter = torch.full((), start, dtype=torch.int32, device=device)
+            self._pending = None
 
     def draw(self, like):
-        if self.counter is None or self.counter.device != like.device:
-            self.counter = torch.zeros((), dtype=torch.int32, device=like.device)
-        return philox_normal(like.shape, torch.initial_seed(), 0, like.device, self.counter)
+        self._ensure(like.device)
+        return philox_normal(like.shape, torch.initial_seed(), 0, like.device, self.counter, self.subsequence())
+
+    def state(self):
+        """{'calls': number of draws so far} (one host sync)."""
+        return {"calls": int(self.counter.item()) if self.counter is not None else int(self._pending or 0)}
+
+    def load_state(self, st):
+        calls = int(st["calls"])
+        if self.counter is not None:
+            self.counter.fill_(calls)
+        else:
+            self._pending = calls
 
 
 class Reparameterize(torch.autograd.Function):
@@ -570,7 +688,7 @@ class Reparameterize(torch.autograd.Function):
         L.require_gpu(mu, logvar, eps)
         mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
         z = torch.empty_like(mu)
-        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), ptr(eps), ptr(z), None, mu.numel(), stream()), "reparam_fwd")
+        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), ptr(eps), ptr(z), None, mu.numel(), None, 0, stream()), "reparam_fwd")
         ctx.save_for_backward(mu, logvar, eps)
         return z
 
@@ -591,7 +709,8 @@ class KLD(torch.autograd.Function):
         L.require_gpu(mu, logvar)
         mu, logvar = mu.contiguous(), logvar.contiguous()
         out = _scalar(mu)
-        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), None, None, ptr(out), mu.numel(), stream()), "kld_fwd")
+        _t, wp, wb = _red_ws(mu)
+        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), None, None, ptr(out), mu.numel(), wp, wb, stream()), "kld_fwd")
         ctx.save_for_backward(mu, logvar)
         return out
 
@@ -617,7 +736,8 @@ class _PairLoss(torch.autograd.Function):
             raise RuntimeError(f"The size of tensor a {tuple(a.shape)} must match the size of tensor b {tuple(b.shape)}")
         out = _scalar(a)
         fwd = lib.cvae_sse_fwd if kind == "sse" else lib.cvae_bce_fwd
-        check(fwd(ptr(a), ptr(b), ptr(out), a.numel(), stream()), kind + "_fwd")
+        _t, wp, wb = _red_ws(a)
+        check(fwd(ptr(a), ptr(b), ptr(out), a.numel(), wp, wb, stream()), kind + "_fwd")
         ctx.save_for_backward(a, b)
         ctx.kind = kind
         return out
@@ -650,9 +770,10 @@ class Elbo(torch.autograd.Function):
             raise RuntimeError(f"The size of tensor a {tuple(recon_x.shape)} must match the size of tensor b {tuple(x.shape)}")
         buf = torch.zeros(4, dtype=torch.float32, device=x.device)
         base = buf.data_ptr()
-        check(lib.cvae_sse_fwd(ptr(recon_x), ptr(x), base + 4, recon_x.numel(), stream()), "sse_fwd")
-        check(lib.cvae_sse_fwd(ptr(m_hat), ptr(m), base + 8, m.numel(), stream()), "sse_fwd")
-        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), None, None, base + 12, mu.numel(), stream()), "kld_fwd")
+        _t, wp, wb = _red_ws(x)                               # one scratch block: the three reductions run in stream order
+        check(lib.cvae_sse_fwd(ptr(recon_x), ptr(x), base + 4, recon_x.numel(), wp, wb, stream()), "sse_fwd")
+        check(lib.cvae_sse_fwd(ptr(m_hat), ptr(m), base + 8, m.numel(), wp, wb, stream()), "sse_fwd")
+        check(lib.cvae_reparam_kld_fwd(ptr(mu), ptr(logvar), None, None, base + 12, mu.numel(), wp, wb, stream()), "kld_fwd")
         check(lib.cvae_combine3(base, float(gamma), 1.0, stream()), "combine3")
         ctx.save_for_backward(*ts)
         ctx.gamma = float(gamma)
@@ -747,17 +868,25 @@ def bce_sum(p, x):
 
 
 class VesselRecon(torch.autograd.Function):
-    """(recon_loss, sparsity_loss) of vessel_analysis/01_train/train.py:27-46 (pos-weighted MSE-sum, background L1)."""
+    """(recon_loss, sparsity_loss) of vessel_analysis/01_train/train.py:27-46 (pos-weighted MSE-sum, background L1).
+    group / sync: under data parallelism pos_weight is a BATCH-GLOBAL scalar in the reference (:30-36); sync=True all-reduces (sum x) over
+    `group` and uses the global element count, so every rank weights with the pos_weight of the whole batch (one 4-byte message)."""
 
     @staticmethod
-    def forward(ctx, r, x):
+    def forward(ctx, r, x, sync=False, group=None):
         L.require_gpu(r, x)
         r, x = r.contiguous(), x.contiguous()
         sx = _scalar(r)
         out2 = torch.zeros(2, dtype=torch.float32, device=r.device)
-        check(lib.cvae_sum_fwd(ptr(x), ptr(sx), x.numel(), stream()), "sum_fwd")
-        check(lib.cvae_wmse_sparsity_fwd(ptr(r), ptr(x), ptr(sx), ptr(out2), r.numel(), stream()), "wmse_sparsity_fwd")
+        _t, wp, wb = _red_ws(r)
+        check(lib.cvae_sum_fwd(ptr(x), ptr(sx), x.numel(), wp, wb, stream()), "sum_fwd")
+        n_pos = x.numel()
+        if sync and _group_size(group) > 1:
+            _all_reduce_sum(sx, group)
+            n_pos *= _group_size(group)
+        check(lib.cvae_wmse_sparsity_fwd(ptr(r), ptr(x), ptr(sx), ptr(out2), r.numel(), n_pos, wp, wb, stream()), "wmse_sparsity_fwd")
         ctx.save_for_backward(r, x, sx)
+        ctx.n_pos = n_pos
         return out2[0], out2[1]
 
     @staticmethod
@@ -766,8 +895,8 @@ class VesselRecon(torch.autograd.Function):
         dr = torch.empty_like(r)
         g_recon = g_recon.contiguous() if g_recon is not None else None
         g_sp = g_sp.contiguous() if g_sp is not None else None
-        check(lib.cvae_wmse_sparsity_bwd(ptr(r), ptr(x), ptr(sx), ptr(g_recon), ptr(g_sp), ptr(dr), r.numel(), stream()), "wmse_sparsity_bwd")
-        return dr, None
+        check(lib.cvae_wmse_sparsity_bwd(ptr(r), ptr(x), ptr(sx), ptr(g_recon), ptr(g_sp), ptr(dr), r.numel(), ctx.n_pos, stream()), "wmse_sparsity_bwd")
+        return dr, None, None, None
 
 
 class GaussNLL(torch.autograd.Function):
@@ -778,7 +907,8 @@ class GaussNLL(torch.autograd.Function):
         L.require_gpu(m, mu, logvar)
         m, mu, logvar = m.contiguous(), mu.contiguous(), logvar.contiguous()
         out = _scalar(m)
-        check(lib.cvae_gauss_nll_fwd(ptr(m), ptr(mu), ptr(logvar), ptr(out), m.numel(), stream()), "gauss_nll_fwd")
+        _t, wp, wb = _red_ws(m)
+        check(lib.cvae_gauss_nll_fwd(ptr(m), ptr(mu), ptr(logvar), ptr(out), m.numel(), wp, wb, stream()), "gauss_nll_fwd")
         ctx.save_for_backward(m, mu, logvar)
         return out
 
@@ -799,7 +929,8 @@ class SoftmaxCE(torch.autograd.Function):
         L.require_gpu(logits, target)
         logits, target = logits.contiguous(), target.contiguous()
         out = _scalar(logits)
-        check(lib.cvae_softmax_ce_fwd(ptr(logits), ptr(target), ptr(out), logits.shape[0], logits.shape[1], stream()), "softmax_ce_fwd")
+        _t, wp, wb = _red_ws(logits)
+        check(lib.cvae_softmax_ce_fwd(ptr(logits), ptr(target), ptr(out), logits.shape[0], logits.shape[1], wp, wb, stream()), "softmax_ce_fwd")
         ctx.save_for_backward(logits, target)
         return out
 
@@ -820,7 +951,8 @@ class UniformKL(torch.autograd.Function):
         L.require_gpu(logits)
         logits = logits.contiguous()
         out = _scalar(logits)
-        check(lib.cvae_uniform_kl_fwd(ptr(logits), ptr(out), logits.shape[0], logits.shape[1], stream()), "uniform_kl_fwd")
+        _t, wp, wb = _red_ws(logits)
+        check(lib.cvae_uniform_kl_fwd(ptr(logits), ptr(out), logits.shape[0], logits.shape[1], wp, wb, stream()), "uniform_kl_fwd")
         ctx.save_for_backward(logits)
         return out
 
@@ -921,9 +1053,10 @@ class BatchNorm2dAct(torch.autograd.Function):
             mean, rstd = _empty((Cc,), torch.float32, x), _empty((Cc,), torch.float32, x)
         else:
             mean, rstd = running_mean.float().clone(), torch.rsqrt(running_var.float() + eps)
+        _t, wp, wb = _scratch(lib.cvae_bn2d_workspace_bytes(P, Cc) if training else 0, x)
         check(lib.cvae_bn2d_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean) if training else None,
                                 ptr(running_var) if training else None, P, Cc, float(momentum), float(eps), 1 if training else 0, L.act_code(act),
-                                L.dtype_code(x.dtype), stream()), "bn2d_fwd")
+                                L.dtype_code(x.dtype), wp, wb, stream()), "bn2d_fwd")
         ctx.save_for_backward(x, y, weight, mean, rstd)
         ctx.cfg = (training, act)
         return y
@@ -939,8 +1072,9 @@ class BatchNorm2dAct(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         dw, db = _empty((Cc,), torch.float32, x), _empty((Cc,), torch.float32, x)
+        _t, wp, wb = _scratch(lib.cvae_bn2d_workspace_bytes(P, Cc), x)
         check(lib.cvae_bn2d_bwd(ptr(x), ptr(g), ptr(y), ptr(weight), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), P, Cc, L.act_code(act),
-                                L.dtype_code(x.dtype), stream()), "bn2d_bwd")
+                                L.dtype_code(x.dtype), wp, wb, stream()), "bn2d_bwd")
         return dx, dw, db, None, None, None, None, None, None
 
 

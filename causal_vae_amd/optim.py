@@ -95,6 +95,30 @@ class FusedAdam(torch.optim.Optimizer):
                                   arr([self.state[p]["exp_avg_sq"].data_ptr() for p in ps]), sizes, n, group["lr"], b1, b2,
                                   group["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, step_ptr, ptr(grad_scale), stream()), "adam_multi")
 
+    # ---- checkpointing: the step count lives on the device when device_step=True (it advances under HIP-graph replay while the host
+    # copies in self.state do not), so it is written back before saving and restored after loading; without this a resumed run would
+    # restart Adam's bias correction on warm moments ----
+    def _sync_step_from_device(self):
+        if self.device_step and self._step_dev is not None:
+            t = int(self._step_dev.item())
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = t
+
+    def state_dict(self):
+        self._sync_step_from_device()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = {int(st["step"]) for st in self.state.values() if "step" in st}
+        if len(steps) > 1:
+            raise L.CvaeError("FusedAdam.load_state_dict: parameters carry different step counts")
+        if self.device_step and steps:
+            dev = next(iter(self.state)).device
+            self._step_dev = torch.full((), steps.pop(), dtype=torch.int32, device=dev)
+        self._counted = False
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
         """grad_scale: optional 0-dim device tensor multiplied into every gradient (clip_grad_norm_ coefficient)."""
@@ -126,11 +150,13 @@ def clip_grad_norm_(parameters, max_norm):
     dev = params[0].device
     sq = torch.zeros((), dtype=torch.float32, device=dev)
     coef = torch.empty((), dtype=torch.float32, device=dev)
+    nws = int(lib.cvae_reduce_workspace_bytes())
+    ws = torch.empty(nws // 4, dtype=torch.float32, device=dev)     # per-workgroup partial sums, added in a fixed order (no float atomics)
     for p in params:
         g = p.grad
         if not g.is_contiguous():
             g = p.grad = g.contiguous()
-        check(lib.cvae_sqnorm(ptr(g), ptr(sq), g.numel(), stream()), "sqnorm")
+        check(lib.cvae_sqnorm(ptr(g), ptr(sq), g.numel(), ptr(ws), nws, stream()), "sqnorm")
     check(lib.cvae_clip_coef(ptr(sq), ptr(coef), float(max_norm), stream()), "clip_coef")
     for p in params:
         check(lib.cvae_scale(ptr(p.grad), p.grad.numel(), ptr(coef), stream()), "scale")

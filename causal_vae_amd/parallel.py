@@ -127,3 +127,36 @@ def all_reduce_scalars(*scalars, group=None):
     buf = torch.stack([s.detach().float() for s in scalars])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return tuple(buf.unbind(0))
+
+
+def convert_sync_batchnorm(module, group=None):
+    """Make every train-mode BatchNorm1d of `module` normalise with the statistics of the GLOBAL batch (ops.SyncBatchNorm1dTrain: 2 x F-float
+    all-reduces forward, one backward) instead of the rank-local one — the exact-equivalence option of SURVEY.md §8(e): with it (and
+    summed gradients) an N-rank step of B samples each equals the reference's single-process step on N * B samples.  The fused bottleneck
+    (ops.BioBottleneck) computes mechanism_net's BatchNorm inside its own launches, so models that have it fall back to the layer-by-layer
+    path (`fuse_bottleneck = False`: ~0.25 ms per step at 128^3).  Returns the module."""
+    from .layers import BatchNorm1d
+    found = False
+    for m in module.modules():
+        if isinstance(m, BatchNorm1d):
+            m.sync, m.sync_group, found = True, group, True
+    if found and hasattr(module, "fuse_bottleneck"):
+        module.fuse_bottleneck = False
+    return module
+
+
+def sync_buffers(module, group=None, mode="average"):
+    """BatchNorm running statistics are updated from rank-local batches and drift apart; call this before saving a checkpoint (or once
+    per epoch) so that every rank — and the file rank 0 writes — holds the same buffers.  mode 'average': mean over ranks of the floating
+    buffers (integer ones, num_batches_tracked, take the maximum); 'broadcast': rank 0's values."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    for b in module.buffers():
+        if mode == "broadcast":
+            dist.broadcast(b.data, src=0, group=group)
+        elif b.is_floating_point():
+            dist.all_reduce(b.data, op=dist.ReduceOp.SUM, group=group)
+            b.data.div_(world)
+        else:
+            dist.all_reduce(b.data, op=dist.ReduceOp.MAX, group=group)

@@ -7,8 +7,10 @@ variant, train_kfold.py:71) + 0.3*sparsity.
 from .. import ops
 
 
-def loss_function(recon_x, x, m_hat, m, mu, logvar, m_mu, m_logvar):
-    recon_loss, sparsity_loss = ops.VesselRecon.apply(recon_x, x)
+def loss_function(recon_x, x, m_hat, m, mu, logvar, m_mu, m_logvar, sync_pos_weight=False, group=None):
+    """sync_pos_weight (data parallelism only): pos_weight from the GLOBAL batch, as the reference's single process computes it (:30-36):
+    (sum x, N) are all-reduced over `group`; False = each rank weights with its own micro-batch's pos_weight (the per-rank definition)."""
+    recon_loss, sparsity_loss = ops.VesselRecon.apply(recon_x, x, sync_pos_weight, group)
     kld_loss = ops.KLD.apply(mu, logvar)
     morph_loss = ops.GaussNLL.apply(m, m_mu, m_logvar)
     return recon_loss, kld_loss, morph_loss, sparsity_loss
@@ -20,8 +22,9 @@ def total_loss(recon, kld, morph, sparsity, beta=0.5, lambda_morph=1.0):
 
 def train_step(vae, opt_vae, x, m, t, eps=None, beta=0.5, lambda_morph=1.0, max_norm=5.0):
     """One iteration of train_one_epoch's body (vessel_analysis/01_train/train.py:70-86): zero_grad -> 6-tuple forward -> vessel loss ->
-    backward -> clip_grad_norm_(5.0) -> step.  With a FusedAdam the clip coefficient stays on the device (no host sync) and is applied
-    inside the update; any other optimizer gets torch's in-place clip.  Returns (loss, recon, kld, morph) as 0-dim device tensors."""
+    backward -> clip_grad_norm_(5.0) -> step.  With a FusedAdam the norm and the clip coefficient are computed and applied on the device
+    (optim.clip_grad_norm_ scales the gradients in place, no host sync); any other optimizer gets torch's in-place clip.
+    Returns (loss, recon, kld, morph) as 0-dim device tensors."""
     from ..optim import FusedAdam, clip_grad_norm_
     opt_vae.zero_grad(set_to_none=True)
     out = vae(x, m, t) if eps is None else vae(x, m, t, eps=eps)
@@ -49,3 +52,31 @@ def train_one_epoch(epoch, vae, train_loader, opt_vae, device="cuda", beta=0.5):
         loss = train_step(vae, opt_vae, x, m, t, beta=beta)[0]
         total = loss if total is None else total + loss
     return float(total.item()) / len(train_loader.dataset)
+
+
+def validate(vae, val_loader, device="cuda", beta=0.5, verbose=False):
+    """validate(vae, val_loader) of the reference (vessel_analysis/01_train/train.py:100-133): eval mode (BatchNorm on its running
+    statistics), no_grad, the 6-tuple forward and the same loss composition as training (recon + BETA * kld + morph + 0.3 * sparsity);
+    returns sum of batch losses / len(dataset).  The reference's four `.item()` syncs per batch become one per call (sums stay on the
+    device); verbose=True prints its "[Val Breakdown]" line."""
+    import torch
+    was_training = vae.training
+    vae.eval()
+    tot = None
+    with torch.no_grad():
+        for x, m, t in val_loader:
+            x, m, t = x.to(device, non_blocking=True), m.to(device, non_blocking=True), t.to(device, non_blocking=True)
+            recon_x, m_hat, mu, logvar, m_mu, m_logvar = vae(x, m, t)
+            recon, kld, morph, sparsity = loss_function(recon_x, x, m_hat, m, mu, logvar, m_mu, m_logvar)
+            loss = total_loss(recon, kld, morph, sparsity, beta=beta)
+            row = torch.stack([loss, recon, kld, morph])
+            tot = row if tot is None else tot + row
+    if was_training:
+        vae.train()
+    n = len(val_loader.dataset)
+    if tot is None:
+        return 0.0
+    val_loss, avg_recon, avg_kld, avg_morph = (float(v) / n for v in tot.cpu())
+    if verbose:
+        print(f"   [Val Breakdown] Recon: {avg_recon:.1f} | KLD: {avg_kld:.1f} | Morph: {avg_morph:.1f}")
+    return val_loss

@@ -132,11 +132,14 @@ int cvae_clamp_bwd(const float* x, const float* g, float* dx, float lo, float hi
 /* nn.BatchNorm2d (+ fused activation `act`) on a channels-last tensor [P = B*H*W][C] (C % 8 == 0).  training: two-pass batch
  * statistics (mean, then sum of squared deviations) into mean / rstd, running_* updated with the unbiased variance (may be NULL);
  * otherwise mean / rstd are inputs (running mean, 1/sqrt(running_var + eps)).  y = act((x - mean) rstd gamma + beta). */
+/* workspace: cvae_bn2d_workspace_bytes(P, C) — per-workgroup partial rows of the channel statistics, added in index order by the
+ * finalize launches (no float atomics; required in training mode and by the backward). */
+size_t cvae_bn2d_workspace_bytes(int64_t P, int64_t C);
 int cvae_bn2d_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean, float* running_var,
-                  int64_t P, int64_t C, float momentum, float eps, int training, int act, int dtype, void* stream);
+                  int64_t P, int64_t C, float momentum, float eps, int training, int act, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* training-mode backward through the activation and the normalisation: dx, dgamma, dbeta (y = the forward's output, for act') */
 int cvae_bn2d_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
-                  float* dbeta, int64_t P, int64_t C, int act, int dtype, void* stream);
+                  float* dbeta, int64_t P, int64_t C, int act, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- The dense bottleneck of CausalBioVAE in 5 + 5 launches (batch M <= 16, fp32 arithmetic) --------------------------------
  * Replaces, between the last encoder conv and the first decoder conv (causal_cascade/models.py:57-79):
@@ -163,15 +166,16 @@ int cvae_bottleneck_sizes(const cvae_bottleneck_dims* dims, int64_t* K1, int64_t
  * writes it itself, saving the caller's one-hot launch), eps [M][Z] (the reparameterisation noise).  bn_training: batch statistics + running-stat /
  * num_batches_tracked update (running_* may be NULL), else running statistics.  Outputs: saved->mu / logvar / m_hat (the
  * model's outputs) and dec_cl [M][OD][OH][OW][C] (conv dtype) = dec_input(cat(z, m_hat)) viewed [M, C, 4..] channels-last.
- * dzm_acc: the accumulator (dzm_partial_floats of cvae_bottleneck_sizes) the backward adds d(zm) into; the forward zeroes it (keep it until
- * the backward has run). */
+ * dzm_acc: scratch of dzm_partial_floats (cvae_bottleneck_sizes) the BACKWARD fills with per-workgroup partials of d(zm) (one slot per
+ * workgroup, plain stores, summed in index order: no float atomics); the forward does not touch it (kept in the signature so one
+ * buffer can serve the pair). */
 int cvae_bottleneck_fwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, float* t_onehot,
                         const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
                         int bn_training, float* xcat, float* fwd_partial, float* dzm_acc, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype,
                         void* stream);
 /* Backward (training-mode BatchNorm only).  g_dec_cl: gradient of dec_cl; g_mu / g_logvar / g_mhat: gradients arriving at the
  * three outputs (NULL = zero).  Writes every parameter gradient and dy_cl, the gradient of y_cl (zeroed where y_cl <= 0 when
- * relu_mask).  g1 is scratch of M*(N1+N2) floats; dzm_partial is the forward's dzm_acc (zero on entry, zero again on exit). */
+ * relu_mask).  g1 is scratch of M*(N1+N2) floats; dzm_partial: dzm_partial_floats of scratch (any contents on entry). */
 int cvae_bottleneck_bwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const cvae_bottleneck_grads* grads,
                         const cvae_bottleneck_saved* saved, const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat,
                         const float* t_onehot, const float* eps, const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1,
@@ -185,8 +189,11 @@ size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd);
 int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, int dbias_side, void* workspace, size_t workspace_bytes,
                     int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                     int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream);
-/* out[c] = sum_p x[p, c] over a channels-last [P, C] tensor (bias gradients). out is overwritten. */
-int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* stream);
+/* out[c] = sum_p x[p, c] over a channels-last [P, C] tensor (bias gradients). out is overwritten.  workspace (optional,
+ * cvae_channel_sum_workspace_bytes): partial rows of a multi-workgroup pass, added in index order (no float atomics); without it
+ * the rows of one channel group are summed by ONE workgroup (same result bits for a given geometry, slower for large P). */
+size_t cvae_channel_sum_workspace_bytes(int64_t P, int64_t C, int dtype);
+int cvae_channel_sum(const void* x, float* out, int64_t P, int64_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* y = act(x) elementwise (nn.ReLU / nn.Sigmoid / nn.LeakyReLU(0.2) when not fused into a producer). */
 int cvae_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
 /* dx = dy * act'(y) elementwise (y = saved activation OUTPUT); dtype applies to all three. */
@@ -208,16 +215,20 @@ int cvae_upsample_linear_bwd(const float* ddst, void* dsrc, int64_t B, int64_t d
                              int64_t D, int64_t H, int64_t W, int64_t C, int dtype, void* stream);
 
 /* ---- fp32 linear layers ------------------------------------------------------------------------------ */
-/* y[M, N] = act(x[M, K] @ W[N, K]^T + b).  workspace: 0 bytes needed; kept for ABI stability. */
+/* Long reductions over few output tiles (the 16415-wide encoder layer at batch 4) are split across workgroups; each split leaves its
+ * partial tile in a slab of `workspace` (cvae_linear_workspace_bytes(M, K, N, op); op 0 = fwd, 1 = bwd_data, 2 = bwd_weight) and a finish
+ * launch adds the slabs in index order — no float atomics.  workspace may be NULL / smaller: the product then runs unsplit. */
+size_t cvae_linear_workspace_bytes(int64_t M, int64_t K, int64_t N, int op);
+/* y[M, N] = act(x[M, K] @ W[N, K]^T + b). */
 int cvae_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N,
-                    int64_t x_stride, int64_t y_stride, int act, void* stream);
+                    int64_t x_stride, int64_t y_stride, int act, void* workspace, size_t workspace_bytes, void* stream);
 /* dx[M, K] = g[M, N] @ W[N, K] with g = dy * act'(y_act) (y_act = the layer's saved OUTPUT, same shape/stride as dy; pass
  * NULL / CVAE_ACT_NONE for g = dy).  The fused activation gradient is available for M <= 16 (the model's batch sizes). */
 int cvae_linear_bwd_data(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N,
-                         int64_t dy_stride, int64_t dx_stride, const float* y_act, int act, void* stream);
+                         int64_t dy_stride, int64_t dx_stride, const float* y_act, int act, void* workspace, size_t workspace_bytes, void* stream);
 /* dW[N, K] = g^T x ; db[N] = column sums of g (db may be NULL).  Both overwritten.  g as above. */
 int cvae_linear_bwd_weight(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N,
-                           int64_t dy_stride, int64_t x_stride, const float* y_act, int act, void* stream);
+                           int64_t dy_stride, int64_t x_stride, const float* y_act, int act, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- BatchNorm1d --------------------------------------------------------------------------------------- */
 /* train: batch statistics (biased var) normalise; running stats updated with momentum (unbiased var). B >= 2. */
@@ -227,42 +238,64 @@ int cvae_bn1d_train_bwd(const float* dy, const float* x, const float* w, const f
                         float* dx, float* dw, float* db, int64_t B, int64_t F, void* stream);
 int cvae_bn1d_eval_fwd(const float* x, const float* w, const float* b, const float* running_mean, const float* running_var,
                        float* y, int64_t B, int64_t F, float eps, void* stream);
+/* The same BatchNorm1d cut where its batch sums appear, for statistics that span data-parallel ranks (SyncBN; the host all-reduces
+ * the F-float sum vectors between the calls: a per-rank batch of 4 then normalises like the reference's single-process batch of 32,
+ * causal_cascade/models.py:36 at the global batch):
+ *   cvae_bn1d_stats        out[f] = sum_b x[b][f] (mean_sum NULL), else sum_b (x[b][f] - mean_sum[f] * inv_n)^2
+ *   cvae_bn1d_apply_stats  y, save_mean, save_rstd, running stats from the reduced sums; inv_n = 1 / global batch
+ *   cvae_bn1d_bwd_sums     sums[0:F] = sum_b dy (this rank's d beta), sums[F:2F] = sum_b dy * xhat (this rank's d gamma)
+ *   cvae_bn1d_bwd_apply    dx from the REDUCED sums */
+int cvae_bn1d_stats(const float* x, const float* mean_sum, float inv_n, float* out, int64_t B, int64_t F, void* stream);
+int cvae_bn1d_apply_stats(const float* x, const float* w, const float* b, const float* mean_sum, const float* sqdev_sum, float inv_n, float* y,
+                          float* save_mean, float* save_rstd, float* running_mean, float* running_var, int64_t B, int64_t F, float momentum,
+                          float eps, void* stream);
+int cvae_bn1d_bwd_sums(const float* dy, const float* x, const float* save_mean, const float* save_rstd, float* sums, int64_t B, int64_t F, void* stream);
+int cvae_bn1d_bwd_apply(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_rstd, const float* sums, float inv_n,
+                        float* dx, int64_t B, int64_t F, void* stream);
 
-/* ---- sampling + losses (all reductions accumulate into a caller-zeroed fp32 scalar) ------------------------- */
-/* eps ~ N(0,1): Philox4x32-10 + Box-Muller, counter-based (seed, offset) -> reproducible per launch.  call_counter
+/* ---- sampling + losses (all reductions accumulate into a caller-zeroed fp32 scalar) -------------------------
+ * Every reduction takes (workspace, workspace_bytes): cvae_reduce_workspace_bytes() of scratch for the per-workgroup partial sums, which a
+ * one-block finish launch adds in index order — no float atomics, the sums are bit-reproducible.  NULL / too small: the reduction runs
+ * as a single workgroup (same contract, slower for large n). */
+size_t cvae_reduce_workspace_bytes(void);
+/* eps ~ N(0,1): Philox4x32-10 + Box-Muller, counter-based (seed = key, offset = counter words 0-1, subsequence = counter words 2-3)
+ * -> reproducible per launch; different subsequences are independent streams of one seed (the Python side passes
+ * (rank << 32) | model instance, so data-parallel ranks that share torch.manual_seed(42) still draw different noise).  call_counter
  * (optional device int): offset += *call_counter << 24, so a captured HIP graph draws fresh numbers on every replay. */
-int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const int* call_counter, void* stream);
+int cvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, uint64_t subsequence, const int* call_counter, void* stream);
 /* The same draw followed by *call_counter += 1 (one launch for n <= 16384): what EpsSource issues once per forward pass. */
-int cvae_philox_normal_advance(float* out, int64_t n, uint64_t seed, uint64_t offset, int* call_counter, void* stream);
+int cvae_philox_normal_advance(float* out, int64_t n, uint64_t seed, uint64_t offset, uint64_t subsequence, int* call_counter, void* stream);
 /* z = mu + eps*exp(logvar/2) (if z != NULL);  *kld += -0.5*sum(1 + logvar - mu^2 - exp(logvar)) (if kld != NULL). */
-int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* stream);
+int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps, float* z, float* kld, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
 /* dmu = dz + gk*mu ; dlogvar = dz*eps*0.5*exp(logvar/2) + gk*0.5*(exp(logvar) - 1), gk = *gkld * gk_scale;
  * dz / gkld (device scalar) may be NULL. */
 int cvae_reparam_kld_bwd(const float* dz, const float* gkld, float gk_scale, const float* mu, const float* logvar, const float* eps,
                          float* dmu, float* dlogvar, int64_t n, void* stream);
 /* *out += sum (a - b)^2 */
-int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
+int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
 /* da = 2*(a - b) * (*gout) * scale   (db = -da is formed by the caller when needed) */
 int cvae_sse_bwd(const float* a, const float* b, const float* gout, float scale, float* da, int64_t n, void* stream);
 /* out4[0] = out4[1] + wb*out4[2] + wc*out4[3]: total loss from its three terms, on the device */
 int cvae_combine3(float* out4, float wb, float wc, void* stream);
 /* F.binary_cross_entropy(p, x, reduction='sum') with torch's log clamp at -100 */
-int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* stream);
+int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_bce_bwd(const float* p, const float* x, const float* gout, float* dp, int64_t n, void* stream);
 /* vessel recon terms (vessel_analysis/01_train/train.py:27-46): stats[0] = sum(x) must be produced first by
- * cvae_sum_fwd; then out[0] += sum (r-x)^2 (1 + (pw-1) x), out[1] += sum |r| [x < 0.1], pw = clamp((1-pf)/(pf+1e-6), 1, 50). */
-int cvae_sum_fwd(const float* x, float* out, int64_t n, void* stream);
-int cvae_wmse_sparsity_fwd(const float* r, const float* x, const float* sum_x, float* out2, int64_t n, void* stream);
+ * cvae_sum_fwd; then out[0] += sum (r-x)^2 (1 + (pw-1) x), out[1] += sum |r| [x < 0.1], pw = clamp((1-pf)/(pf+1e-6), 1, 50),
+ * pf = *sum_x / (n_pos + 1e-6).  n_pos = the element count sum_x was taken over: n for a single process; under data parallelism the
+ * caller all-reduces sum_x and passes the GLOBAL count, which reproduces the reference's batch-global pos_weight (:30-36). */
+int cvae_sum_fwd(const float* x, float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
+int cvae_wmse_sparsity_fwd(const float* r, const float* x, const float* sum_x, float* out2, int64_t n, int64_t n_pos, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_wmse_sparsity_bwd(const float* r, const float* x, const float* sum_x, const float* g_recon, const float* g_sparsity,
-                           float* dr, int64_t n, void* stream);
+                           float* dr, int64_t n, int64_t n_pos, void* stream);
 /* *out += 0.5 * sum(logvar + (m - mu)^2 / exp(logvar)) */
-int cvae_gauss_nll_fwd(const float* m, const float* mu, const float* logvar, float* out, int64_t n, void* stream);
+int cvae_gauss_nll_fwd(const float* m, const float* mu, const float* logvar, float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_gauss_nll_bwd(const float* m, const float* mu, const float* logvar, const float* gout, float* dmu, float* dlogvar, int64_t n, void* stream);
 /* *out += mean_b CE(logits[b, :], target[b])  (F.cross_entropy, reduction='mean'); dlogits = (softmax - onehot)/B * gout */
-int cvae_softmax_ce_fwd(const float* logits, const int64_t* target, float* out, int64_t B, int64_t C, void* stream);
+int cvae_softmax_ce_fwd(const float* logits, const int64_t* target, float* out, int64_t B, int64_t C, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_softmax_ce_bwd(const float* logits, const int64_t* target, const float* gout, float* dlogits, int64_t B, int64_t C, void* stream);
 /* *out += F.kl_div(log_softmax(logits), full(1/C), reduction='batchmean'); dlogits = (softmax - 1/C)/B * gout */
-int cvae_uniform_kl_fwd(const float* logits, float* out, int64_t B, int64_t C, void* stream);
+int cvae_uniform_kl_fwd(const float* logits, float* out, int64_t B, int64_t C, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_uniform_kl_bwd(const float* logits, const float* gout, float* dlogits, int64_t B, int64_t C, void* stream);
 
 /* ---- optimiser ---------------------------------------------------------------------------------------------- */
@@ -280,7 +313,7 @@ int cvae_multi_copy(const float* const* src, float* const* dst, const int64_t* n
 /* *counter += delta (device int; step counters that must advance inside a captured graph) */
 int cvae_counter_add(int* counter, int delta, void* stream);
 /* *out += sum g^2 */
-int cvae_sqnorm(const float* g, float* out, int64_t n, void* stream);
+int cvae_sqnorm(const float* g, float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
 /* g *= *scale  (in place; scale is a device scalar) */
 int cvae_scale(float* g, int64_t n, const float* scale, void* stream);
 /* *scale = min(1, max_norm / (sqrt(*sqnorm) + 1e-6))   (clip_grad_norm_ coefficient, on device) */

@@ -201,28 +201,56 @@ def test_bio2d_odd_intermediate_extents_match_oracle(H, W):
             adam_close(p, sd1[k], k)
 
 
+# Stated bf16 bounds (conv GEMM inputs rounded to bf16 = 2^-9 relative, fp32 accumulate, fp32 heads / losses / master weights), measured on
+# MI355X at 4 x 128^3 and held with ~1.5x margin.  rel-L2 = ||got - ref||_2 / ||ref||_2 against the fp32 CPU oracle.
+BF16_RECON_REL_L2 = 2e-2                 # the decoder output resized to the input grid
+BF16_GRAD_REL_L2 = {                     # per-layer weight gradients: the error grows along the bf16 backward chain (decoder -> bottleneck -> encoder)
+    "dec_conv.6.weight": 0.03, "dec_conv.4.weight": 0.04, "dec_conv.2.weight": 0.05, "dec_conv.0.weight": 0.06, "dec_input.weight": 0.06,
+    "fc_mu.weight": 0.08, "fc_logvar.weight": 0.08, "enc_fc.2.weight": 0.08, "enc_fc.0.weight": 0.10,
+    "enc_conv.6.weight": 0.10, "enc_conv.4.weight": 0.12, "enc_conv.2.weight": 0.15, "enc_conv.0.weight": 0.20,
+    "mechanism_net.0.weight": 0.02, "mechanism_net.3.weight": 0.02, "mechanism_net.5.weight": 0.02,
+}
+
+
 @pytest.mark.parametrize("B,size", [(2, 64), (4, 128)])          # (4, 128): the bench workload itself (BASELINE.json north_star)
 def test_bio3d_bf16_elbo_vs_fp32_oracle(B, size):
-    """bf16 conv path (fp32 accumulate, fp32 heads and losses): ELBO relative error vs the fp32 CPU oracle, stated; every conv / linear
-    weight gradient points the way the fp32 one does."""
+    """bf16 conv path (fp32 accumulate, fp32 heads and losses) against the fp32 CPU oracle on the same batch: the ELBO within the BASELINE
+    target of 1e-4 relative, each of its three terms, the reconstruction itself (relative L2), and every weight gradient by relative L2 (not
+    only its direction) within the stated bf16 bounds above."""
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, 1, size, size, size, generator=g)
     m, t, eps = torch.rand(B, 12, generator=g), torch.randint(0, 19, (B,), generator=g), torch.randn(B, 64, generator=g)
     _, _, st = _oracle_step("bio3d", x, m, t, eps, 3)
     torch.manual_seed(42)
     model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    xd, md, td, ed = x.to(DEV), m.to(DEV), t.to(DEV), eps.to(DEV)
+    # the reconstruction and the latent heads (layer-by-layer bf16 path under no_grad; BatchNorm buffers restored afterwards)
+    bn = model.mechanism_net[1]
+    saved = (bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone())
+    with torch.no_grad():
+        recon_x, m_hat, mu, logvar = model(xd, md, td, eps=ed)
+        kld = ops_mod.KLD.apply(mu, logvar)
+    bn.running_mean.copy_(saved[0]); bn.running_var.copy_(saved[1]); bn.num_batches_tracked.copy_(saved[2])
+    ref = st["outputs"]["recon_x"]
+    rl2 = float((recon_x.cpu() - ref).norm() / ref.norm())
+    print(f"bf16 recon_x rel-L2 vs fp32 oracle: {rl2:.3e}; kld rel err {rel(kld, st['kld']):.3e}")
+    assert rl2 < BF16_RECON_REL_L2
+    assert rel(kld, st["kld"]) < 1e-3                                        # the heads are fp32: only their bf16-conv inputs differ
+    torch.testing.assert_close(m_hat.cpu(), st["outputs"]["m_hat"], rtol=1e-5, atol=1e-6)     # mechanism_net never sees a bf16 tensor
     opt = FusedAdam(model.parameters(), lr=1e-3)
-    loss, l_recon, l_m = train_step(model, opt, x.to(DEV), m.to(DEV), t.to(DEV), eps=eps.to(DEV))
+    loss, l_recon, l_m = train_step(model, opt, xd, md, td, eps=ed)                            # the fused fast path, as bench.py runs it
     err = rel(loss, st["loss"])
-    print(f"bf16 ELBO rel err vs fp32 oracle: {err:.3e} (loss {float(loss):.4f} vs {float(st['loss']):.4f})")
-    assert err < 1e-3
-    # direction of the update agrees with the fp32 gradients
+    print(f"bf16 ELBO rel err vs fp32 oracle: {err:.3e} (loss {float(loss):.4f} vs {float(st['loss']):.4f}); recon {rel(l_recon, st['recon']):.3e}, "
+          f"m_loss {rel(l_m, st['m_loss']):.3e}")
+    assert err < 1e-4                                                       # BASELINE.md target
+    assert rel(l_recon, st["recon"]) < 1e-4 and rel(l_m, st["m_loss"]) < 1e-5
     for k, p in model.named_parameters():
-        if k.endswith(".weight") and p.dim() > 1 and k != "mechanism_net.1.weight":
-            a, b = p.grad.cpu().flatten(), st["grads"][k].flatten()
+        if k.endswith(".weight") and p.dim() > 1:
+            a, b = p.grad.cpu().double().flatten(), st["grads"][k].double().flatten()
             cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-            print(f"  cos(bf16 grad, fp32 oracle grad) {k}: {cos:.5f}")
-            # the first encoder layer sits at the end of the whole bf16 backward chain: 0.989 at 4 x 128^3, > 0.995 everywhere else
+            l2 = float((a - b).norm() / b.norm())
+            print(f"  {k}: rel-L2 {l2:.4f}  cos {cos:.5f}")
+            assert l2 < BF16_GRAD_REL_L2[k], (k, l2)
             assert cos > (0.98 if k == "enc_conv.0.weight" else 0.99), (k, cos)
 
 
@@ -312,26 +340,44 @@ def test_graphed_step_matches_eager_steps():
     x, m = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
     t = torch.randint(0, 19, (2,), generator=g).to(DEV)
     lf = lambda o, xx, mm: loss_function(o[0], xx, o[1], mm, o[2], o[3])
+    ops_mod.EpsSource._instances = 0                      # same Philox subsequence for the arms compared below
     torch.manual_seed(42)
     m_e = CausalBioVAE3D().to(DEV).train()
     o_e = FusedAdam(m_e.parameters(), lr=1e-4, device_step=True)
     eager = [float(train_step(m_e, o_e, x, m, t)[0]) for _ in range(6)]
+    ops_mod.EpsSource._instances = 0                      # same Philox subsequence for the arms compared below
     torch.manual_seed(42)
     m_g = CausalBioVAE3D().to(DEV).train()
     o_g = FusedAdam(m_g.parameters(), lr=1e-4, device_step=True)
     gs = GraphedTrainStep(m_g, o_g, (x, m, t), lf, warmup=3)
     graphed = [float(gs()[0]) for _ in range(3)]
-    for a, b in zip(eager[3:], graphed):
-        assert rel(b, a) < 2e-4, (eager, graphed)
+    assert graphed == eager[3:], (eager, graphed)                   # bit for bit: no kernel on the path uses float atomics
     assert len(set(graphed)) == 3                                   # the replays really advance (weights + eps change)
-    # A few reductions use fp32 atomics (bias sums, d(zm) in csrc/bottleneck.hip), so two runs of the SAME eager loop already differ in
-    # the last bit of some gradients, and Adam's first steps (update = lr * g / |g|) amplify that where g ~ 0: two eager runs differ by
-    # up to ~6e-4 in isolated weights after 6 steps at lr = 1e-4 (tools measurement).  Bound: 2 * lr per step, and a small mean drift.
     for (k, p), q in zip(m_e.named_parameters(), m_g.parameters()):
-        if k != NOISE_KEY:
-            dlt = (p.detach() - q.detach()).abs()
-            assert float(dlt.max()) <= 2 * 1e-4 * 6 + 1e-6, k
-            assert float(dlt.mean()) <= 5e-5, k
+        assert torch.equal(p.detach(), q.detach()), k               # every weight identical after 6 steps, mechanism_net.0.bias included
+
+
+@pytest.mark.parametrize("size,dtype,fused", [(64, torch.bfloat16, True), (32, torch.float32, True), (32, torch.float32, False), (48, torch.bfloat16, False)])
+def test_two_runs_of_the_same_training_are_bit_identical(size, dtype, fused):
+    """No kernel of the train step accumulates across workgroups with float atomics (slabs / partial rows added in index order instead), so
+    6 eager steps from the same seed give the same losses and the same weights bit for bit — on the fused fast path and on the
+    layer-by-layer path (linear split-K slabs, channel sums, loss reductions)."""
+    g = torch.Generator().manual_seed(21)
+    x, m = torch.randn(3, 1, size, size, size, generator=g).to(DEV), torch.rand(3, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (3,), generator=g).to(DEV)
+    runs = []
+    for _ in range(2):
+        ops_mod.EpsSource._instances = 0                      # same Philox subsequence for the arms compared below
+        torch.manual_seed(42)
+        model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(dtype)
+        model.fuse_bottleneck = fused
+        model.fuse_recon_loss = fused
+        opt = FusedAdam(model.parameters(), lr=1e-4, device_step=True)
+        losses = [tuple(float(v) for v in train_step(model, opt, x, m, t)) for _ in range(6)]
+        runs.append((losses, {k: p.detach().clone() for k, p in model.named_parameters()}))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
 def test_split_backward_capture_matches_eager_steps():
@@ -342,25 +388,23 @@ def test_split_backward_capture_matches_eager_steps():
     g = torch.Generator().manual_seed(12)
     x, m = torch.randn(2, 1, 64, 64, 64, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
     t = torch.randint(0, 19, (2,), generator=g).to(DEV)
+    ops_mod.EpsSource._instances = 0                      # same Philox subsequence for the arms compared below
     torch.manual_seed(42)
     m_e = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
     o_e = FusedAdam(m_e.parameters(), lr=1e-4, device_step=True)
     eager = [float(train_step(m_e, o_e, x, m, t)[0]) for _ in range(6)]
+    ops_mod.EpsSource._instances = 0                      # same Philox subsequence for the arms compared below
     torch.manual_seed(42)
     m_g = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
     o_g = FusedAdam(m_g.parameters(), lr=1e-4, device_step=True)
     gs = GraphedTrainStep(m_g, o_g, (x, m, t), None, warmup=3, overlap_exchange=True)
     graphed = [float(gs()[0]) for _ in range(3)]
-    for a, b in zip(eager[3:], graphed):
-        assert rel(b, a) < 2e-4, (eager, graphed)
+    assert graphed == eager[3:], (eager, graphed)                   # same kernels, same order of every sum: bit-identical
     assert len(set(graphed)) == 3
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m_g.parameters())
     assert len(gs.red_a.params) + len(gs.red_b.params) == len(list(m_g.parameters())) and len(gs.red_b.params) == 8
     for (k, p), q in zip(m_e.named_parameters(), m_g.parameters()):
-        if k != NOISE_KEY:
-            dlt = (p.detach() - q.detach()).abs()
-            assert float(dlt.max()) <= 2 * 1e-4 * 6 + 1e-6, k
-            assert float(dlt.mean()) <= 5e-5, k
+        assert torch.equal(p.detach(), q.detach()), k
 
 
 def test_gaussian_head_variant_matches_reference_golden(golden):
@@ -535,13 +579,14 @@ def test_elbo_values_are_bit_reproducible_and_onehot_input_equals_label_input():
 
 def test_adam_overlapped_with_backward_gives_the_same_training():
     """FusedAdam.overlap_backward: the non-encoder update runs on a side stream under the encoder backward; same losses and
-    parameters as the plain step (up to the atomic-order drift bounded in test_graphed_step_matches_eager_steps)."""
+    parameters as the plain step, bit for bit."""
     from causal_vae_amd.graph import GraphedTrainStep
     g = torch.Generator().manual_seed(13)
     x, m = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
     t = torch.randint(0, 19, (2,), generator=g).to(DEV)
     runs = []
     for mode in ("plain", "overlap", "overlap-graph"):
+        ops_mod.EpsSource._instances = 0                      # same Philox subsequence for the arms compared below
         torch.manual_seed(42)
         model = CausalBioVAE3D().to(DEV).train()
         opt = FusedAdam(model.parameters(), lr=1e-4, device_step=True)
@@ -555,12 +600,9 @@ def test_adam_overlapped_with_backward_gives_the_same_training():
         torch.cuda.synchronize()
         runs.append((losses, [p.detach().clone() for p in model.parameters()], [int(opt.state[p]["step"]) for p in model.parameters()]))
     for losses, params, steps in runs[1:]:
-        for a, b in zip(runs[0][0], losses):
-            assert rel(b, a) < 2e-4, (runs[0][0], losses)
+        assert losses == runs[0][0], (runs[0][0], losses)            # bit for bit
         for (k, _), p, q in zip(CausalBioVAE3D().named_parameters(), runs[0][1], params):
-            if k != NOISE_KEY:
-                dlt = (p - q).abs()
-                assert float(dlt.max()) <= 2 * 1e-4 * 6 + 1e-6 and float(dlt.mean()) <= 5e-5, k
+            assert torch.equal(p, q), k
     assert len(set(runs[1][2])) == 1 and runs[1][2][0] == 6          # every parameter stepped exactly once per iteration
 
 
@@ -598,10 +640,47 @@ def test_vessel2d_matches_reference_golden(golden):
         assert abs(got_l2 - ref_l2) <= 2e-3 * ref_l2, (k, got_l2, ref_l2)
         assert abs(float(f.sum()) - d[0]) <= 5e-3 * d[1] + 1e-6, (k, "sum", float(f.sum()), d[0])
         np_head = f[:8].numpy()
-        # single entries of a BatchNorm-chain gradient are sums with heavy cancellation (run-to-run +-0.3 % with atomic partial sums)
+        # single entries of a BatchNorm-chain gradient are sums with heavy cancellation: summation order (ours vs aten's) moves them by ~0.3 %
         assert np.allclose(np_head, d[3:3 + len(np_head)], rtol=5e-2, atol=1e-2 * float(f.abs().max())), (k, np_head, d[3:11])
     for k in g.keys("sd1"):
         g.check("sd1", k, model.state_dict()[k], rtol=1e-3, atol=1e-5)
+
+
+def test_vessel2d_eval_mode_and_validate_match_reference_golden(golden):
+    """Eval-mode CausalVesselVAE (BatchNorm2d / BatchNorm1d on running statistics) against the reference class in eval mode on the same batch
+    (tools/make_golden.py:vessel2d_case, second file), and validate(vae, val_loader) (vessel_analysis/01_train/train.py:100-133): eval mode,
+    no_grad, same loss composition, sum / len(dataset); the model is left in the mode it came in."""
+    from conftest import vessel2d_inputs
+    from causal_vae_amd.vessel import CausalVesselVAE, loss_function as vessel_loss, total_loss, validate
+    g, ge = golden("vessel2d_b4"), golden("vessel2d_b4_eval")
+    torch.manual_seed(42)
+    model = CausalVesselVAE().to(DEV)
+    sd = model.state_dict()
+    for k in g.keys("sd1"):                                   # the buffers the reference's training forward left behind
+        sd[k].copy_(g.t("sd1/" + k).to(DEV))
+    B, seed = (int(v) for v in ge.t("in/seed"))
+    x, m, t, eps = (v.to(DEV) for v in vessel2d_inputs(B, seed))
+    model.eval()
+    with torch.no_grad():
+        out = model(x, m, t, eps=eps)
+        terms = vessel_loss(out[0], x, out[1], m, out[2], out[3], out[4], out[5])
+        total = total_loss(*terms, beta=0.5)
+    for k, v in zip(("recon_x", "m_hat", "mu", "logvar", "m_mu", "m_logvar"), out):
+        ge.check("eval", k, v, rtol=1e-3, atol=2e-4)
+    for k, v in zip(("recon", "kld", "morph", "sparsity", "total"), (*terms, total)):
+        assert rel(v, ge.t("eval/" + k)) < 1e-4, (k, float(v), float(ge.t("eval/" + k)))
+    # validate(): two batches of 2 from the same 4 samples.  The forward draws its own eps there (reference: reparameterize inside forward),
+    # so only the eps-independent structure is checked against the golden: mode handling, no gradient state, finite, per-sample scale.
+    data = [(x[i].cpu(), m[i].cpu(), t[i].cpu()) for i in range(B)]
+    loader = torch.utils.data.DataLoader(data, batch_size=2, shuffle=False)
+    model.train()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    val = validate(model, loader, device=DEV)
+    assert model.training                                                     # restored
+    assert all(torch.equal(before[k], v) for k, v in model.state_dict().items())   # eval mode: no running-stat update, no weight change
+    assert all(p.grad is None for p in model.parameters())
+    ref_per_sample = float(ge.t("eval/total")) / B
+    assert math.isfinite(val) and abs(val - ref_per_sample) < 0.05 * ref_per_sample, (val, ref_per_sample)   # eps only enters through z (5 % bound)
 
 
 def test_vessel2d_bf16_step_tracks_fp32():
@@ -643,17 +722,17 @@ def test_vessel2d_train_step_clip_and_adam_follow_torch():
         assert float((p - q).abs().max()) <= 2 * 1e-4 * 2 + 1e-7          # Adam: +-lr per step where a clipped gradient is ~0
         if k in noise:                                                     # zero-gradient biases in front of a BatchNorm: Adam steps on rounding noise
             continue
-        # run-to-run noise of the BatchNorm-chain gradients (atomics in the batch statistics) moves isolated ~0-gradient weights by a whole
-        # step; the bound is 15 % of the two steps' travel — a wrong update rule would show up as ~100 % (seen once in ~15 runs at 5 %)
+        # the two arms differ in the order the clipped gradient is rounded (scale-then-Adam vs Adam-with-scale), which moves isolated
+        # ~0-gradient weights by a whole step; the bound is 15 % of the two steps' travel — a wrong update rule would show up as ~100 %
         assert float((p - q).abs().mean()) <= 3e-5, k
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-3)], ids=["f32", "bf16"])
-def test_mnist_batch_1024_step_matches_oracle(dtype, tol):
-    """BASELINE.json configs[1]: the MNIST CausalMorphVAE12 adversarial step at batch 1024 (fp32 parity; bf16 = the configuration named there)
-    against the CPU oracle's step on the same batch: every loss term, and the direction of the VAE / discriminator updates."""
+@pytest.mark.parametrize("B,dtype,tol", [(128, torch.float32, 1e-4), (1024, torch.float32, 1e-4), (1024, torch.bfloat16, 2e-3)], ids=["b128-f32", "b1024-f32", "b1024-bf16"])
+def test_mnist_batch_1024_step_matches_oracle(B, dtype, tol):
+    """BASELINE.json configs[0] (batch 128, fp32: the reference's own mnist_test/01 configuration, config.py BATCH_SIZE) and configs[1] (the MNIST
+    CausalMorphVAE12 adversarial step at batch 1024; fp32 parity and bf16 = the configuration named there) against the CPU oracle's step on the
+    same batch: every loss term."""
     g = torch.Generator().manual_seed(1024)
-    B = 1024
     x, m = torch.rand(B, 1, 28, 28, generator=g), torch.rand(B, 12, generator=g)
     t = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float()
     eps = tuple(torch.randn(B, 10, generator=g) for _ in range(3))
@@ -679,6 +758,7 @@ def test_mnist_adversarial_step_replays_as_one_hip_graph():
     t = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float().to(DEV)
     runs = []
     for graphed in (False, True):
+        ops_mod.EpsSource._instances = 0                      # same Philox subsequence for the arms compared below
         torch.manual_seed(42)
         vae, disc = CausalMorphVAE12().to(DEV).train(), LatentDiscriminator().to(DEV).train()
         ov, od = FusedAdam(vae.parameters(), lr=1e-3, device_step=True), FusedAdam(disc.parameters(), lr=1e-3, device_step=True)
@@ -691,5 +771,5 @@ def test_mnist_adversarial_step_replays_as_one_hip_graph():
         runs.append(losses)
     for a, b in zip(*runs):
         for k in a:
-            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-4, (k, runs)
+            assert a[k] == b[k], (k, runs)                          # bit for bit: deterministic reductions everywhere
     assert len({l["loss"] for l in runs[1]}) == 3

@@ -143,6 +143,15 @@ def test_vessel2d_matches_reference(golden):
         g.check("grad", k, gr, rtol=5e-4, atol=5e-4 * scale)
     for k in g.keys("sd1"):
         g.check("sd1", k, leaves[k], rtol=2e-5, atol=1e-6)
+    # eval mode on the same batch with the running statistics just updated — the forward validate() runs (01_train/train.py:100-133)
+    ge = golden("vessel2d_b4_eval")
+    with torch.no_grad():
+        ev = ofn.vessel_vae_forward({k: v.detach() for k, v in leaves.items()}, x, m, t, eps, training=False)
+        r2, k2, mo2, sp2 = ofn.vessel_loss(ev["recon_x"], x, ev["m_hat"], m, ev["mu"], ev["logvar"], ev["m_mu"], ev["m_logvar"])
+    for k in ("recon_x", "m_hat", "mu", "logvar", "m_mu", "m_logvar"):
+        ge.check("eval", k, ev[k], rtol=5e-5, atol=5e-6)
+    for k, v in dict(recon=r2, kld=k2, morph=mo2, sparsity=sp2, total=r2 + 0.5 * k2 + mo2 + 0.3 * sp2).items():
+        ge.check("eval", k, v, rtol=5e-5, atol=1e-3)
 
 
 def test_bio3d_degenerates_to_2d_slicewise():

@@ -301,6 +301,18 @@ def vessel2d_case(name, B=4, seed_data=4321):
     pack("sd1", {k: v for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}, store)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
     print(name, "total", float(total), "keys", len(store))
+    # eval mode on the same batch, as validate() runs it (vessel_analysis/01_train/train.py:100-133): BatchNorm layers on the running
+    # statistics the training forward above has just updated (sd1), no_grad, the same loss composition.  Kept in a file of its own.
+    model.eval()
+    with torch.no_grad():
+        recon_x, m_hat, mu, logvar, m_mu, m_logvar = model(x, m, t)
+        recon, kld, morph, sparsity = lns["loss_function"](recon_x, x, m_hat, m, mu, logvar, m_mu, m_logvar)
+        total = recon + 0.5 * kld + morph + 0.3 * sparsity
+    ev = {"in/seed": np.array([B, seed_data], dtype=np.int64)}
+    pack("eval", dict(recon_x=recon_x, m_hat=m_hat, mu=mu, logvar=logvar, m_mu=m_mu, m_logvar=m_logvar, recon=recon, kld=kld, morph=morph,
+                      sparsity=sparsity, total=total), ev)
+    np.savez_compressed(os.path.join(OUT, name + "_eval.npz"), **ev)
+    print(name + "_eval", "total", float(total), "keys", len(ev))
 
 
 def main():
