@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--overlap-adam", action="store_true", help="run the non-encoder part of the Adam update on a side stream under the encoder backward")
     ap.add_argument("--fork", action="store_true", help="run weight-gradient kernels on a side stream (overlap with data-gradient kernels)")
+    ap.add_argument("--fork-max-positions", type=int, default=0, help="with --fork: only layers with at most this many S positions per batch fork (0 = all)")
+    ap.add_argument("--defer-join", action="store_true", help="with --fork: join the side stream once before the optimizer instead of after every layer")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")
     ap.add_argument("--force-overlap-exchange", action="store_true", help="take the split-backward capture also at N = 1 (no exchange happens)")
@@ -108,6 +110,8 @@ def main():
     if args.fork:
         from causal_vae_amd import ops as _ops0
         _ops0.FORK_BACKWARD = True
+        _ops0.FORK_MAX_POSITIONS = args.fork_max_positions
+        _ops0.DEFER_JOIN = args.defer_join
     rank, world, local_rank = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")

@@ -42,7 +42,7 @@ class GraphedTrainStep:
         self.g2 = self.g1b = None
         if overlap_exchange:
             self._capture_split()
-        elif reducer is None or reducer.world_size() == 1:
+        elif reducer is None or not reducer.active():
             with torch.cuda.graph(self.g1):
                 self.out = self._fwd_bwd()
                 self.opt.step()
@@ -72,7 +72,8 @@ class GraphedTrainStep:
         ids_a = {id(p) for p in params_a}
         params_b = [p for p in self.model.parameters() if p.requires_grad and id(p) not in ids_a]
         group = self.reducer.group if self.reducer is not None else None
-        self.red_a, self.red_b = GradAllReducer(params_a, group), GradAllReducer(params_b, group)
+        always = self.reducer.always_exchange if self.reducer is not None else False
+        self.red_a, self.red_b = GradAllReducer(params_a, group, always), GradAllReducer(params_b, group, always)
         self.red_a.pack(); self.red_b.pack()                 # the warm-up left every .grad in place: the flat buckets are allocated here,
         torch.cuda.synchronize()                             # in the ordinary pool, because RCCL touches them outside the graphs
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):

@@ -14,8 +14,11 @@ from ._lib import lib, check, ptr, stream
 
 
 _SIDE = {}
-FORK_BACKWARD = False      # True: weight-gradient kernels run on a side stream next to the data-gradient kernels (A/B on MI355X:
-                           # -2 % at 128^3 once the kernels fill the chip; kept as an option for small volumes)
+FORK_BACKWARD = False      # True: weight-gradient kernels run on a side stream next to the data-gradient kernels
+FORK_MAX_POSITIONS = 0     # > 0: only layers with at most this many S positions per batch fork (the small, latency-bound layers)
+DEFER_JOIN = False         # True: the side stream is not joined after each layer but once, by join_side_streams(), before the gradients are
+                           # consumed (exchange / optimizer): the weight gradients then trail the data-gradient chain instead of gating it
+_PENDING = {}              # device key -> tensors produced on the side stream since the last join (kept alive until then)
 
 
 class _Fork:
@@ -24,12 +27,14 @@ class _Fork:
     only share inputs, so the two kernels (often too small to fill 256 CUs each) overlap.  Captured graphs record the
     fork/join as dependencies."""
 
-    def __init__(self, device):
+    def __init__(self, device, positions=None):
         self.main = torch.cuda.current_stream(device)
         key = (device.index if device.index is not None else torch.cuda.current_device())
+        self.key = key
         if key not in _SIDE:
             _SIDE[key] = torch.cuda.Stream(device=device)
-        self.side = _SIDE[key] if FORK_BACKWARD else None
+        on = FORK_BACKWARD and (FORK_MAX_POSITIONS <= 0 or positions is None or positions <= FORK_MAX_POSITIONS)
+        self.side = _SIDE[key] if on else None
         self.ctx = None
 
     def __enter__(self):
@@ -45,11 +50,28 @@ class _Fork:
         return False
 
     def join(self, *tensors):
-        if self.side is not None:
-            self.main.wait_stream(self.side)
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self.main)
+        if self.side is None:
+            return
+        if DEFER_JOIN:
+            _PENDING.setdefault(self.key, []).extend(t for t in tensors if t is not None)
+            return
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.main)
+
+
+def join_side_streams():
+    """Make the current stream wait for every weight gradient still running on a side stream (DEFER_JOIN).  Called before anything reads
+    `.grad`: the gradient exchange, clip_grad_norm_, optimizer.step()."""
+    for key, tensors in list(_PENDING.items()):
+        if not tensors:
+            continue
+        main = torch.cuda.current_stream(tensors[0].device)
+        main.wait_stream(_SIDE[key])
+        for t in tensors:
+            t.record_stream(main)
+        tensors.clear()
 
 
 def _cl_dims(t):
@@ -353,7 +375,7 @@ class ConvDown(torch.autograd.Function):
             g = _act_bwd(g, y, act)
         dx = dw = db = None
         want_db = has_bias and ctx.needs_input_grad[2]
-        fork = _Fork(g.device)
+        fork = _Fork(g.device, g.shape[0] * g.shape[1] * g.shape[2] * g.shape[3])
         with fork:
             if ctx.needs_input_grad[1]:
                 if want_db:
@@ -391,7 +413,7 @@ class ConvUp(torch.autograd.Function):
         if act not in (None, "none") and not (premasked and act == "relu"):
             g = _act_bwd(g, y, act)
         dx = dw = db = None
-        fork = _Fork(g.device)
+        fork = _Fork(g.device, x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3])
         with fork:
             want_db = has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:

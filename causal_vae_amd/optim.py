@@ -126,6 +126,8 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from . import ops
+        ops.join_side_streams()                              # weight gradients still running on a side stream (ops.DEFER_JOIN)
         early_done = self._early_ran
         if early_done and grad_scale is not None:
             raise L.CvaeError("FusedAdam: grad_scale cannot be combined with overlap_backward (part of the update has already run)")
@@ -144,6 +146,8 @@ class FusedAdam(torch.optim.Optimizer):
 def clip_grad_norm_(parameters, max_norm):
     """torch.nn.utils.clip_grad_norm_ (vessel_analysis/01_train/train.py:85) without a host sync: returns
     (total_norm ** 2, coef) as 0-dim device tensors; gradients are scaled in place by coef = min(1, max_norm/(norm+1e-6))."""
+    from . import ops
+    ops.join_side_streams()
     params = [p for p in parameters if p.grad is not None]
     if not params:
         return None, None

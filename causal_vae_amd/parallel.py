@@ -38,13 +38,20 @@ class GradAllReducer:
     """Sums `.grad` of `params` across ranks through one flat bucket.  Call it between backward and optimizer.step
     (the `grad_hook` of causal_cascade.train.train_step)."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, always_exchange=False):
+        """always_exchange: issue the collective even in a one-rank group (a one-rank RCCL all-reduce is the identity; used to run the
+        capture / async-exchange machinery against RCCL on a single card)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.always_exchange = bool(always_exchange)
         self._flat = None
 
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def active(self):
+        """True when a step has to exchange gradients: more than one rank, or always_exchange inside an initialised group."""
+        return self.world_size() > 1 or (self.always_exchange and dist.is_initialized())
 
     def _grads(self):
         return [p.grad for p in self.params if p.grad is not None]
@@ -78,6 +85,9 @@ class GradAllReducer:
 
     def pack(self):
         """Copy every gradient into the flat fp32 bucket (capturable: fixed addresses once the bucket exists)."""
+        if self.params and self.params[0].is_cuda:
+            from . import ops
+            ops.join_side_streams()                          # weight gradients still running on a side stream (ops.DEFER_JOIN)
         self._copy(True)
 
     def all_reduce(self):
@@ -86,7 +96,7 @@ class GradAllReducer:
     def all_reduce_async(self):
         """Start the exchange of the packed bucket and return its Work handle (None without a process group): on RCCL it runs on the
         communicator's stream, ordered after what the current stream holds so far, and `.wait()` orders the current stream after it."""
-        if not dist.is_initialized() or self.world_size() == 1 or self._flat is None:
+        if not self.active() or self._flat is None:
             return None
         return dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -105,7 +115,7 @@ class GradAllReducer:
             off += n
 
     def __call__(self):
-        if self.world_size() == 1 or not self._grads():
+        if not self.active() or not self._grads():
             return
         self.pack()
         self.all_reduce()

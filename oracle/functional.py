@@ -49,19 +49,52 @@ def _bn1d(sd, prefix, x, training, update_running=True, momentum=0.1, bn_eps=1e-
     return F.batch_norm(x, None, None, w, b, True, momentum, bn_eps)
 
 
+class _RoundBoth(torch.autograd.Function):
+    """Value rounded to `dtype` on the way forward, gradient rounded to `dtype` on the way back: a tensor that is STORED in that dtype
+    together with its gradient (the conv activations of the bf16 build)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).float(), None
+
+
+class _RoundFwd(torch.autograd.Function):
+    """Value rounded to `dtype` forward, gradient untouched: an operand copied to that dtype whose master (and gradient) stay fp32
+    (the conv weights of the bf16 build)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return x.to(dtype).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 def bio_vae_forward(sd, x, m, t, eps, *, nd=None, training=True, update_running=True,
-                    keep_acts=False):
+                    keep_acts=False, conv_dtype=None):
     """CausalBioVAE.forward (causal_cascade/models.py:70-89) for nd=2, or its 3D lift
      for nd=3.  ``t`` is an int64 class index.  Returns a dict with
-    recon_x, m_hat, mu, logvar, z (+ per-layer activations when keep_acts)."""
+    recon_x, m_hat, mu, logvar, z (+ per-layer activations when keep_acts).
+
+    conv_dtype=torch.bfloat16 is NOT a reference mode: it restates, in fp32 CPU arithmetic, where the MI355X build's bf16 configuration
+    rounds — conv operands (activations, weights) and every stored conv activation / activation gradient are rounded to bf16, sums stay
+    fp32, the dense middle and the losses stay fp32 — so a test can separate "bf16 storage" from "kernel error"."""
     nd = x.dim() - 2 if nd is None else nd
     conv, convT = _conv(nd), _convT(nd)
+    q = (lambda v: _RoundBoth.apply(v, conv_dtype)) if conv_dtype is not None else (lambda v: v)
+    qw = (lambda v: _RoundFwd.apply(v, conv_dtype)) if conv_dtype is not None else (lambda v: v)
     t_dim = sd["mechanism_net.0.weight"].shape[1]
     t_onehot = F.one_hot(t, num_classes=t_dim).float()                    # :71
     acts = {}
-    h = x
+    h = qw(x)
     for i in range(4):                                                    # :12-16
-        h = F.relu(conv(h, sd[f"enc_conv.{2*i}.weight"], sd[f"enc_conv.{2*i}.bias"], stride=2, padding=1))
+        h = q(F.relu(conv(h, qw(sd[f"enc_conv.{2*i}.weight"]), sd[f"enc_conv.{2*i}.bias"], stride=2, padding=1)))
         acts[f"enc{i+1}"] = h
     pool = F.adaptive_avg_pool2d if nd == 2 else F.adaptive_avg_pool3d
     feat = pool(h, (4,) * nd).flatten(1)                                  # :18-19
@@ -76,12 +109,13 @@ def bio_vae_forward(sd, x, m, t, eps, *, nd=None, training=True, update_running=
     g = F.relu(_lin(sd, "mechanism_net.3", g))
     m_hat = _lin(sd, "mechanism_net.5", g)
     d = _lin(sd, "dec_input", torch.cat([z, m_hat], dim=1))               # :80-81
-    d = d.view(-1, 256, *([4] * nd))                                      # :82
+    d = q(d.view(-1, 256, *([4] * nd)))                                   # :82
     acts["dec_in"] = d
     for i in range(4):                                                    # :51-54
-        d = convT(d, sd[f"dec_conv.{2*i}.weight"], sd[f"dec_conv.{2*i}.bias"], stride=2, padding=1)
+        d = convT(d, qw(sd[f"dec_conv.{2*i}.weight"]), sd[f"dec_conv.{2*i}.bias"], stride=2, padding=1)
         if i < 3:
             d = F.relu(d)
+        d = q(d)
         acts[f"dec{i+1}"] = d
     mode = "bilinear" if nd == 2 else "trilinear"
     recon_x = F.interpolate(d, size=x.shape[2:], mode=mode, align_corners=False)   # :87

@@ -65,12 +65,12 @@ def clip_grad_norm(grads, max_norm):
 
 
 def cascade_train_step(sd, x, m, t, eps, adam_state=None, *, lr=1e-3, gamma=2000.0, nd=None,
-                       apply_update=True):
+                       apply_update=True, conv_dtype=None):
     """One iteration of train_one_epoch (causal_cascade/train.py:26-37): zero_grad ->
     forward -> loss -> backward -> Adam.  ``sd`` is updated in place (parameters and BN
     running stats).  Returns dict(loss, recon, m_loss, kld, grads, outputs)."""
     leaves = _leaves(sd)
-    out = fn.bio_vae_forward(leaves, x, m, t, eps, nd=nd, training=True)
+    out = fn.bio_vae_forward(leaves, x, m, t, eps, nd=nd, training=True, conv_dtype=conv_dtype)
     loss, recon, m_loss, kld = fn.cascade_loss(out["recon_x"], x, out["m_hat"], m,
                                                out["mu"], out["logvar"], gamma)
     keys = trainable_keys(sd)

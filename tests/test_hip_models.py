@@ -204,10 +204,13 @@ def test_bio2d_odd_intermediate_extents_match_oracle(H, W):
 # Stated bf16 bounds (conv GEMM inputs rounded to bf16 = 2^-9 relative, fp32 accumulate, fp32 heads / losses / master weights), measured on
 # MI355X at 4 x 128^3 and held with ~1.5x margin.  rel-L2 = ||got - ref||_2 / ||ref||_2 against the fp32 CPU oracle.
 BF16_RECON_REL_L2 = 2e-2                 # the decoder output resized to the input grid
-BF16_GRAD_REL_L2 = {                     # per-layer weight gradients: the error grows along the bf16 backward chain (decoder -> bottleneck -> encoder)
-    "dec_conv.6.weight": 0.03, "dec_conv.4.weight": 0.04, "dec_conv.2.weight": 0.05, "dec_conv.0.weight": 0.06, "dec_input.weight": 0.06,
-    "fc_mu.weight": 0.08, "fc_logvar.weight": 0.08, "enc_fc.2.weight": 0.08, "enc_fc.0.weight": 0.10,
-    "enc_conv.6.weight": 0.10, "enc_conv.4.weight": 0.12, "enc_conv.2.weight": 0.15, "enc_conv.0.weight": 0.20,
+BF16_GRAD_REL_L2 = {                     # per-layer weight gradients: the error grows along the bf16 backward chain (decoder -> bottleneck -> encoder).
+    # Large in relative terms because at the initial weights on N(0,1) volumes d(recon) ~ -2x is noise, and every weight gradient is a
+    # heavily cancelling sum of it; the SAME numbers come out of an fp32 computation whose conv operands are rounded to bf16
+    # (test_bio3d_bf16_matches_bf16_rounding_oracle bounds the kernels against that at ~1e-2): bf16 storage, not the kernels.
+    "dec_conv.6.weight": 0.10, "dec_conv.4.weight": 0.10, "dec_conv.2.weight": 0.10, "dec_conv.0.weight": 0.10, "dec_input.weight": 0.10,
+    "fc_mu.weight": 0.10, "fc_logvar.weight": 0.09, "enc_fc.2.weight": 0.11, "enc_fc.0.weight": 0.15,
+    "enc_conv.6.weight": 0.15, "enc_conv.4.weight": 0.17, "enc_conv.2.weight": 0.20, "enc_conv.0.weight": 0.22,
     "mechanism_net.0.weight": 0.02, "mechanism_net.3.weight": 0.02, "mechanism_net.5.weight": 0.02,
 }
 
@@ -252,6 +255,35 @@ def test_bio3d_bf16_elbo_vs_fp32_oracle(B, size):
             print(f"  {k}: rel-L2 {l2:.4f}  cos {cos:.5f}")
             assert l2 < BF16_GRAD_REL_L2[k], (k, l2)
             assert cos > (0.98 if k == "enc_conv.0.weight" else 0.99), (k, cos)
+
+
+def test_bio3d_bf16_matches_bf16_rounding_oracle():
+    """The same bf16 step against the oracle run with conv_dtype=bfloat16 (fp32 CPU arithmetic that rounds exactly where the bf16 build stores
+    bf16: conv operands, conv activations and their gradients).  Against THAT the kernels agree an order of magnitude tighter than against the
+    pure-fp32 oracle, for every weight gradient: the several-percent gaps of test_bio3d_bf16_elbo_vs_fp32_oracle are bf16 storage on noise-like
+    gradients, not kernel error."""
+    B, size = 2, 64
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 1, size, size, size, generator=g)
+    m, t, eps = torch.rand(B, 12, generator=g), torch.randint(0, 19, (B,), generator=g), torch.randn(B, 64, generator=g)
+    sd = oracle.init_state_dict("bio3d", seed=42)
+    st = oracle.cascade_train_step(sd, x, m, t, eps, nd=3, apply_update=False, conv_dtype=torch.bfloat16)
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    loss, l_recon, l_m = train_step(model, opt, x.to(DEV), m.to(DEV), t.to(DEV), eps=eps.to(DEV))
+    print(f"bf16 HIP vs bf16-rounding oracle: ELBO rel err {rel(loss, st['loss']):.3e}")
+    assert rel(loss, st["loss"]) < 2e-6 and rel(l_recon, st["recon"]) < 2e-6
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k == NOISE_KEY:
+            continue
+        a, b = p.grad.cpu().double().flatten(), st["grads"][k].double().flatten()
+        l2 = float((a - b).norm() / b.norm())
+        worst = max(worst, l2)
+        print(f"  {k}: rel-L2 vs bf16-rounding oracle {l2:.2e}")
+        assert l2 < 1.5e-2, (k, l2)                                           # measured <= ~5e-3: isolated bf16 ties / ReLU masks that flip with the summation order
+    print(f"worst rel-L2 {worst:.2e}")
 
 
 def test_consumer_access_patterns_and_checkpoint_interchange():
@@ -378,6 +410,44 @@ def test_two_runs_of_the_same_training_are_bit_identical(size, dtype, fused):
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+@pytest.mark.parametrize("graphed", [False, True], ids=["eager", "graph"])
+def test_training_state_checkpoint_resumes_the_same_run(graphed):
+    """causal_vae_amd.checkpoint: model (reference keys only) + FusedAdam (moments and the DEVICE step count) + the Philox call count.  Three
+    steps, save, three more == load into a fresh model / optimizer and run the same three: identical losses and weights, i.e. the resumed run
+    neither replays the noise of steps 1-3 nor restarts Adam's bias correction (the step count advances on the device under graph replay)."""
+    from causal_vae_amd import checkpoint
+    from causal_vae_amd.graph import GraphedTrainStep
+    g = torch.Generator().manual_seed(31)
+    x, m = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (2,), generator=g).to(DEV)
+
+    def make():
+        ops_mod.EpsSource._instances = 0
+        torch.manual_seed(42)
+        mdl = CausalBioVAE3D().to(DEV).train()
+        return mdl, FusedAdam(mdl.parameters(), lr=1e-4, device_step=True)
+    m_a, o_a = make()
+    if graphed:
+        gs = GraphedTrainStep(m_a, o_a, (x, m, t), None, warmup=3)          # the 3 capture warm-up steps ARE steps 1-3
+        step_a = lambda: float(gs()[0])
+    else:
+        step_a = lambda: float(train_step(m_a, o_a, x, m, t)[0])
+        [step_a() for _ in range(3)]
+    buf = io.BytesIO()
+    torch.save(checkpoint.training_state(m_a, o_a), buf)
+    assert set(checkpoint.training_state(m_a, o_a)["model"]) == set(oracle.init_state_dict("bio3d", seed=42))     # reference keys, nothing extra
+    cont = [step_a() for _ in range(3)]
+    buf.seek(0)
+    m_b, o_b = make()
+    checkpoint.load_training_state(torch.load(buf, map_location=DEV), m_b, o_b)
+    assert int(o_b._step_dev) == 3 and m_b._eps.state()["calls"] == 3
+    resumed = [float(train_step(m_b, o_b, x, m, t)[0]) for _ in range(3)]
+    assert resumed == cont, (cont, resumed)
+    for (k, p), q in zip(m_a.named_parameters(), m_b.parameters()):
+        assert torch.equal(p.detach(), q.detach()), k
+    assert o_b.state_dict()["state"][0]["step"] == 6
 
 
 def test_split_backward_capture_matches_eager_steps():
