@@ -31,6 +31,14 @@ METRIC = "training samples/sec on 128^3 vessel volumes (3D CausalVAE train step)
 def conv_flops(name):
     """Algorithmic FLOPs (2*MACs, no padding / zero-insertion counted: SURVEY.md §8(d)) of one conv launch from its timer label."""
     import re
+    if name.startswith("conv_wgrad_multi"):                 # one grouped launch: the sum over its layers
+        head, layers = name.rsplit(" ", 1)
+        nd_, B_ = re.search(r"nd(\d)", head).group(1), re.search(r" B(\d+)", head).group(1)
+        tot = 0.0
+        for lay in layers.split(";"):
+            mm = re.match(r"S(\d+)x(\d+)x(\d+)x(\d+)L(\d+)", lay)
+            tot += conv_flops(f"conv_wgrad nd{nd_} B{B_} S{mm.group(1)}x{mm.group(2)}x{mm.group(3)}x{mm.group(4)} L{mm.group(5)}")
+        return tot
     nd = int(re.search(r"nd(\d)", name).group(1))
     B = int(re.search(r" B(\d+)", name).group(1))
     taps = 64 if nd == 3 else 16
@@ -97,6 +105,7 @@ def main():
     ap.add_argument("--fork-max-positions", type=int, default=0, help="with --fork: only layers with at most this many S positions per batch fork (0 = all)")
     ap.add_argument("--defer-join", action="store_true", help="with --fork: join the side stream once before the optimizer instead of after every layer")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--no-defer-wgrad", action="store_true", help="compute every conv weight gradient in its own launch (A/B of the grouped end-of-backward launch)")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")
     ap.add_argument("--force-overlap-exchange", action="store_true", help="take the split-backward capture also at N = 1 (no exchange happens)")
     ap.add_argument("--roofline-steps", type=int, default=5, help="eager steps with per-launch HIP events after the timed region")
@@ -107,6 +116,9 @@ def main():
     from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters, init_distributed
     import torch.distributed as dist
 
+    if args.no_defer_wgrad:
+        from causal_vae_amd import ops as _ops1
+        _ops1.DEFER_WGRAD = False
     if args.fork:
         from causal_vae_amd import ops as _ops0
         _ops0.FORK_BACKWARD = True

@@ -46,6 +46,7 @@ SIGNATURES = {
     "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
     "cvae_conv_wgrad_workspace_bytes": [_i64, _i64, _i],
     "cvae_conv_wgrad": [_p, _p, _p, _p, _i, _p, _sz] + [_i64] * 9 + [_i, _i, _p],
+    "cvae_conv_wgrad_multi": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "cvae_channel_sum_workspace_bytes": [_i64, _i64, _i],
     "cvae_channel_sum": [_p, _p, _i64, _i64, _i, _p, _sz, _p],
     "cvae_act_fwd": [_p, _p, _i64, _i, _i, _p],

@@ -621,9 +621,31 @@ __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(PairTable tb) {
 // Workgroup: 8 waves; block of 64 cs x 32 cl; one depth tap kd (3D) / all taps (2D); wave w owns kh = w & 3, kw = 0..3 and
 // the 32-row half sg = w >> 2 of the cs block: 4 accumulator tiles (64 VGPRs), so two workgroups (16 waves) fit a CU with the
 // next tile's global loads held in registers during the MFMA phase.
+// Several layers can share ONE launch (cvae_conv_wgrad_multi: the deferred weight gradients of a whole backward pass): the grid is the
+// concatenation of the per-layer grids and a workgroup finds its layer in the table that rides in the kernel arguments.  The small layers
+// (a handful of tiles each, latency-bound on their own) then run in the shadow of the large ones instead of each paying a launch.
+#define WG_MULTI_MAX 8
+struct WgradEntry {
+    const void* S; const void* L; float* ws; float* bias_ws;
+    ConvGeom g;
+    int n_split, cb, tg, bias_mode;
+};
+struct WgradTable { WgradEntry e[WG_MULTI_MAX]; int blk_start[WG_MULTI_MAX + 1]; int count; };
+
 template <typename T, int ND>
-__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, ConvGeom g, int n_split,
-                                                                                          float* __restrict__ bias_ws, int bias_mode) {
+__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel(WgradTable tb) {
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    const T* __restrict__ S = (const T*)tb.e[ti].S;
+    const T* __restrict__ L = (const T*)tb.e[ti].L;
+    float* __restrict__ ws = tb.e[ti].ws;
+    float* __restrict__ bias_ws = tb.e[ti].bias_ws;
+    const ConvGeom g = tb.e[ti].g;
+    const int n_split = tb.e[ti].n_split, bias_mode = tb.e[ti].bias_mode, grid_y = tb.e[ti].cb;
+    // the layer's own grid (n_split, cb, tg), x fastest
+    int lb = (int)blockIdx.x - tb.blk_start[ti];
+    const int bx = lb % n_split; lb /= n_split;
+    const int by = lb % grid_y, bz = lb / grid_y;
     using TL = Tile<ND, 128>;
     constexpr int NT = 512;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
@@ -636,8 +658,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     char* l_lds = smem + S_BYTES;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cl_blocks = g.Cl / 32;
-    const int cs0 = (blockIdx.y / cl_blocks) * 64, cl0 = (blockIdx.y % cl_blocks) * 32;
-    const int kd = (ND == 3) ? blockIdx.z : 0;
+    const int cs0 = (by / cl_blocks) * 64, cl0 = (by % cl_blocks) * 32;
+    const int kd = (ND == 3) ? bz : 0;
     const int kh = wave & 3, sg = wave >> 2;
     // Bank-conflict-free LDS images for the transposing reads.  One 32-lane group of ds_read_b64_tr_b16 reads 4 k-rows x 64
     // bytes = the whole 256-byte bank row, provided the 4 rows sit in 4 different 64-byte quarters.  The k-rows of a group are 4
@@ -649,7 +671,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     auto l_row = [](int line, int x) -> int { return (x & 1) * LPLANE + line * LHALF + (x >> 1); };
     const int tiles_per_b = g.tiles_d * g.tiles_h * g.tiles_w, total_tiles = g.B * tiles_per_b;
 #ifdef CVAE_STAMP
-    const unsigned stamp_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned stamp_wg = blockIdx.x;
     if (t == 0 && stamp_wg < CVAE_STAMP_WGS) {
         g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 30] = wall_clock64();
         g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 29] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
@@ -668,8 +690,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     // layers), done by the (cl block 0, kd 0) workgroups from their S tiles; bias_mode 2 = per-channel sum of L (ConvTranspose
     // layers), done by the (cs block 0, kd 1 | 2) workgroups from the non-halo part of their L tiles (kd = 1 sees the even planes,
     // kd = 2 the odd ones; in 2D the single tap group sees the one plane).  Partials go to bias_ws, wgrad_reduce_kernel sums them.
-    const bool bias_s = bias_mode == 1 && (blockIdx.y % cl_blocks) == 0 && kd == 0;
-    const bool bias_l = bias_mode == 2 && (blockIdx.y / cl_blocks) == 0 && (ND == 2 || kd == 1 || kd == 2);
+    const bool bias_s = bias_mode == 1 && (by % cl_blocks) == 0 && kd == 0;
+    const bool bias_l = bias_mode == 2 && (by / cl_blocks) == 0 && (ND == 2 || kd == 1 || kd == 2);
     float bacc = 0.f;
     // S tile: 128 positions x 64 channels; L tile: planes lz = 2 (o0d + d) - 1 + kd, rows 2 o0h - 1 + y, cols 2 o0w - 1 + x.
     // Both LDS images are piece-linear (piece `it` at byte 16 it / 32 it).  The global loads of tile i+1 are issued right after
@@ -713,8 +735,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
             okmask |= (unsigned)ok << (SN + i);
         }
     };
-    if ((int)blockIdx.x < total_tiles) load_tile(blockIdx.x);
-    for (int tile = blockIdx.x; tile < total_tiles; tile += n_split) {
+    if (bx < total_tiles) load_tile(bx);
+    for (int tile = bx; tile < total_tiles; tile += n_split) {
         __syncthreads();                                     // the previous tile's readers are done with both images
 #ifdef CVAE_STAMP
         if (stamp_it < 8) STAMP(2 + 3 * stamp_it);
@@ -822,18 +844,18 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v += red[q * 64 + t];
-            bias_ws[((size_t)(blockIdx.y / cl_blocks) * n_split + blockIdx.x) * 64 + t] = v;
+            bias_ws[((size_t)(by / cl_blocks) * n_split + bx) * 64 + t] = v;
         }
         if (bias_l && t < 32) {
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) v += red[q * 32 + t];
             const int half = (ND == 3) ? kd - 1 : 0, nhalf = (ND == 3) ? 2 : 1;
-            bias_ws[(((size_t)(blockIdx.y % cl_blocks) * nhalf + half) * n_split + blockIdx.x) * 32 + t] = v;
+            bias_ws[(((size_t)(by % cl_blocks) * nhalf + half) * n_split + bx) * 32 + t] = v;
         }
     }
     const int col = lane & 31, hq = lane >> 5;
-    float* slab = ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * n_split + blockIdx.x) * 32768;
+    float* slab = ws + ((size_t)(bz * grid_y + by) * n_split + bx) * 32768;
 #pragma unroll
     for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
@@ -851,14 +873,26 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
 // dW[cs][cl][kd][kh][0..3] = sum over the n_split slabs of group (kd, channel block).  One thread per (kd, kh, cs, cl)
 // sums the 4 kw values (a 16-byte store into the reference layout); 4 thread groups split the slab range, LDS combines.
 // Blocks past the dW range sum the bias partials: block j handles 64 channels, 4 thread groups split the partial rows.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Cs, int Cl, int taps, int n_split, int cb,
-                                                           int dw_blocks, const float* __restrict__ bias_ws, float* __restrict__ dbias, int bias_n, int bias_rows,
-                                                           int bias_width) {
+struct WgradReduceEntry {
+    const float* ws; float* dW; const float* bias_ws; float* dbias;
+    int Cs, Cl, n_split, cb, dw_blocks, bias_n, bias_rows, bias_width;
+};
+struct WgradReduceTable { WgradReduceEntry e[WG_MULTI_MAX]; int blk_start[WG_MULTI_MAX + 1]; int count, taps; };
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceTable tb) {
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    const float* __restrict__ ws = tb.e[ti].ws;
+    float* __restrict__ dW = tb.e[ti].dW;
+    const float* __restrict__ bias_ws = tb.e[ti].bias_ws;
+    float* __restrict__ dbias = tb.e[ti].dbias;
+    const int Cl = tb.e[ti].Cl, taps = tb.taps, n_split = tb.e[ti].n_split, cb = tb.e[ti].cb, dw_blocks = tb.e[ti].dw_blocks;
+    const int bias_n = tb.e[ti].bias_n, bias_rows = tb.e[ti].bias_rows, bias_width = tb.e[ti].bias_width;
+    const int lbx = (int)blockIdx.x - tb.blk_start[ti];
     __shared__ float4 part[4][64];
-    if ((int)blockIdx.x >= dw_blocks) {
+    if (lbx >= dw_blocks) {
         // bias_ws is [channel group][bias_rows][bias_width]; channel = group * bias_width + lane
         __shared__ float bred[4][64];
-        const int ch = ((int)blockIdx.x - dw_blocks) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+        const int ch = (lbx - dw_blocks) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
         float v = 0.f;
         if (ch < bias_n) {
             const float* base = bias_ws + (size_t)(ch / bias_width) * bias_rows * bias_width + (ch % bias_width);
@@ -870,8 +904,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         return;
     }
     const int cl_blocks = Cl / 32;
-    // blockIdx.x enumerates (group = kd * cb + block, kh, cs row pair) ; 64 threads = 2 cs rows x 32 cl
-    int bi = blockIdx.x;
+    // lbx enumerates (group = kd * cb + block, kh, cs row pair) ; 64 threads = 2 cs rows x 32 cl
+    int bi = lbx;
     const int rowpair = bi % 32; bi /= 32;
     const int kh = bi % 4; bi /= 4;
     const int grp = bi;                                      // kd * cb + channel block
@@ -895,17 +929,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 #define WGRAD_MAX_WG 512
-template <typename T, int ND>
-int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbias, int bias_mode, ConvGeom g, hipStream_t stream) {
+template <typename T, int ND> constexpr size_t wgrad_lds_bytes() {
     using TL = Tile<ND, 128>;
-    constexpr size_t LDS = (size_t)128 * 64 * sizeof(T) + (size_t)TL::TD * (2 * TL::TH + 2) * (2 * TL::TW + 2) * 32 * sizeof(T);
-    static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
-    auto kern = conv_wgrad_kernel<T, ND>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
-        attr_set = true;
-    }
+    return (size_t)128 * 64 * sizeof(T) + (size_t)TL::TD * (2 * TL::TH + 2) * (2 * TL::TW + 2) * 32 * sizeof(T);
+}
+// Launch geometry of one layer's weight gradient: fills the two table entries, returns the workgroup counts of the main and the reduce pass.
+template <typename T, int ND>
+int plan_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbias, int bias_mode, ConvGeom g, WgradEntry* me, WgradReduceEntry* re, int* main_blocks,
+               int* reduce_blocks) {
+    using TL = Tile<ND, 128>;
     g.tiles_d = (g.sd + TL::TD - 1) / TL::TD; g.tiles_h = (g.sh + TL::TH - 1) / TL::TH; g.tiles_w = (g.sw + TL::TW - 1) / TL::TW;
     const long long total_tiles = (long long)g.B * g.tiles_d * g.tiles_h * g.tiles_w;
     const int cb = (g.Cs / 64) * (g.Cl / 32), tg = (ND == 3) ? 4 : 1;
@@ -924,22 +956,49 @@ int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbia
 #endif
     if (n_split < 1) n_split = 1;
     if (n_split > total_tiles) n_split = total_tiles;
-    if (cb > 65535) return CVAE_E_BADSHAPE;
-    dim3 grid((unsigned)n_split, (unsigned)cb, (unsigned)tg);
+    if ((long long)cb * tg * n_split > (1 << 24)) return CVAE_E_BADSHAPE;
     // bias partials live behind the slabs: [channel group][rows][width] with (mode 1) 64-wide groups of cs, n_split rows;
     // (mode 2) 32-wide groups of cl, (2 plane parities in 3D) * n_split rows
     const long long wgs = (long long)cb * tg * n_split;
     float* bias_ws = ws + (size_t)(wgs > WGRAD_MAX_WG ? wgs : WGRAD_MAX_WG) * 32768;
     if (!dbias) bias_mode = 0;
-    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, (const T*)S, (const T*)L, ws, g, (int)n_split, bias_ws, bias_mode);
-    CVAE_CHECK_LAUNCH();
+    *me = WgradEntry{S, L, ws, bias_ws, g, (int)n_split, cb, tg, bias_mode};
+    *main_blocks = (int)wgs;
     const int dw_blocks = cb * tg * 4 * 32;
     const int bias_n = bias_mode == 1 ? g.Cs : (bias_mode == 2 ? g.Cl : 0), bias_width = bias_mode == 1 ? 64 : 32;
     const int bias_rows = (int)n_split * ((bias_mode == 2 && ND == 3) ? 2 : 1);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(dw_blocks + (bias_n + 63) / 64)), dim3(256), 0, stream, (const float*)ws, dW, g.Cs, g.Cl, (ND == 3) ? 64 : 16,
-                       (int)n_split, cb, dw_blocks, (const float*)bias_ws, dbias, bias_n, bias_rows, bias_width);
+    *re = WgradReduceEntry{ws, dW, bias_ws, dbias, g.Cs, g.Cl, (int)n_split, cb, dw_blocks, bias_n, bias_rows, bias_width};
+    *reduce_blocks = dw_blocks + (bias_n + 63) / 64;
+    return CVAE_OK;
+}
+template <typename T, int ND>
+int launch_wgrad_tables(WgradTable& mt, WgradReduceTable& rt, hipStream_t stream) {
+    constexpr size_t LDS = wgrad_lds_bytes<T, ND>();
+    static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
+    auto kern = conv_wgrad_kernel<T, ND>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
+        attr_set = true;
+    }
+    rt.taps = (ND == 3) ? 64 : 16;
+    hipLaunchKernelGGL(kern, dim3((unsigned)mt.blk_start[mt.count]), dim3(512), LDS, stream, mt);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rt.blk_start[rt.count]), dim3(256), 0, stream, rt);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
+}
+template <typename T, int ND>
+int launch_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbias, int bias_mode, ConvGeom g, hipStream_t stream) {
+    WgradTable mt;
+    WgradReduceTable rt;
+    int mb, rb;
+    const int rc = plan_wgrad<T, ND>(S, L, ws, dW, dbias, bias_mode, g, &mt.e[0], &rt.e[0], &mb, &rb);
+    if (rc != CVAE_OK) return rc;
+    mt.count = rt.count = 1;
+    mt.blk_start[0] = rt.blk_start[0] = 0;
+    mt.blk_start[1] = mb; rt.blk_start[1] = rb;
+    return launch_wgrad_tables<T, ND>(mt, rt, stream);
 }
 
 bool geom_ok(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd) {
@@ -1162,4 +1221,47 @@ extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* d
     if (dtype == CVAE_BF16)
         return nd == 3 ? launch_wgrad<bf16, 3>(S, L, (float*)workspace, dW, db, bias_mode, g, st) : launch_wgrad<bf16, 2>(S, L, (float*)workspace, dW, db, bias_mode, g, st);
     return nd == 3 ? launch_wgrad<float, 3>(S, L, (float*)workspace, dW, db, bias_mode, g, st) : launch_wgrad<float, 2>(S, L, (float*)workspace, dW, db, bias_mode, g, st);
+}
+
+template <typename T, int ND>
+static int wgrad_multi_t(int count, const void* const* S, const void* const* L, float* const* dW, float* const* dbias, const int* dbias_side, void* const* workspace,
+                         const int64_t* dims, hipStream_t st) {
+    WgradTable mt;
+    WgradReduceTable rt;
+    int mb = 0, rb = 0;
+    for (int i = 0; i < count; ++i) {
+        const int64_t* d = dims + 9 * i;
+        ConvGeom g{(int)d[0], (int)d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], (int)d[6], (int)d[7], (int)d[8], 0, 0, 0};
+        const int bias_mode = dbias[i] ? (dbias_side[i] ? 2 : 1) : 0;
+        int m1, r1;
+        const int rc = plan_wgrad<T, ND>(S[i], L[i], (float*)workspace[i], dW[i], dbias[i], bias_mode, g, &mt.e[i], &rt.e[i], &m1, &r1);
+        if (rc != CVAE_OK) return rc;
+        mt.blk_start[i] = mb; rt.blk_start[i] = rb;
+        mb += m1; rb += r1;
+    }
+    mt.blk_start[count] = mb; rt.blk_start[count] = rb;
+    mt.count = rt.count = count;
+    return launch_wgrad_tables<T, ND>(mt, rt, st);
+}
+
+extern "C" int cvae_conv_wgrad_multi(int count, const void* const* S, const void* const* L, float* const* dW, float* const* dbias, const int* dbias_side,
+                                     void* const* workspace, const size_t* workspace_bytes, const int64_t* dims, int nd, int dtype, void* stream) {
+    if (count < 0 || count > WG_MULTI_MAX || (nd != 2 && nd != 3)) return CVAE_E_BADSHAPE;
+    if (count == 0) return CVAE_OK;
+    if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (!S || !L || !dW || !dbias || !dbias_side || !workspace || !workspace_bytes || !dims) return CVAE_E_NULLPTR;
+    for (int i = 0; i < count; ++i) {
+        const int64_t* d = dims + 9 * i;
+        const int64_t B = d[0], sd = d[1], sh = d[2], sw = d[3], Cs = d[4], ld = d[5], lh = d[6], lw = d[7], Cl = d[8];
+        if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || B == 0) return CVAE_E_BADSHAPE;
+        if (Cl == 1 || Cs % 64 || Cl % 32) return CVAE_E_UNSUPPORTED;                       // the single-channel layers have their own kernels
+        if (dbias_side[i] != 0 && dbias_side[i] != 1) return CVAE_E_BADSHAPE;
+        if (dbias[i] && dbias_side[i] == 1 && (lh != 2 * sh || lw != 2 * sw || (nd == 3 && ld != 2 * sd))) return CVAE_E_UNSUPPORTED;   // odd L extent: cvae_conv_wgrad sums L separately
+        if (!S[i] || !L[i] || !dW[i] || !workspace[i]) return CVAE_E_NULLPTR;
+        if (workspace_bytes[i] < cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd)) return CVAE_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVAE_BF16)
+        return nd == 3 ? wgrad_multi_t<bf16, 3>(count, S, L, dW, dbias, dbias_side, workspace, dims, st) : wgrad_multi_t<bf16, 2>(count, S, L, dW, dbias, dbias_side, workspace, dims, st);
+    return nd == 3 ? wgrad_multi_t<float, 3>(count, S, L, dW, dbias, dbias_side, workspace, dims, st) : wgrad_multi_t<float, 2>(count, S, L, dW, dbias, dbias_side, workspace, dims, st);
 }

@@ -318,6 +318,40 @@ def _conv_up(St, wp, bias, mask, Cl, nd, act, l_dims=None):
     return Lt
 
 
+DEFER_WGRAD = True     # weight gradients of the MFMA conv layers are queued during a backward pass and computed by ONE grouped launch (+ one
+                       # reduce launch) at its end (cvae_conv_wgrad_multi): the small layers run in the shadow of the large ones
+_WG_PENDING = []
+_WG_QUEUED = [False]
+
+
+def _wgrad_flush():
+    """Run every queued weight gradient (grouped by device / nd / dtype, <= 8 layers per launch).  Installed as the autograd engine's
+    end-of-backward callback, so `.grad` is complete when loss.backward() / torch.autograd.grad() returns — any optimizer works."""
+    _WG_QUEUED[0] = False
+    if not _WG_PENDING:
+        return
+    todo = list(_WG_PENDING)
+    _WG_PENDING.clear()
+    groups = {}
+    for e in todo:
+        groups.setdefault((e["S"].device, e["nd"], e["S"].dtype), []).append(e)
+    for (dev, nd, dt), es in groups.items():
+        with torch.cuda.device(dev):
+            for c0 in range(0, len(es), 8):
+                ch = es[c0:c0 + 8]
+                k = len(ch)
+                vp = lambda key: (C_.c_void_p * k)(*[(e[key].data_ptr() if e[key] is not None else None) for e in ch])
+                dims = (C_.c_int64 * (9 * k))(*[v for e in ch for v in e["dims"]])
+                label = f"conv_wgrad_multi nd{nd} B{ch[0]['dims'][0]} " + ";".join("S{1}x{2}x{3}x{4}L{8}".format(*e["dims"]) for e in ch)
+                check(L.timed(label, lib.cvae_conv_wgrad_multi, k, vp("S"), vp("L"), vp("dW"), vp("db"), (C_.c_int * k)(*[e["side"] for e in ch]), vp("ws"),
+                              (C_.c_size_t * k)(*[e["nbytes"] for e in ch]), dims, nd, L.dtype_code(dt), stream()), "conv_wgrad_multi")
+
+
+def flush_pending_wgrads():
+    """Compute queued weight gradients now (FusedAdam.overlap_backward reads gradients before the backward pass has ended)."""
+    _wgrad_flush()
+
+
 def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False):
     """dW and, in the same pass, the bias gradient: want_sbias = per-channel sum of S (Conv layer), want_lbias = of L (ConvTranspose)."""
     B, sd, sh, sw, Cs = _cl_dims(St)
@@ -326,6 +360,17 @@ def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False):
     db = torch.empty(Cl if want_lbias else Cs, dtype=torch.float32, device=St.device) if (want_sbias or want_lbias) else None
     nbytes = lib.cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=St.device)
+    exact2x = lh == 2 * sh and lw == 2 * sw and (nd == 2 or ld == 2 * sd)
+    if (DEFER_WGRAD and Cl != 1 and Cs % 64 == 0 and Cl % 32 == 0 and B > 0 and (exact2x or not want_lbias)):
+        try:
+            if not _WG_QUEUED[0]:
+                torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush)     # only legal inside a backward pass
+                _WG_QUEUED[0] = True
+            _WG_PENDING.append(dict(S=St, L=Lt, dW=dW, db=db, side=1 if want_lbias else 0, ws=ws, nbytes=nbytes, nd=nd,
+                                    dims=(B, sd, sh, sw, Cs, ld, lh, lw, Cl)))
+            return (dW, db) if (want_sbias or want_lbias) else dW
+        except RuntimeError:
+            pass                                             # not inside a backward pass (a direct call): compute now
     check(L.timed(f"conv_wgrad nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L{Cl}", lib.cvae_conv_wgrad, ptr(St), ptr(Lt), ptr(dW), ptr(db), 1 if want_lbias else 0, ptr(ws), nbytes,
                   B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), stream()), "conv_wgrad")
     return (dW, db) if (want_sbias or want_lbias) else dW

@@ -45,6 +45,8 @@ class FusedAdam(torch.optim.Optimizer):
     def _early_hook(self, p):
         self._early_left -= 1
         if self._early_left == 0:
+            from . import ops
+            ops.flush_pending_wgrads()                       # queued conv weight gradients must exist before they are read
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()

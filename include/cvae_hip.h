@@ -189,6 +189,14 @@ size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd);
 int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, int dbias_side, void* workspace, size_t workspace_bytes,
                     int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                     int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, void* stream);
+/* The weight gradients of `count` (<= 8) layers in ONE main launch and ONE reduce launch: what a backward pass defers to its end, so
+ * that the small layers (a few tiles each, launch- and latency-bound alone) run in the shadow of the large ones.  Arrays of `count`
+ * entries; dims: count rows of 9 int64 {B, sd, sh, sw, Cs, ld, lh, lw, Cl}; every layer needs its OWN workspace
+ * (cvae_conv_wgrad_workspace_bytes) because they run concurrently.  All layers share nd and dtype; Cl != 1, Cs % 64 == 0,
+ * Cl % 32 == 0; an entry with dbias_side 1 needs L == 2 S (otherwise use cvae_conv_wgrad for that layer).  Same results, bit for
+ * bit, as `count` calls of cvae_conv_wgrad. */
+int cvae_conv_wgrad_multi(int count, const void* const* S, const void* const* L, float* const* dW, float* const* dbias, const int* dbias_side,
+                          void* const* workspace, const size_t* workspace_bytes, const int64_t* dims, int nd, int dtype, void* stream);
 /* out[c] = sum_p x[p, c] over a channels-last [P, C] tensor (bias gradients). out is overwritten.  workspace (optional,
  * cvae_channel_sum_workspace_bytes): partial rows of a multi-workgroup pass, added in index order (no float atomics); without it
  * the rows of one channel group are summed by ONE workgroup (same result bits for a given geometry, slower for large P). */

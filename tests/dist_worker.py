@@ -55,7 +55,7 @@ def mode_dp_step(rank, world, dev):
     from causal_vae_amd.causal_cascade import CausalBioVAE3D, train_step
     from causal_vae_amd.graph import GraphedTrainStep
     from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters
-    B, S = 2, 32
+    B, S = 2, 64                                                 # 64^3: the fused bottleneck (and with it the split backward) needs a >= 4^3 encoder output
     x, m, t, eps = global_batch(world, B, S)
     sl = slice(rank * B, (rank + 1) * B)
     xd, md, td, ed = (v[sl].to(dev) for v in (x, m, t, eps))
