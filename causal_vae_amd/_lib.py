@@ -44,6 +44,9 @@ SIGNATURES = {
     "cvae_conv_data_workspace_bytes": [_i64] * 9 + [_i, _i],
     "cvae_conv_down": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
     "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
+    "cvae_conv_image_supported": [_p, _i64, _i, _i],
+    "cvae_conv_down_image": [_p, _i, _p, _p, _p, _p] + [_i64] * 8 + [_i, _i, _i, _p],
+    "cvae_conv_wgrad_image": [_p, _p, _i, _p, _p, _p, _sz] + [_i64] * 8 + [_i, _i, _p],
     "cvae_conv_wgrad_workspace_bytes": [_i64, _i64, _i],
     "cvae_conv_wgrad": [_p, _p, _p, _p, _i, _p, _sz] + [_i64] * 9 + [_i, _i, _p],
     "cvae_conv_wgrad_multi": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],

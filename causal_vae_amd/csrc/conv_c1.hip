@@ -144,6 +144,116 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
     }
 }
 
+// -------------------------------------------------------------------------------------- down, Cl == 1, image read in its own dtype
+// The same product for a bf16 S with the 1-channel image read as it is stored (fp32 for the network input: no separate cast pass; bf16 for
+// a gradient image) in 16-BYTE pieces: a halo row is the aligned window [2 o0w - EPV, 2 o0w + 2 TW + EPV) of EPV-element vectors (EPV = 4
+// fp32 / 8 bf16), i.e. 6 (4) coalesced loads per row instead of 18 two-byte ones, converted to bf16 on the way into LDS.  The tap window of
+// an output starts at an ODD element of that row image, so a lane reads 3 aligned dwords per row and funnel-shifts (v_alignbit) the 4
+// bf16 it needs out of them.  Needs lw % EPV == 0 and a 16-byte aligned image (cvae_conv_image_supported); everything else as above.
+template <typename TL, int ND>
+__global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__ L, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const bf16* __restrict__ mask, bf16* __restrict__ S, int sd, int sh, int sw, int ld, int lh, int lw,
+                                                          int tiles_h, int tiles_w, int act) {
+    using TLE = TileC1<ND>;
+    using OP = C1Ops<bf16>;
+    constexpr int CS = 32;
+    constexpr int TD = TLE::TD, TH = TLE::TH, TW = TLE::TW;
+    constexpr int EPV = 16 / sizeof(TL), NV = (2 * TW + 2 * EPV) / EPV, IWP = NV * EPV;
+    constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, NROW = ID * IH, NVEC = NROW * NV;
+    constexpr int TAPS = (ND == 3) ? 64 : 16, NKB = TAPS / 16, HN = (NVEC + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16 halo[NROW * IWP + 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5, b = blockIdx.z;
+    int tile = blockIdx.x;
+    const int tw_i = tile % tiles_w; tile /= tiles_w;
+    const int th_i = tile % tiles_h; tile /= tiles_h;
+    const int o0d = tile * TD, o0h = th_i * TH, o0w = tw_i * TW;
+    const int gx0 = 2 * o0w - EPV;
+    // ---- all halo vectors in flight at once, weights into B fragments meanwhile ----
+    uint4 hv[HN];
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+        const int it = min(t + i * 256, NVEC - 1), row = it / NV, j = it % NV;
+        const int y = row % IH, z = row / IH;
+        const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = gx0 + j * EPV;
+        const bool ok = (gz >= 0) & (gz < ld) & (gy >= 0) & (gy < lh) & (gx >= 0) & (gx < lw);      // lw % EPV == 0: a vector is inside or outside as a whole
+        const uint4 v = *(const uint4*)(L + (((size_t)b * ld + min(max(gz, 0), ld - 1)) * lh + min(max(gy, 0), lh - 1)) * lw + min(max(gx, 0), lw - EPV));   // clamped: unconditional load
+        hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+    typename OP::BFrag bfr[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) OP::load_b(bfr[kb], w + (size_t)r * TAPS, kb, h);
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+        const int it = t + i * 256;
+        if (it < NVEC) {
+            if constexpr (sizeof(TL) == 4) {
+                const float* f = (const float*)&hv[i];
+                union { uint2 u; bf16 e[4]; } o;
+                o.e[0] = (bf16)f[0]; o.e[1] = (bf16)f[1]; o.e[2] = (bf16)f[2]; o.e[3] = (bf16)f[3];
+                *(uint2*)(halo + it * EPV) = o.u;           // row * IWP + j * EPV == it * EPV
+            } else {
+                *(uint4*)(halo + it * EPV) = hv[i];
+            }
+        }
+    }
+    __syncthreads();
+    float bv[2][8];                                          // bias of this lane's two 8-channel pieces (channels 16 j + 8 h + q)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (bias) { b0 = *(const float4*)(bias + 16 * j + 8 * h); b1 = *(const float4*)(bias + 16 * j + 8 * h + 4); }
+        bv[j][0] = b0.x; bv[j][1] = b0.y; bv[j][2] = b0.z; bv[j][3] = b0.w; bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
+    }
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int m = (wave * 2 + ms) * 32 + r;
+        const int w0 = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+        // element index of the aligned dword that holds tap kw = 0 in its upper half: x = 2 w0 - 1 - gx0 = 2 w0 + EPV - 1 (odd)
+        const int pb = ((2 * d) * IH + 2 * hh) * IWP + 2 * w0 + EPV - 2;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            union { uint32_t u[4]; bf16x8 v; } a;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {                 // rows kh = 2 h + rr
+                const uint32_t* p = (const uint32_t*)(halo + pb + (kb * IH + 2 * h + rr) * IWP);
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                a.u[2 * rr] = __builtin_amdgcn_alignbit(d1, d0, 16);
+                a.u[2 * rr + 1] = __builtin_amdgcn_alignbit(d2, d1, 16);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kb].v, a.v, acc, 0, 0, 0);       // D = W x im2col^T: rows = channels, columns = positions
+        }
+        const int ow = o0w + w0, oh = o0h + hh, od = o0d + d;
+        const bool ok = od < sd && oh < sh && ow < sw;
+        const size_t pidx = ((((size_t)b * sd + od) * sh + oh) * sw + ow) * CS;
+        float v[2][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[4 + i]), false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 + i]), __float_as_uint(acc[12 + i]), false, false);
+            v[0][i] = __uint_as_float(lo[0]); v[0][4 + i] = __uint_as_float(lo[1]);
+            v[1][i] = __uint_as_float(hi[0]); v[1][4 + i] = __uint_as_float(hi[1]);
+        }
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = 16 * j + 8 * h;
+                __attribute__((aligned(16))) bf16 mv[8], ov[8];
+                if (mask) *(uint4*)mv = *(const uint4*)(mask + pidx + c);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float x = apply_act(v[j][q] + bv[j][q], act);
+                    if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
+                    ov[q] = from_f32<bf16>(x);
+                }
+                *(uint4*)(S + pidx + c) = *(const uint4*)ov;
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------- up, Cl == 1
 // One thread per (source voxel q, half of the CS channels): the 2 x 2 x 2 (3D) / 2 x 2 (2D) outputs around q read the 3^nd
 // neighbourhood of q, so each neighbour's 16 channels are loaded ONCE (two 16-byte loads) and feed every output parity that
@@ -352,8 +462,9 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
 //         elements per lane); v_mfma_f32_32x32x16_bf16.  A third accumulator S^T . ones yields the bias gradient.
 //   fp32: v_mfma_f32_32x32x2_f32, one element per lane per operand.
 // Each workgroup walks `total / n_split` tiles of 128 positions and leaves with fp32 atomics directly in [Cs][1][taps].
-template <typename T, int ND, bool LSUM>
-__global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, const T* __restrict__ L, float* __restrict__ ws, bool want_bias, int B, int sd, int sh, int sw,
+// TL: the dtype the 1-channel image L is STORED in (fp32 for the network input: read directly, rounded to T on the way into LDS).
+template <typename T, typename TL, int ND, bool LSUM>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, const TL* __restrict__ L, float* __restrict__ ws, bool want_bias, int B, int sd, int sh, int sw,
                                                        int Cs, int ld, int lh, int lw, int tiles_d, int tiles_h, int tiles_w, int n_split, float* __restrict__ lsum_ws) {
     constexpr int TD = (ND == 3) ? 4 : 1, TH = (ND == 3) ? 4 : 8, TW = (ND == 3) ? 8 : 16;     // 128 positions
     constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, IW = 2 * TW + 2, NPOS = ID * IH * IW;
@@ -415,7 +526,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
             const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
             const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - 1 + x;
             const bool ok = pos < NPOS && gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
-            hv[i] = ok ? L[(((size_t)b * ld + gz) * lh + gy) * lw + gx] : from_f32<T>(0.f);
+            hv[i] = ok ? from_f32<T>(to_f32(L[(((size_t)b * ld + gz) * lh + gy) * lw + gx])) : from_f32<T>(0.f);
             if (LSUM) {
                 const bool inner = (ND == 2 || (z >= 1 && z <= 2 * TD)) && y >= 1 && y <= 2 * TH && x >= 1 && x <= 2 * TW;
                 if (want_lsum && ok && inner) lacc += to_f32(hv[i]);
@@ -553,12 +664,28 @@ __global__ __launch_bounds__(256) void wgrad_c1_finish_kernel(const float* __res
 
 }  // namespace
 
-int cvae_conv_down_c1(const void* L, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
+// 1 when the vector-load form can read this image: whole 16-byte vectors per row and a 16-byte aligned base
+static bool image_vec_ok(const void* L, int64_t lw, int l_dtype) {
+    const int epv = l_dtype == CVAE_BF16 ? 8 : 4;
+    return lw % epv == 0 && lw >= epv && (((uintptr_t)L) & 15) == 0;
+}
+int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                       int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream) {
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
     const int th = (nd == 3) ? 8 : 16, tw = (nd == 3) ? 8 : 16, td = (nd == 3) ? 4 : 1;
     const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
     dim3 grid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
+    if (dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype)) {          // bf16 output: the 16-byte-load form, image in its own dtype
+#define LAUNCH_DOWN_VEC(TLT, ND)                                                                                                      \
+    hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
+                       (int)sw, (int)ld, (int)lh, (int)lw, tiles_h, tiles_w, act)
+        if (l_dtype == CVAE_F32) { if (nd == 3) LAUNCH_DOWN_VEC(float, 3); else LAUNCH_DOWN_VEC(float, 2); }
+        else { if (nd == 3) LAUNCH_DOWN_VEC(bf16, 3); else LAUNCH_DOWN_VEC(bf16, 2); }
+#undef LAUNCH_DOWN_VEC
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
+    if (l_dtype != dtype) return CVAE_E_UNSUPPORTED;         // the element-wise form reads the image in the compute dtype
 #define LAUNCH_DOWN_C1(T, ND)                                                                                                         \
     hipLaunchKernelGGL((down_c1_kernel<T, ND, 32>), grid, dim3(256), 0, stream, (const T*)L, w, bias, (const T*)mask, (T*)S, (int)sd, (int)sh, \
                        (int)sw, (int)ld, (int)lh, (int)lw, tiles_h, tiles_w, act)
@@ -599,8 +726,9 @@ size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd) {
     return ((size_t)2048 * 32 * rw + 2048) * sizeof(float);  // (Cs/32) * n_split <= 2048 slabs of [32][rw], then <= 2048 partial sums of L
 }
 
-int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
+int cvae_conv_wgrad_c1(const void* S, const void* L, int l_dtype, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
                        int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream) {
+    if (l_dtype != dtype && !(dtype == CVAE_BF16 && l_dtype == CVAE_F32)) return CVAE_E_UNSUPPORTED;     // mixed form: fp32 image, bf16 gradient
     // dbias: per-channel sum of S (Conv bias) or NULL; dbias_l: sum of L (ConvTranspose bias, one value; needs L == 2 S) or NULL
     if (dbias_l && (lh != 2 * sh || lw != 2 * sw || (nd == 3 && ld != 2 * sd))) return CVAE_E_UNSUPPORTED;
     if (Cs % 32 || Cs > 1024 * 32) return CVAE_E_UNSUPPORTED;
@@ -626,8 +754,14 @@ int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, fl
 #define LAUNCH_WG_C1(T, ND)                                                                                                           \
     if (lsum_ws) LAUNCH_WG_C1_(T, ND, true); else LAUNCH_WG_C1_(T, ND, false)
 #define LAUNCH_WG_C1_(T, ND, LS)                                                                                                      \
-    hipLaunchKernelGGL((wgrad_c1_kernel<T, ND, LS>), grid, dim3(256), 0, stream, (const T*)S, (const T*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
-                       (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split, lsum_ws)
+    do {                                                                                                                              \
+        if (l_dtype == dtype)                                                                                                         \
+            hipLaunchKernelGGL((wgrad_c1_kernel<T, T, ND, LS>), grid, dim3(256), 0, stream, (const T*)S, (const T*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
+                               (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split, lsum_ws);         \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((wgrad_c1_kernel<T, float, ND, LS>), grid, dim3(256), 0, stream, (const T*)S, (const float*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
+                               (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split, lsum_ws);         \
+    } while (0)
     if (dtype == CVAE_BF16) { if (nd == 3) { LAUNCH_WG_C1(bf16, 3); } else { LAUNCH_WG_C1(bf16, 2); } }
     else { if (nd == 3) { LAUNCH_WG_C1(float, 3); } else { LAUNCH_WG_C1(float, 2); } }
 #undef LAUNCH_WG_C1

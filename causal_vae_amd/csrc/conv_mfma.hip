@@ -1015,12 +1015,12 @@ bool geom_ok(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t 
 }  // namespace
 
 // C1 kernels live in conv_c1.hip
-int cvae_conv_down_c1(const void* L, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
+int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                       int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd);
-int cvae_conv_wgrad_c1(const void* S, const void* L, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
+int cvae_conv_wgrad_c1(const void* S, const void* L, int l_dtype, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
                        int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
 
 #ifdef CVAE_STAMP
@@ -1141,13 +1141,42 @@ extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, c
     if (B == 0) return CVAE_OK;
     if (!L || !w || !S) return CVAE_E_NULLPTR;
     hipStream_t st = (hipStream_t)stream;
-    if (Cl == 1) return cvae_conv_down_c1(L, (const float*)w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
+    if (Cl == 1) return cvae_conv_down_c1(L, dtype, (const float*)w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
     if (Cl % 16 || Cs % 64) return CVAE_E_UNSUPPORTED;
     GEOM_INIT();
     if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
                                            : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
     return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
                    : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
+}
+
+// ---- the single-channel image end of the network, image read in the dtype it is stored in (no cast pass in front of the first conv) ----
+extern "C" int cvae_conv_image_supported(const void* L, int64_t lw, int l_dtype, int dtype) {
+    if (l_dtype == dtype) return 1;
+    if (!(dtype == CVAE_BF16 && l_dtype == CVAE_F32)) return 0;
+    return lw % 4 == 0 && lw >= 4 && (((uintptr_t)L) & 15) == 0;
+}
+extern "C" int cvae_conv_down_image(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S,
+                                    int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, 1, nd)) return CVAE_E_BADSHAPE;
+    if ((dtype != CVAE_F32 && dtype != CVAE_BF16) || (l_dtype != CVAE_F32 && l_dtype != CVAE_BF16)) return CVAE_E_DTYPE;
+    if (B == 0) return CVAE_OK;
+    if (!L || !w || !S) return CVAE_E_NULLPTR;
+    if (!cvae_conv_image_supported(L, lw, l_dtype, dtype)) return CVAE_E_UNSUPPORTED;
+    return cvae_conv_down_c1(L, l_dtype, w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, (hipStream_t)stream);
+}
+extern "C" int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                                     int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, 1, nd)) return CVAE_E_BADSHAPE;
+    if ((dtype != CVAE_F32 && dtype != CVAE_BF16) || (l_dtype != CVAE_F32 && l_dtype != CVAE_BF16)) return CVAE_E_DTYPE;
+    if (!dW) return CVAE_E_NULLPTR;
+    const int taps = (nd == 3) ? 64 : 16;
+    if (B == 0) {
+        if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cs * sizeof(float), (hipStream_t)stream) != hipSuccess) return CVAE_E_LAUNCH;
+        return hipMemsetAsync(dW, 0, (size_t)Cs * taps * sizeof(float), (hipStream_t)stream) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
+    }
+    if (!S || !L) return CVAE_E_NULLPTR;
+    return cvae_conv_wgrad_c1(S, L, l_dtype, dW, dbias, nullptr, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, (hipStream_t)stream);
 }
 
 extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
@@ -1203,7 +1232,7 @@ extern "C" int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* d
             }
             dbias = nullptr;
         }
-        return cvae_conv_wgrad_c1(S, L, dW, dbias, dbias_l, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);   // S-side bias sum fused (S^T . ones)
+        return cvae_conv_wgrad_c1(S, L, dtype, dW, dbias, dbias_l, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, st);   // S-side bias sum fused (S^T . ones)
     }
     if (Cs % 64 || Cl % 32) return CVAE_E_UNSUPPORTED;
     int bias_mode = dbias ? (dbias_side ? 2 : 1) : 0;

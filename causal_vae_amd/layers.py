@@ -29,7 +29,9 @@ class _ConvBase:
     _nd = 2
     _fn = ops.ConvDown
 
-    def forward_cl(self, x_cl, act=None, in_is_relu_out=False, grad_premasked=False, packed=None):
+    def forward_cl(self, x_cl, act=None, in_is_relu_out=False, grad_premasked=False, packed=None, out_dtype=None):
+        if out_dtype is not None:
+            return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked, packed, out_dtype)
         return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked, packed)
 
     def forward(self, x):                                   # NC(D)HW fp32 in / out, like the stock layer
@@ -143,6 +145,17 @@ class UpConv2dK3(nn.Conv2d):
                         "(a bare 3x3 convolution has no gfx950 kernel here)")
 
 
+def _image_cl(x, compute_dtype):
+    """The network input NC(D)HW as the first conv's channels-last operand.  A single-channel image IS channels-last already; when the
+    kernels can read it in its own dtype (fp32 batch, bf16 model) it is handed over as a view — no cast launch, no bf16 copy — and the
+    second value is the dtype the first conv must produce; otherwise (None) the usual converting copy is made."""
+    if (x.shape[1] == 1 and not x.requires_grad and x.dtype == torch.float32 and compute_dtype != torch.float32 and x.is_contiguous()
+            and ops.image_direct_ok(x, compute_dtype)):
+        sp = tuple(x.shape[2:])
+        return x.view(x.shape[0], *((1,) + sp if len(sp) == 2 else sp), 1), compute_dtype
+    return ops.ToChannelsLast.apply(x, compute_dtype), None
+
+
 _ACT_NAME = {nn.ReLU: "relu", nn.Sigmoid: "sigmoid"}
 
 
@@ -168,13 +181,14 @@ class ConvStack(nn.Sequential):
         convs = [m for m in mods if isinstance(m, _ConvBase)]
         if not convs or x.shape[1] != convs[0].in_channels:
             raise RuntimeError(f"expected input with {convs[0].in_channels if convs else '?'} channels, got {tuple(x.shape)}")
-        h = ops.ToChannelsLast.apply(x, self.compute_dtype)
+        h, first_dtype = _image_cl(x, self.compute_dtype)
         packed = iter(packed if packed is not None else ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))
         i, prev_act = 0, None
         while i < len(mods) and isinstance(mods[i], _ConvBase):
             act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
             # every consumer of a ReLU output inside this stack (next conv, final pool) folds that ReLU's mask
-            h = mods[i].forward_cl(h, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu"), packed=next(packed))
+            h = mods[i].forward_cl(h, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu"), packed=next(packed),
+                                   out_dtype=first_dtype if i == 0 else None)
             prev_act = act
             i += 2 if act else 1
         return h, mods[i:], prev_act
@@ -255,13 +269,13 @@ class BNConvStack(nn.Sequential):
     def forward(self, x):
         require_gpu(x)
         mods = list(self)
-        h = ops.ToChannelsLast.apply(x, self.compute_dtype)
+        h, first_dtype = _image_cl(x, self.compute_dtype)
         i = 0
         while i < len(mods) and isinstance(mods[i], _ConvBase):
             conv, bn = mods[i], mods[i + 1]
             if not isinstance(bn, BatchNorm2d) or _act_of(mods[i + 2]) is None:
                 raise CvaeError("BNConvStack: Conv2d, BatchNorm2d, activation triples expected")
-            h = bn.forward_cl(conv.forward_cl(h, act=None), act=_act_of(mods[i + 2]))
+            h = bn.forward_cl(conv.forward_cl(h, act=None, out_dtype=first_dtype if i == 0 else None), act=_act_of(mods[i + 2]))
             i += 3
         if i != len(mods) - 1 or not isinstance(mods[i], nn.Flatten):
             raise CvaeError("BNConvStack: trailing Flatten expected")

@@ -289,6 +289,19 @@ def pack_weights(weights, nd, dtype):
 SPLIT_K = True      # hand the conv data kernels their split-K scratch (tests switch it off to cover the unsplit path)
 
 
+def _can_defer(weight, bias):
+    """A weight gradient may be computed at the END of the backward pass only if nothing looks at it earlier: no accumulation onto an
+    existing .grad (AccumulateGrad would add the still-empty tensor), no tensor hooks, no double backward."""
+    if torch.is_grad_enabled():
+        return False
+    for p in (weight, bias):
+        if p is None:
+            continue
+        if not p.is_leaf or p.grad is not None or p._backward_hooks:      # a derived weight (ops.Conv3ToK4) hands its gradient on at once
+            return False
+    return True
+
+
 def _conv_data_workspace(device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, for_up):
     """Split-K scratch for the small-grid layers (cvae_conv_data_workspace_bytes; 0 bytes for the large ones)."""
     nbytes = lib.cvae_conv_data_workspace_bytes(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, for_up) if SPLIT_K else 0
@@ -297,9 +310,22 @@ def _conv_data_workspace(device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, for_up):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
 
 
-def _conv_down(Lt, wp, bias, mask, Cs, nd, act):
+def image_direct_ok(x, dtype):
+    """True when the first conv can read the 1-channel image `x` in ITS dtype while computing in `dtype` (cvae_conv_down_image)."""
+    return x.dtype != dtype and x.is_contiguous() and bool(lib.cvae_conv_image_supported(ptr(x), x.shape[-2] if x.dim() == 5 and x.shape[-1] == 1 else x.shape[-1],
+                                                                                        L.dtype_code(x.dtype), L.dtype_code(dtype)))
+
+
+def _conv_down(Lt, wp, bias, mask, Cs, nd, act, out_dtype=None):
     B, ld, lh, lw, Cl = _cl_dims(Lt)
     sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
+    if out_dtype is not None and out_dtype != Lt.dtype:      # single-channel image read in its own dtype, S in the compute dtype
+        if Cl != 1:
+            raise L.CvaeError("a mixed-dtype conv is available for the single-channel image layer only")
+        S = _empty((B, sd, sh, sw, Cs), out_dtype, Lt)
+        check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down_image, ptr(Lt), L.dtype_code(Lt.dtype), ptr(wp), ptr(bias), ptr(mask), ptr(S),
+                      B, sd, sh, sw, Cs, ld, lh, lw, nd, L.dtype_code(out_dtype), L.act_code(act), stream()), "conv_down_image")
+        return S
     S = _empty((B, sd, sh, sw, Cs), Lt.dtype, Lt)
     ws, nbytes = _conv_data_workspace(Lt.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, 0)
     check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down, ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S),
@@ -340,7 +366,7 @@ def _wgrad_flush():
             for c0 in range(0, len(es), 8):
                 ch = es[c0:c0 + 8]
                 k = len(ch)
-                vp = lambda key: (C_.c_void_p * k)(*[(e[key].data_ptr() if e[key] is not None else None) for e in ch])
+                vp = lambda key: (C_.c_void_p * k)(*[((e[key] if isinstance(e[key], int) else e[key].data_ptr()) if e[key] is not None else None) for e in ch])
                 dims = (C_.c_int64 * (9 * k))(*[v for e in ch for v in e["dims"]])
                 label = f"conv_wgrad_multi nd{nd} B{ch[0]['dims'][0]} " + ";".join("S{1}x{2}x{3}x{4}L{8}".format(*e["dims"]) for e in ch)
                 check(L.timed(label, lib.cvae_conv_wgrad_multi, k, vp("S"), vp("L"), vp("dW"), vp("db"), (C_.c_int * k)(*[e["side"] for e in ch]), vp("ws"),
@@ -352,22 +378,31 @@ def flush_pending_wgrads():
     _wgrad_flush()
 
 
-def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False):
-    """dW and, in the same pass, the bias gradient: want_sbias = per-channel sum of S (Conv layer), want_lbias = of L (ConvTranspose)."""
+def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False, may_defer=False):
+    """dW and, in the same pass, the bias gradient: want_sbias = per-channel sum of S (Conv layer), want_lbias = of L (ConvTranspose).
+    may_defer: the caller has checked that nothing reads the returned tensors before the backward pass ends (see _can_defer)."""
     B, sd, sh, sw, Cs = _cl_dims(St)
     _, ld, lh, lw, Cl = _cl_dims(Lt)
     dW = torch.empty(wshape, dtype=torch.float32, device=St.device)
     db = torch.empty(Cl if want_lbias else Cs, dtype=torch.float32, device=St.device) if (want_sbias or want_lbias) else None
     nbytes = lib.cvae_conv_wgrad_workspace_bytes(Cs, Cl, nd)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=St.device)
+    if Lt.dtype != St.dtype:                                 # the image layer of a bf16 model: L is the fp32 input itself
+        if Cl != 1 or want_lbias:
+            raise L.CvaeError("a mixed-dtype weight gradient is available for the single-channel image layer only")
+        check(L.timed(f"conv_wgrad nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L{Cl}", lib.cvae_conv_wgrad_image, ptr(St), ptr(Lt), L.dtype_code(Lt.dtype), ptr(dW), ptr(db), ptr(ws), nbytes,
+                      B, sd, sh, sw, Cs, ld, lh, lw, nd, L.dtype_code(St.dtype), stream()), "conv_wgrad_image")
+        return (dW, db) if want_sbias else dW
     exact2x = lh == 2 * sh and lw == 2 * sw and (nd == 2 or ld == 2 * sd)
-    if (DEFER_WGRAD and Cl != 1 and Cs % 64 == 0 and Cl % 32 == 0 and B > 0 and (exact2x or not want_lbias)):
+    if (DEFER_WGRAD and may_defer and Cl != 1 and Cs % 64 == 0 and Cl % 32 == 0 and B > 0 and (exact2x or not want_lbias)):
         try:
             if not _WG_QUEUED[0]:
                 torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush)     # only legal inside a backward pass
                 _WG_QUEUED[0] = True
-            _WG_PENDING.append(dict(S=St, L=Lt, dW=dW, db=db, side=1 if want_lbias else 0, ws=ws, nbytes=nbytes, nd=nd,
-                                    dims=(B, sd, sh, sw, Cs, ld, lh, lw, Cl)))
+            # the outputs are queued by ADDRESS: a second reference to dW / db would make AccumulateGrad clone them (still empty) instead of
+            # adopting them as .grad; their storage is kept alive by whoever receives the gradient (.grad or torch.autograd.grad's result)
+            _WG_PENDING.append(dict(S=St, L=Lt, dW=dW.data_ptr(), db=(db.data_ptr() if db is not None else None), side=1 if want_lbias else 0, ws=ws,
+                                    nbytes=nbytes, nd=nd, dims=(B, sd, sh, sw, Cs, ld, lh, lw, Cl)))
             return (dW, db) if (want_sbias or want_lbias) else dW
         except RuntimeError:
             pass                                             # not inside a backward pass (a direct call): compute now
@@ -401,12 +436,17 @@ class ConvDown(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None):
+    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None, out_dtype=None):
+        """out_dtype (single-channel image layer only): compute / output dtype when it differs from x's — the fp32 input batch of a bf16 model
+        is read as it is, without a cast pass."""
         L.require_gpu(x, weight, bias)
         Cs = weight.shape[0]
-        wp = packed[0] if packed is not None else pack_weight(weight, nd, False, x.dtype)
-        y = _conv_down(x, wp, bias, None, Cs, nd, act)
+        if out_dtype is not None and out_dtype == x.dtype:
+            out_dtype = None
+        wp = packed[0] if packed is not None else pack_weight(weight, nd, False, out_dtype or x.dtype)
+        y = _conv_down(x, wp, bias, None, Cs, nd, act, out_dtype)
         ctx.save_for_backward(x, weight, y)
+        ctx.bias_ref = bias
         ctx.packed_bwd = packed[1] if packed is not None else None
         ctx.cfg = (nd, act, in_is_relu_out, grad_premasked, bias is not None)
         return y
@@ -423,17 +463,20 @@ class ConvDown(torch.autograd.Function):
         fork = _Fork(g.device, g.shape[0] * g.shape[1] * g.shape[2] * g.shape[3])
         with fork:
             if ctx.needs_input_grad[1]:
+                defer = _can_defer(weight, ctx.bias_ref if want_db else None)
                 if want_db:
-                    dw, db = _conv_wgrad(g, x, nd, weight.shape, want_sbias=True)
+                    dw, db = _conv_wgrad(g, x, nd, weight.shape, want_sbias=True, may_defer=defer)
                 else:
-                    dw = _conv_wgrad(g, x, nd, weight.shape)
+                    dw = _conv_wgrad(g, x, nd, weight.shape, may_defer=defer)
             elif want_db:
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
             wp_up = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, True, g.dtype)
+            if x.dtype != g.dtype:
+                raise L.CvaeError("the image read in its own dtype carries no gradient (cast it first if it needs one)")
             dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None, l_dims=x.shape[1:4])
         fork.join(dw, db)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class ConvUp(torch.autograd.Function):
@@ -446,6 +489,7 @@ class ConvUp(torch.autograd.Function):
         wp = packed[1] if packed is not None else pack_weight(weight, nd, True, x.dtype)
         y = _conv_up(x, wp, bias, None, Cl, nd, act)
         ctx.save_for_backward(x, weight, y)
+        ctx.bias_ref = bias
         ctx.packed_bwd = packed[0] if packed is not None else None
         ctx.cfg = (nd, act, in_is_relu_out, grad_premasked, bias is not None)
         return y
@@ -462,10 +506,11 @@ class ConvUp(torch.autograd.Function):
         with fork:
             want_db = has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
+                defer = _can_defer(weight, ctx.bias_ref if want_db else None)
                 if want_db:
-                    dw, db = _conv_wgrad(x, g, nd, weight.shape, want_lbias=True)
+                    dw, db = _conv_wgrad(x, g, nd, weight.shape, want_lbias=True, may_defer=defer)
                 else:
-                    dw = _conv_wgrad(x, g, nd, weight.shape)
+                    dw = _conv_wgrad(x, g, nd, weight.shape, may_defer=defer)
             elif want_db:
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:

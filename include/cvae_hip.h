@@ -101,6 +101,17 @@ int cvae_conv_up(const void* S, const void* w, const float* bias, const void* ma
                  int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                  int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* The first conv of the encoder (Cl == 1) with the IMAGE read in the dtype it is stored in (l_dtype) while S is written in the compute
+ * dtype (`dtype`): the fp32 input volume of a bf16 model feeds the kernels directly — no cast pass, no bf16 copy of the batch
+ * (causal_cascade/models.py:13: nn.Conv2d(img_channels, 32, 4, 2, 1) on the fp32 batch).  cvae_conv_down_image = cvae_conv_down with
+ * Cl == 1 (w = the fp32 master weight); cvae_conv_wgrad_image = cvae_conv_wgrad with Cl == 1 and the S-side bias sum.  The mixed
+ * (fp32 image, bf16 S) forward reads 16-byte rows: it needs lw % 4 == 0 and a 16-byte aligned image (cvae_conv_image_supported == 1),
+ * otherwise cast the image and use the plain entry points. */
+int cvae_conv_image_supported(const void* L, int64_t lw, int l_dtype, int dtype);
+int cvae_conv_down_image(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S,
+                         int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, void* stream);
+int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                          int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, void* stream);
 /* ---- Exact-2x linear resize (decoder output d x h x w, one channel -> 2d x 2h x 2w; D == d == 1 for 2D) fused with the ELBO ----
  * causal_cascade/models.py:84-87 + train.py:5-17: the resized volume is recomputed from the small tensor wherever it is needed
  * instead of being written and re-read (csrc/recon_loss.hip).  cvae_up2x_supported: 1 when the shapes qualify (w % 4 == 0). */
