@@ -5,15 +5,26 @@
 
 One "step" = zero_grad -> forward -> ELBO -> backward -> (RCCL SUM all-reduce of the flat gradient bucket) -> Adam, on one
 batch of synthetic 128^3 volumes (B = 4 per GPU, bf16 conv arithmetic, fp32 heads/losses/master weights).  Inputs are
-resident in HBM before the timed region.  Rank 0 prints ONE JSON line with the whole-job throughput plus
-  roofline     : the dominant conv kernel's algorithmic FLOP/s (HIP events around each of its launches inside the timed
-                 region) against the dense bf16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PFLOP/s);
+resident in HBM before the timed region.  The timed region is EXACTLY K steps between barrier + synchronize brackets; it is
+repeated until >= 0.2 s have been timed and the MEDIAN repetition is reported (`timed_reps`, min / max alongside): one
+repetition of 20 steps is 19 ms, the same order as box-to-box noise.  Rank 0 prints ONE JSON line with the whole-job throughput plus
+  roofline     : the kernel family with the largest total time per step (HIP events around each of its launches, on the stream
+                 they are launched on, over eager steps run right after the timed region): algorithmic FLOP/s against the dense
+                 bf16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PFLOP/s); `traffic` = HBM bytes per launch from
+                 the committed rocprofv3 --pmc passes of THIS round's kernels (file and commit named in the line); `step` = the
+                 whole step's algorithmic FLOPs and bytes against both peaks; `top` = the five heaviest launches;
   cpu_baseline : the CPU oracle's train step (oracle/, pinned to the reference by golden vectors) timed on this node's
-                 host cores on a bounded sample of the same workload — a reported baseline, not the target.
+                 host cores on a bounded sample of the same workload — a reported baseline, not the target;
+  elbo_rel_err / elbo_rel_err_after_k : ELBO of the first batch at the initial weights, and after K = 5 Adam steps with injected
+                 noise, against the oracle's.
+
+Other workloads of BASELINE.json (`--workload`): vol64-f32 (configs[2]), mnist (configs[1]), decode (configs[4]: 240 stacked
+counterfactual decodes per rank), vol128-vessel (the vessel recipe's loss on binary ~10 % volumes).
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -25,12 +36,13 @@ if ROOT not in sys.path:
 
 PEAK_BF16_FLOPS = 2.5e15     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_FLOPS = 157.3e12    # fp32 MFMA / vector peak
+PEAK_HBM = 8.0e12            # HBM3E spec (6.3 TB/s achievable)
 METRIC = "training samples/sec on 128^3 vessel volumes (3D CausalVAE train step)"
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def conv_flops(name):
     """Algorithmic FLOPs (2*MACs, no padding / zero-insertion counted: SURVEY.md §8(d)) of one conv launch from its timer label."""
-    import re
     if name.startswith("conv_wgrad_multi"):                 # one grouped launch: the sum over its layers
         head, layers = name.rsplit(" ", 1)
         nd_, B_ = re.search(r"nd(\d)", head).group(1), re.search(r" B(\d+)", head).group(1)
@@ -39,6 +51,9 @@ def conv_flops(name):
             mm = re.match(r"S(\d+)x(\d+)x(\d+)x(\d+)L(\d+)", lay)
             tot += conv_flops(f"conv_wgrad nd{nd_} B{B_} S{mm.group(1)}x{mm.group(2)}x{mm.group(3)}x{mm.group(4)} L{mm.group(5)}")
         return tot
+    if name.startswith("linear_"):
+        M, K, N = (int(v) for v in re.search(r"M(\d+) K(\d+) N(\d+)", name).groups())
+        return 2.0 * M * K * N
     nd = int(re.search(r"nd(\d)", name).group(1))
     B = int(re.search(r" B(\d+)", name).group(1))
     taps = 64 if nd == 3 else 16
@@ -53,17 +68,68 @@ def conv_flops(name):
     return 2.0 * B * pos * Cs * Cl * taps
 
 
-def make_batch(B, size, seed, device):
+def family(label):
+    """Kernel family of a timer label = one row of the rocprofv3 summary (the template instance serving several layers)."""
+    for pre, fam in (("conv_wgrad", "conv_wgrad_kernel + wgrad_reduce_kernel (weight gradients: main + slab reduction)"),
+                     ("conv_down", "conv_data_kernel<DOWN> / down_c1 (conv forward, convT backward-data)"),
+                     ("conv_up", "conv_data_kernel<UP> / up_c1 (convT forward, conv backward-data)"),
+                     ("linear_", "linear layers (gemm / skinny kernels)")):
+        if label.startswith(pre):
+            return fam
+    return label
+
+
+def step_algorithmic(B, size, esz, n_params, conv_params):
+    """Algorithmic FLOPs and HBM bytes of one train step: conv FLOPs = fwd + bwd-data + bwd-weight (no bwd-data for the
+    first layer); activation bytes (7V + 6A) * esz per sample when the decoder output is resized ((3V + 6A) * esz at the native 64^3),
+    Adam 28 B/param, weights: fp32 dense layers read fwd, read + written bwd; packed conv weights written once, read fwd and bwd."""
+    chans = [(1, 32), (32, 64), (64, 128), (128, 256)]
+    fl, A, s = 0.0, 0, size
+    for i, (ci, co) in enumerate(chans):                     # encoder: output extent s / 2
+        s //= 2
+        f = 2.0 * B * s ** 3 * ci * co * 64
+        fl += f * (3 if i else 2)
+        A += s ** 3 * co
+    d = 4
+    for i, (ci, co) in enumerate([(256, 128), (128, 64), (64, 32), (32, 1)]):    # decoder: input extent d
+        fl += 3 * 2.0 * B * d ** 3 * ci * co * 64
+        d *= 2
+        A += d ** 3 * co
+    V = size ** 3
+    act = B * ((7 * V + 6 * A) if size != 64 else (3 * V + 6 * A)) * esz
+    dense = n_params - conv_params
+    byt = act + 28 * n_params + 3 * 4 * dense + conv_params * (4 + 3 * esz)
+    return fl, byt
+
+
+def make_batch(B, size, seed, device, binary=False):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 1, size, size, size, generator=g)            # z-scored volumes (causal_cascade/dataset.py:132-134)
+    if binary:                                                      # vessel recipe: min-max + mean-threshold binarised, sparse (vessel .../dataset.py:236-237)
+        import torch.nn.functional as F
+        sm = F.avg_pool3d(x, 5, 1, 2)
+        x = (sm > torch.quantile(sm.flatten()[:: max(1, sm.numel() // 1000000)], 0.90)).float()
     m = torch.rand(B, 12, generator=g)                              # min-max normalised morphology (dataset.py:148)
     t = torch.randint(0, 19, (B,), generator=g)
     eps = torch.randn(B, 64, generator=g)
     return tuple(v.to(device) for v in (x, m, t, eps))
 
 
-def cpu_baseline(B, size, budget_s, x, m, t, eps, lr=1e-3, threads=16):
-    """Oracle train steps on the host CPU: bounded sample (>= 2 timed steps, stops after ~budget_s seconds)."""
+def cpu_info():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return dict(os_cpu_count=os.cpu_count(), affinity=aff, cpu_model=model)
+
+
+def cpu_baseline(B, size, budget_s, x, m, t, eps, lr, threads, min_steps):
+    """Oracle train steps on the host CPU: bounded sample (>= min_steps steps, stops after ~budget_s seconds)."""
     import oracle
     torch.set_num_threads(threads)
     sd = oracle.init_state_dict("bio3d", seed=42)
@@ -79,13 +145,332 @@ def cpu_baseline(B, size, budget_s, x, m, t, eps, lr=1e-3, threads=16):
             times.append(dt)                                         # step 0 = warm-up (allocator, mkldnn primitive cache)
         losses.append(float(st["loss"]))
         step += 1
-        if (len(times) >= 2 and time.time() - t_all > budget_s) or len(times) >= 20:
+        if (len(losses) >= min_steps and len(times) >= 2 and time.time() - t_all > budget_s) or len(times) >= 20:
             break
     times.sort()
     med = times[len(times) // 2]
+    info = cpu_info()
     return dict(value=B / med, unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{len(times)} timed oracle train steps (fp32, B={B}, {size}^3) after 1 warm-up; median {med * 1e3:.0f} ms/step",
-                losses=[v if v == v and abs(v) != float("inf") else None for v in losses[:4]]), losses[0]
+                losses=[v if v == v and abs(v) != float("inf") else None for v in losses[:8]], **info), losses
+
+
+def timed_region(step, steps, warmup, world, dev, min_total_s):
+    """W warm-up steps, then repetitions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides and reduced with MAX
+    over ranks; repeated until min_total_s have been timed.  Returns (per-repetition seconds, last step's outputs)."""
+    import torch.distributed as dist
+    out = None
+    for _ in range(warmup):
+        out = step()
+    reps = []
+    while True:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())                                    # the same number on every rank: they all stop together
+        reps.append(el)
+        if sum(reps) >= min_total_s or len(reps) >= 64:
+            return reps, out
+
+
+def timing_fields(reps, steps, samples_per_step):
+    srt = sorted(reps)
+    med = srt[len(srt) // 2]
+    return {"value": samples_per_step * steps / med, "ms_per_step": med / steps * 1e3, "timed_reps": len(reps),
+            "ms_per_step_min": srt[0] / steps * 1e3, "ms_per_step_max": srt[-1] / steps * 1e3}
+
+
+def traffic_table():
+    p = os.path.join(ROOT, TRAFFIC_FILE)
+    if not os.path.exists(p):
+        return {}, None
+    try:
+        import subprocess
+        commit = subprocess.run(["git", "log", "-1", "--format=%h", "--", TRAFFIC_FILE], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+    except Exception:                                               # noqa: BLE001 - no git on the box
+        commit = None
+    return json.load(open(p)), commit
+
+
+def roofline_from_timer(timer, n_steps, dtype, step_ms, step_flops, step_bytes, linear_dtype=None):
+    """Families by total time per step; the dominant one is the roofline kernel.  linear_dtype: arithmetic of the linear family when it
+    differs from the convs' (fp32 MFMA linears next to bf16 convs price against the fp32 peak)."""
+    summ = timer.summary()
+    peak = PEAK_BF16_FLOPS if dtype == "bf16" else PEAK_F32_FLOPS
+    fams = {}
+    for k, (n, ms) in summ.items():
+        f = fams.setdefault(family(k), dict(ms=0.0, flops=0.0, launches=0))
+        f["ms"] += n * ms / n_steps
+        f["flops"] += n * conv_flops(k) / n_steps
+        f["launches"] += n / n_steps
+    dom = max(fams, key=lambda f: fams[f]["ms"])
+    d = fams[dom]
+    if dom.startswith("linear") and linear_dtype is not None:
+        peak = PEAK_BF16_FLOPS if linear_dtype == "bf16" else PEAK_F32_FLOPS
+    traffic, commit = traffic_table()
+    tr = traffic.get(dom, {})
+    ach = d["flops"] / (d["ms"] * 1e-3)
+    roof = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": tr.get("hbm_bytes_per_step"), "traffic_algorithmic": tr.get("algorithmic_bytes_per_step"),
+            "traffic_source": (f"{TRAFFIC_FILE} @ {commit}" if tr else None),
+            "avg_ms": d["ms"] / d["launches"], "ms_per_step": d["ms"], "launches_per_step": d["launches"],
+            "algorithmic_gflop_per_step": d["flops"] / 1e9,
+            "timing": f"HIP events around each launch of the family over {n_steps} eager steps run right after the timed region",
+            "step": {"algorithmic_gflop": step_flops / 1e9, "algorithmic_mb": step_bytes / 1e6, "ms": step_ms,
+                     "mfma_frac": step_flops / (step_ms * 1e-3) / peak, "hbm_frac": step_bytes / (step_ms * 1e-3) / PEAK_HBM}}
+    per = sorted(summ.items(), key=lambda kv: -kv[1][0] * kv[1][1])
+    top = []
+    for k, (n, ms) in per[:5]:
+        e = {"launch": k, "per_step": n / n_steps, "avg_ms": round(ms, 4), "tflops": round(conv_flops(k) / (ms * 1e-3) / 1e12, 1)}
+        t_ = traffic.get(k)
+        if t_:
+            e["hbm_mb_counter"] = round(t_.get("hbm_bytes_per_launch", 0) / 1e6, 1)
+            e["hbm_mb_algorithmic"] = round(t_.get("algorithmic_bytes_per_launch", 0) / 1e6, 1)
+        top.append(e)
+    roof["top"] = top
+    kernels = {k: {"per_step": n / n_steps, "avg_ms": round(ms, 4), "tflops": round(conv_flops(k) / (ms * 1e-3) / 1e12, 1)} for k, (n, ms) in per}
+    fam_out = {f: {"ms_per_step": round(v["ms"], 4), "launches_per_step": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+               for f, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
+    return roof, kernels, fam_out
+
+
+# ------------------------------------------------------------------------------------------------------------------ volume workloads
+def run_volume(args, rank, world, dev):
+    from causal_vae_amd import FusedAdam, _lib
+    from causal_vae_amd import ops as _ops
+    from causal_vae_amd.causal_cascade import CausalBioVAE3D, loss_function, train_step
+    from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters
+    vessel = args.workload == "vol128-vessel"
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(42)                                            # causal_cascade/main.py:28
+    model = CausalBioVAE3D().to(dev).train().set_compute_dtype(dtype)
+    broadcast_parameters(model)
+    opt = FusedAdam(model.parameters(), lr=args.lr, device_step=True)   # main.py:50
+    if world == 1 and args.overlap_adam:
+        opt.overlap_backward(model.early_gradient_parameters())        # measured: -4 % (the streaming update slows the co-running conv kernels more than it hides)
+    reducer = GradAllReducer(model.parameters()) if world > 1 else None
+    x, m, t, eps = make_batch(args.batch, args.size, 1234 + rank, dev, binary=vessel)
+
+    if vessel:
+        from causal_vae_amd.optim import clip_grad_norm_
+        from causal_vae_amd.vessel import loss_function as vessel_loss, total_loss
+
+        def vessel_step_fn():
+            """The vessel recipe's step on volumes (vessel_analysis/01_train/train.py:18-60, 70-86): pos-weighted MSE-sum + 0.3 * background L1 +
+            0.5 * KLD + Gaussian NLL of m (unit variance: the lift has no m_logvar head), clip_grad_norm_(5.0), Adam."""
+            opt.zero_grad(set_to_none=True)
+            recon_x, m_hat, mu, logvar = model(x, m, t)
+            recon, kld, morph, sparsity = vessel_loss(recon_x, x, m_hat, m, mu, logvar, m_hat, torch.zeros_like(m_hat))
+            loss = total_loss(recon, kld, morph, sparsity, beta=0.5)
+            _ops.backward_from(loss)
+            if reducer is not None:
+                reducer()
+            clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            return loss.detach(), recon.detach(), morph.detach()
+        eager_step = vessel_step_fn
+    else:
+        def eager_step():
+            return train_step(model, opt, x, m, t, grad_hook=reducer)
+
+    # ELBO of the first batch at the initial weights (compared with the oracle's below, rank 0 / N = 1)
+    with torch.no_grad():
+        out = model(x, m, t, eps=eps)
+        elbo0 = float(loss_function(out[0], x, out[1], m, out[2], out[3])[0])
+    del out
+
+    use_graph = not args.no_graph
+    n_pre, want_split, capture_fallback = 0, False, None
+    if use_graph and vessel:
+        from causal_vae_amd.graph import GraphedCallable
+        if world > 1:
+            raise SystemExit("vol128-vessel is a single-GPU secondary workload")
+        gc = GraphedCallable(eager_step, warmup=3)
+        n_pre = 3
+        step = lambda: gc()
+    elif use_graph:
+        from causal_vae_amd.graph import GraphedTrainStep
+        # N > 1: the backward is split at the encoder output so the decoder + bottleneck gradients are exchanged under the encoder's backward
+        want_split = (world > 1 and not args.no_overlap_exchange) or args.force_overlap_exchange
+        try:
+            gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3, overlap_exchange=want_split)   # None: model.forward_elbo, as train_step
+            n_pre = 3                                                # the capture warm-up runs 3 real steps
+        except Exception as e:                                       # noqa: BLE001 - the plain two-graph exchange is always available
+            if not want_split:
+                raise
+            capture_fallback = repr(e)
+            print(f"[bench] split-backward capture failed ({e!r}); falling back to one exchange after the backward", file=sys.stderr)
+            want_split = False
+            gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3)
+            n_pre = 6                                                # both attempts trained 3 warm-up steps each
+        step = lambda: gstep()
+    else:
+        step = eager_step
+
+    reps, out = timed_region(step, args.steps, max(args.warmup - n_pre, 1), world, dev, args.min_timed_s)
+    final_loss = out[0].clone()
+    # ---- roofline leg: the same step issued eagerly with HIP events around every conv launch (events cannot sit inside a
+    # replayed graph); same process, same buffers, directly after the timed region ----
+    timer = None
+    if not args.no_kernel_timer and args.roofline_steps > 0:
+        _ops.FORK_BACKWARD = False                                   # one stream: every launch is timed alone
+        timer = _lib.KernelTimer()
+        eager_step()
+        torch.cuda.synchronize()
+        _lib.TIMER = timer
+        for _ in range(args.roofline_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        _lib.TIMER = None
+    fin = lambda v: float(v) if torch.isfinite(torch.as_tensor(float(v))) else None
+    if rank != 0:
+        return None
+    n_params = sum(p.numel() for p in model.parameters())
+    conv_params = sum(p.numel() for n_, p in model.named_parameters() if ("enc_conv" in n_ or "dec_conv" in n_) and p.dim() > 1)
+    res = {"metric": METRIC if args.workload == "vol128" else f"training samples/sec, workload {args.workload}", "unit": "samples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
+    res.update(timing_fields(reps, args.steps, world * args.batch))
+    loss_name = ("vessel recipe: pos-weighted MSE-sum + 0.3*background-L1 + 0.5*KLD + Gaussian-NLL(m), clip 5.0" if vessel
+                 else "ELBO = MSE-sum + 2000*MSE-sum(m) + KLD")
+    res["config"] = {"workload": f"3D vessel CausalVAE train step, {args.size}^3 {args.dtype} volumes ({'binary ~10 % density' if vessel else 'z-scored N(0,1)'}), "
+                                 f"batch {args.batch}/GPU, Adam lr {args.lr:g}, {loss_name}",
+                     "global_batch": world * args.batch, "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}", "params": n_params}
+    res["exchange"] = ("split backward: decoder + bottleneck bucket all-reduced under the encoder backward" if (use_graph and want_split) else
+                       ("one all-reduce after the backward" if world > 1 else "none (1 rank)"))
+    if capture_fallback:
+        res["capture_fallback"] = capture_fallback
+    res.update({"final_loss": fin(final_loss), "lr": args.lr, "hip_graph": use_graph, "deferred_wgrad": bool(_ops.DEFER_WGRAD)})
+    step_ms = res["ms_per_step"]
+    fl, byt = step_algorithmic(args.batch, args.size, 2 if args.dtype == "bf16" else 4, n_params, conv_params)
+    if timer is not None:
+        roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, step_ms, fl, byt)
+        res["roofline"] = roof
+        res["conv_ms_per_step"] = sum(v["ms_per_step"] for v in fams.values())
+        res["families"] = fams
+        res["kernels"] = kernels
+    if world == 1 and args.cpu_seconds > 0 and not vessel:
+        info = cpu_info()
+        threads = args.cpu_threads if args.cpu_threads > 0 else min(info["affinity"], 16)
+        K = 5
+        cb, ref_losses = cpu_baseline(args.batch, args.size, args.cpu_seconds, x.cpu(), m.cpu(), t.cpu(), eps.cpu(), args.lr, threads, K + 1)
+        res["cpu_baseline"] = cb
+        res["elbo_rel_err"] = abs(elbo0 - ref_losses[0]) / abs(ref_losses[0])
+        res["gpu_over_cpu"] = res["value"] / cb["value"]
+        # the same K + 1 steps on the GPU from the same initial weights with the same injected noise: ELBO after K Adam updates
+        _ops.EpsSource._instances = 0
+        torch.manual_seed(42)
+        m2 = CausalBioVAE3D().to(dev).train().set_compute_dtype(dtype)
+        o2 = FusedAdam(m2.parameters(), lr=args.lr)
+        gl = [float(train_step(m2, o2, x, m, t, eps=eps)[0]) for _ in range(K + 1)]
+        res["elbo_rel_err_after_k"] = {"k": K, "value": abs(gl[K] - ref_losses[K]) / abs(ref_losses[K]), "gpu": gl[K], "oracle": ref_losses[K],
+                                       "trajectory_rel_err": [abs(a - b) / abs(b) for a, b in zip(gl, ref_losses)]}
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------ MNIST (configs[1])
+def run_mnist(args, rank, world, dev):
+    from causal_vae_amd import FusedAdam, _lib
+    from causal_vae_amd.graph import GraphedCallable
+    from causal_vae_amd.mnist_baseline import CausalMorphVAE12, LatentDiscriminator, train_step as mnist_step
+    if world > 1:
+        raise SystemExit("the MNIST workload is single-GPU (BASELINE.json configs[1])")
+    B = args.batch
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(1234)
+    x, m = torch.rand(B, 1, 28, 28, generator=g).to(dev), torch.rand(B, 12, generator=g).to(dev)
+    t = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float().to(dev)
+    torch.manual_seed(42)
+    vae, disc = CausalMorphVAE12().to(dev).train().set_compute_dtype(dtype), LatentDiscriminator().to(dev).train()
+    ov, od = FusedAdam(vae.parameters(), lr=1e-3, device_step=True), FusedAdam(disc.parameters(), lr=1e-3, device_step=True)
+    eager = lambda: mnist_step(vae, disc, ov, od, x, m, t)
+    n_pre = 0
+    if not args.no_graph:
+        gs = GraphedCallable(eager, warmup=3)
+        n_pre = 3
+        step = lambda: (gs()["loss"],)
+    else:
+        step = lambda: (eager()["loss"],)
+    reps, out = timed_region(step, args.steps, max(args.warmup - n_pre, 1), world, dev, args.min_timed_s)
+    timer = _lib.KernelTimer()
+    eager(); torch.cuda.synchronize()
+    _lib.TIMER = timer
+    for _ in range(args.roofline_steps):
+        eager()
+    torch.cuda.synchronize()
+    _lib.TIMER = None
+    res = {"metric": "training samples/sec, MNIST CausalMorphVAE12 adversarial step (BASELINE.json configs[1])", "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
+    res.update(timing_fields(reps, args.steps, B))
+    res["config"] = {"workload": f"MNIST CausalMorphVAE12 adversarial step (D step + VAE step, mnist_test/01_baseline_causal_vae/train.py:34-93), batch {B}, "
+                                 f"{args.dtype} convs" + (" and large linears" if getattr(vae, "linear_dtype", None) == torch.bfloat16 else ", fp32 linears"),
+                     "global_batch": B, "params": sum(p.numel() for p in vae.parameters()) + sum(p.numel() for p in disc.parameters())}
+    res["final_loss"] = float(out[0])
+    res["hip_graph"] = not args.no_graph
+    # algorithmic FLOPs of the step: 3 VAE forwards' worth is NOT what runs — one no-grad forward (D step), one forward + backward (VAE step)
+    n_params = res["config"]["params"]
+    fwd = 2.0 * B * (14 * 14 * 32 * 16 + 7 * 7 * 64 * 32 * 16 + 3158 * 512 + 512 * 20 + 10 * 128 + 128 * 12 + 22 * 3136 + 7 * 7 * 64 * 32 * 16 + 14 * 14 * 32 * 16)
+    step_fl = fwd * (1 + 3)
+    step_by = 28 * n_params + 3 * 4 * n_params + B * 4 * (2 * 784 * 3 + 6 * (6272 + 3136 + 3136 + 6272))
+    lin_dt = "bf16" if getattr(vae, "linear_dtype", None) == torch.bfloat16 else "f32"
+    roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, res["ms_per_step"], step_fl, step_by, linear_dtype=lin_dt)
+    roof["linear_arithmetic"] = lin_dt
+    res["roofline"], res["families"], res["kernels"] = roof, fams, kernels
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------ decode (configs[4])
+def run_decode(args, rank, world, dev):
+    from causal_vae_amd import _lib
+    from causal_vae_amd.causal_cascade import CausalBioVAE3D
+    from causal_vae_amd.counterfactual import sweep_inputs
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(dev).eval().set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(1234 + rank)
+    z, m = torch.randn(args.batch, 64, generator=g).to(dev), torch.rand(args.batch, 12, generator=g).to(dev)
+    z_rep, m_cf = sweep_inputs(z, m, list(range(12)), [0.0, 0.25, 0.5, 0.75, 1.0])      # 60 decodes per sample (SURVEY.md §8(d) config 5)
+    rows = z_rep.shape[0]
+    size = None if args.decode_native else (args.size,) * 3
+
+    def step():
+        with torch.no_grad():
+            return (model.decode(z_rep, m_cf, size),)
+    reps, out = timed_region(step, args.steps, max(args.warmup, 1), world, dev, args.min_timed_s)
+    shape = tuple(out[0].shape)
+    del out
+    timer = _lib.KernelTimer()
+    step(); torch.cuda.synchronize()
+    _lib.TIMER = timer
+    for _ in range(args.roofline_steps):
+        step()
+    torch.cuda.synchronize()
+    _lib.TIMER = None
+    if rank != 0:
+        return None
+    res = {"metric": "counterfactual decodes/sec (batched M-sweep decode, BASELINE.json configs[4])", "unit": "decodes/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
+    res.update(timing_fields(reps, args.steps, world * rows))
+    res["config"] = {"workload": f"batched counterfactual decode: {args.batch} samples x 12 features x 5 values = {rows} stacked rows per rank -> dec_input -> dec_conv -> "
+                                 f"{'native 64^3' if size is None else 'trilinear resize to %d^3' % args.size}, {args.dtype} convs "
+                                 "(replaces the per-value loop of vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:77-99)",
+                     "rows_per_rank": rows, "output_shape": list(shape)}
+    fl = 2.0 * rows * 64 * (4 ** 3 * 256 * 128 + 8 ** 3 * 128 * 64 + 16 ** 3 * 64 * 32 + 32 ** 3 * 32 * 1) + 2.0 * rows * 76 * 16384
+    A = rows * (8 ** 3 * 128 + 16 ** 3 * 64 + 32 ** 3 * 32 + 64 ** 3)
+    esz = 2 if args.dtype == "bf16" else 4
+    byt = 2 * A * esz + rows * 16384 * esz + (rows * args.size ** 3 * 4 if size is not None else rows * 64 ** 3 * 4)
+    roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, res["ms_per_step"], fl, byt)
+    res["roofline"], res["families"], res["kernels"] = roof, fams, kernels
+    return res
 
 
 def main():
@@ -93,9 +478,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=128, help="volume edge (128 = BASELINE config)")
-    ap.add_argument("--batch", type=int, default=4, help="samples per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="vol128", choices=["vol128", "vol64-f32", "mnist", "decode", "vol128-vessel"])
+    ap.add_argument("--size", type=int, default=None, help="volume edge (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
+    ap.add_argument("--min-timed-s", type=float, default=0.2, help="repeat the K-step timed region until this much has been timed; the median repetition is reported")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = the box's CPU share: min(affinity, 16 per GPU))")
     ap.add_argument("--lr", type=float, default=1e-4, help="Adam learning rate (the reference uses 1e-3, causal_cascade/main.py:50, at which the 3D lift diverges on step 3 in the oracle too: DESIGN.md)")
@@ -109,21 +496,21 @@ def main():
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")
     ap.add_argument("--force-overlap-exchange", action="store_true", help="take the split-backward capture also at N = 1 (no exchange happens)")
     ap.add_argument("--roofline-steps", type=int, default=5, help="eager steps with per-launch HIP events after the timed region")
+    ap.add_argument("--decode-native", action="store_true", help="decode workload: stop at the decoder's native 64^3 (no resize)")
     args = ap.parse_args()
+    defaults = {"vol128": (128, 4, "bf16"), "vol128-vessel": (128, 4, "bf16"), "vol64-f32": (64, 16, "f32"), "mnist": (28, 1024, "bf16"), "decode": (128, 4, "bf16")}
+    dsz, dB, ddt = defaults[args.workload]
+    args.size = args.size or dsz
+    args.batch = args.batch or dB
+    args.dtype = args.dtype or ddt
 
-    from causal_vae_amd import FusedAdam, _lib
-    from causal_vae_amd.causal_cascade import CausalBioVAE3D, loss_function, train_step
-    from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters, init_distributed
+    from causal_vae_amd import ops as _ops
+    from causal_vae_amd.parallel import init_distributed
     import torch.distributed as dist
-
     if args.no_defer_wgrad:
-        from causal_vae_amd import ops as _ops1
-        _ops1.DEFER_WGRAD = False
+        _ops.DEFER_WGRAD = False
     if args.fork:
-        from causal_vae_amd import ops as _ops0
-        _ops0.FORK_BACKWARD = True
-        _ops0.FORK_MAX_POSITIONS = args.fork_max_positions
-        _ops0.DEFER_JOIN = args.defer_join
+        _ops.FORK_BACKWARD, _ops.FORK_MAX_POSITIONS, _ops.DEFER_JOIN = True, args.fork_max_positions, args.defer_join
     rank, world, local_rank = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -133,129 +520,13 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-
-    torch.manual_seed(42)                                            # causal_cascade/main.py:28
-    model = CausalBioVAE3D().to(dev).train().set_compute_dtype(dtype)
-    broadcast_parameters(model)
-    opt = FusedAdam(model.parameters(), lr=args.lr, device_step=True)   # main.py:50
-    if world == 1 and args.overlap_adam:
-        opt.overlap_backward(model.early_gradient_parameters())        # measured: -4 % (the streaming update slows the co-running conv kernels more than it hides)
-    reducer = GradAllReducer(model.parameters()) if world > 1 else None
-    x, m, t, eps = make_batch(args.batch, args.size, 1234 + rank, dev)
-
-    # ELBO of the first batch at the initial weights (compared with the oracle's below, rank 0 / N = 1)
-    with torch.no_grad():
-        out = model(x, m, t, eps=eps)
-        elbo0 = float(loss_function(out[0], x, out[1], m, out[2], out[3])[0])
-    del out
-
-    def eager_step():
-        return train_step(model, opt, x, m, t, grad_hook=reducer)
-
-    use_graph = not args.no_graph
-    n_pre, want_split = 0, False
-    if use_graph:
-        from causal_vae_amd.graph import GraphedTrainStep
-        # N > 1: the backward is split at the encoder output so the decoder + bottleneck gradients are exchanged under the encoder's backward
-        want_split = (world > 1 and not args.no_overlap_exchange) or args.force_overlap_exchange
-        try:
-            gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3, overlap_exchange=want_split)   # None: model.forward_elbo, as train_step
-        except Exception as e:                                       # noqa: BLE001 - the plain two-graph exchange is always available
-            if not want_split:
-                raise
-            print(f"[bench] split-backward capture failed ({e!r}); falling back to one exchange after the backward", file=sys.stderr)
-            want_split = False
-            gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3)
-        n_pre = 3                                                    # the capture warm-up runs 3 real steps
-        step = lambda: gstep()
+    if args.workload == "mnist":
+        res = run_mnist(args, rank, world, dev)
+    elif args.workload == "decode":
+        res = run_decode(args, rank, world, dev)
     else:
-        step = eager_step
-
-    traj = []
-    for _ in range(max(args.warmup - n_pre, 1)):
-        traj.append(step()[0].clone())
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()[0]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    traj.append(loss.clone())
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # ---- roofline leg: the same step issued eagerly with HIP events around every conv launch (events cannot sit inside a
-    # replayed graph); same process, same buffers, directly after the timed region ----
-    timer = None
-    if not args.no_kernel_timer and args.roofline_steps > 0:
-        from causal_vae_amd import ops as _ops
-        _ops.FORK_BACKWARD = False                                   # one stream: every launch is timed alone
-        timer = _lib.KernelTimer()
-        eager_step()
-        torch.cuda.synchronize()
-        _lib.TIMER = timer
-        for _ in range(args.roofline_steps):
-            eager_step()
-        torch.cuda.synchronize()
-        _lib.TIMER = None
-    fin = lambda v: float(v) if torch.isfinite(torch.as_tensor(float(v))) else None
-    final_loss = fin(loss)
-    traj = [fin(v) for v in traj]
-
+        res = run_volume(args, rank, world, dev)
     if rank == 0:
-        total = world * args.batch * args.steps
-        res = {
-            "metric": METRIC, "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"3D vessel CausalVAE train step, {args.size}^3 {args.dtype} volumes, batch {args.batch}/GPU, "
-                                   f"Adam lr {args.lr:g}, ELBO = MSE-sum + 2000*MSE-sum(m) + KLD", "global_batch": world * args.batch,
-                       "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}",
-                       "params": sum(p.numel() for p in model.parameters())},
-            "exchange": ("split backward: decoder + bottleneck bucket all-reduced under the encoder backward" if (use_graph and want_split) else
-                         ("one all-reduce after the backward" if world > 1 else "none (1 rank)")),
-            "final_loss": final_loss, "loss_trajectory": traj if len(traj) <= 6 else traj[:4] + traj[-2:], "lr": args.lr, "hip_graph": use_graph, "side_stream_fork": args.fork,
-        }
-        if timer is not None:
-            summ = timer.summary()
-            per_step = {k: (n / args.roofline_steps, ms) for k, (n, ms) in summ.items()}
-            # dominant kernel = the heaviest single-kernel conv launch (a conv_wgrad call is two kernels, main + slab reduction, so its
-            # event time has no single row in the rocprof summary to agree with; it is listed under "kernels" like everything else)
-            # Among launches within 10 % of the heaviest, an `up` launch is preferred: enc2's backward-data is the only user of its
-            # template instance, so it has its own row in the rocprof summary, while the `down` rows average three layers.
-            single = [k for k in summ if k.startswith(("conv_down", "conv_up"))] or list(summ)
-            cost = lambda k: summ[k][0] * summ[k][1]
-            top = max(cost(k) for k in single)
-            dom = max((k for k in single if cost(k) >= 0.9 * top), key=lambda k: (k.startswith("conv_up"), cost(k)))
-            n, ms = summ[dom]
-            fl = conv_flops(dom)
-            peak = PEAK_BF16_FLOPS if args.dtype == "bf16" else PEAK_F32_FLOPS
-            ach = fl / (ms * 1e-3)
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tfile):                                # HBM bytes per launch from the committed rocprofv3 --pmc passes
-                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic, "avg_ms": ms, "launches_per_step": n / args.roofline_steps,
-                               "timing": f"HIP events around each launch over {args.roofline_steps} eager steps run right after the timed region",
-                               "algorithmic_gflop_per_launch": fl / 1e9}
-            conv_ms = sum(n_ * ms_ for n_, ms_ in summ.values()) / args.roofline_steps
-            res["conv_ms_per_step"] = conv_ms
-            res["kernels"] = {k: {"per_step": v[0], "avg_ms": round(v[1], 4), "tflops": round(conv_flops(k) / (v[1] * 1e-3) / 1e12, 1)}
-                              for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0] * kv[1][1])}
-        if world == 1 and args.cpu_seconds > 0:
-            aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            threads = args.cpu_threads if args.cpu_threads > 0 else min(aff, 16)
-            cb, elbo_ref = cpu_baseline(args.batch, args.size, args.cpu_seconds, x.cpu(), m.cpu(), t.cpu(), eps.cpu(), args.lr, threads)
-            res["cpu_baseline"] = cb
-            res["elbo_rel_err"] = abs(elbo0 - elbo_ref) / abs(elbo_ref)
-            res["gpu_over_cpu"] = res["value"] / cb["value"]
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

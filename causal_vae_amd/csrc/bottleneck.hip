@@ -500,26 +500,37 @@ __global__ __launch_bounds__(256) void dec_input_bwd_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ d(zm) -> LDS
-// dzs[i] = sum_q slot[q][i], q in index order; `n` floats per slot.  Threads take 4 consecutive elements (one 16-byte load per slot; n % 4 == 0
-// whenever K4 % 4 == 0, else element-wise) and keep 8 slots in flight.
-__device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n, int nslots) {
-    if ((n & 3) == 0) {
-        for (int i4 = threadIdx.x; i4 < n / 4; i4 += blockDim.x) {
+__device__ __forceinline__ float* lds_align16(float* p) { return (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15); }
+// dzs[i] = sum_q slot[q][i]; `n` floats per slot (n <= 2048).  With n % 4 == 0 (K4 % 4 == 0) all threads take part: thread (i4, part) adds the slots
+// of its contiguous part of the slot range for 4 consecutive elements (one 16-byte load per slot, 16 in flight), the parts meet in `scratch`
+// (>= n * parts floats of LDS behind dzs ... the caller's dynamic LDS is sized for it) and are added in part order — a fixed summation order.
+__device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n, int nslots, float* scratch) {
+    const int nt = blockDim.x, n4 = n >> 2;
+    if ((n & 3) == 0 && n4 <= nt) {
+        const int parts = nt / n4, i4 = threadIdx.x % n4, part = threadIdx.x / n4;
+        if (part < parts) {
+            const int q0 = (int)((long long)nslots * part / parts), q1 = (int)((long long)nslots * (part + 1) / parts);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int q = 0;
-            for (; q + 8 <= nslots; q += 8) {
-                float4 u[8];
+            int q = q0;
+            for (; q + 16 <= q1; q += 16) {
+                float4 u[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) u[j] = *(const float4*)(dzm_acc + (size_t)(q + j) * n + 4 * i4);
+                for (int j = 0; j < 16; ++j) u[j] = *(const float4*)(dzm_acc + (size_t)(q + j) * n + 4 * i4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
+                for (int j = 0; j < 16; ++j) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
             }
-            for (; q < nslots; ++q) { const float4 u = *(const float4*)(dzm_acc + (size_t)q * n + 4 * i4); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-            dzs[4 * i4] = v.x; dzs[4 * i4 + 1] = v.y; dzs[4 * i4 + 2] = v.z; dzs[4 * i4 + 3] = v.w;
+            for (; q < q1; ++q) { const float4 u = *(const float4*)(dzm_acc + (size_t)q * n + 4 * i4); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            *(float4*)(scratch + (size_t)part * n + 4 * i4) = v;
         }
-        return;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += nt) {
+            float a = 0.f;
+            for (int p = 0; p < parts; ++p) a += scratch[(size_t)p * n + i];
+            dzs[i] = a;
+        }
+        return;                                              // the caller's next __syncthreads() publishes dzs
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n; i += nt) {
         float v = 0.f;
         for (int q = 0; q < nslots; ++q) v += dzm_acc[(size_t)q * n + i];
         dzs[i] = v;
@@ -539,7 +550,7 @@ __device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads
     float* dy = da2 + M * HM;            // [M][HM]
     float* xh = dy + M * HM;             // [M][HM]
     float* ts = xh + M * HM;             // [M][T]
-    load_dzm(dzm_part, dzs, M * K4, d.NZ);
+    load_dzm(dzm_part, dzs, M * K4, d.NZ, lds_align16(ts + M * d.T));    // scratch: 4 * blockDim.x floats behind the operands (mech_bwd_lds)
     for (int i = tid; i < M * HM; i += T) { a2s[i] = sv.a2[i]; a1n[i] = sv.a1n[i]; xh[i] = sv.xhat[i]; }
     for (int i = tid; i < M * d.T; i += T) ts[i] = t_onehot[i];
     __syncthreads();
@@ -598,7 +609,7 @@ __global__ __launch_bounds__(256) void mulv_bwd_kernel(TailDims d, TailParams p,
     }
     const int ie = min(tid, M * Z - 1);
     const float e_eps = eps[ie], e_lv = sv.logvar[ie], e_gm = g_mu ? g_mu[ie] : 0.f, e_gl = g_logvar ? g_logvar[ie] : 0.f;
-    load_dzm(dzm_part, dzs, M * K4, d.NZ);
+    load_dzm(dzm_part, dzs, M * K4, d.NZ, lds_align16(red + 16 * M * 16));     // scratch: 4 * 256 floats behind `red` (launch LDS size)
     for (int i = tid; i < M * 16; i += 256) h2c[i] = (k0 + (i & 15) < d.N2) ? sv.h2[(i >> 4) * d.N2 + k0 + (i & 15)] : 0.f;
     __syncthreads();
     for (int i = tid; i < M * Z; i += 256) {
@@ -843,7 +854,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 }
 
 size_t mech_fwd_lds(const TailDims& d) { return sizeof(float) * (size_t)d.M * (d.T + 2 * d.HM); }
-size_t mech_bwd_lds(const TailDims& d) { return sizeof(float) * (size_t)d.M * (d.Z + d.DM + d.DM + 5 * d.HM + d.T); }
+size_t mech_bwd_lds(const TailDims& d) { return sizeof(float) * ((size_t)d.M * (d.Z + d.DM + d.DM + 5 * d.HM + d.T) + 4 * 256 + 4); }   // + load_dzm's scratch (16-byte aligned)
 
 }  // namespace
 
@@ -953,7 +964,7 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     const TailGrads g{gr->db1, gr->dW2, gr->db2, gr->dWmu, gr->dbmu, gr->dWlv, gr->dblv, gr->dWm0, gr->dbm0, gr->dgamma, gr->dbeta, gr->dWm3, gr->dbm3, gr->dWm5, gr->dbm5};
     const TailSaved s{sv->h1, sv->h2, sv->mu, sv->logvar, sv->xhat, sv->invstd, sv->a1n, sv->a2, sv->m_hat, sv->zm};
     float* dh2 = g1 + (size_t)M * q->N1;                     // second part of the g1 scratch
-    hipLaunchKernelGGL(mulv_bwd_kernel, dim3((unsigned)((q->N2 + 15) / 16)), dim3(256), sizeof(float) * ((size_t)M * K4 + 2 * (size_t)M * q->Z + 17 * (size_t)M * 16), st,
+    hipLaunchKernelGGL(mulv_bwd_kernel, dim3((unsigned)((q->N2 + 15) / 16)), dim3(256), sizeof(float) * ((size_t)M * K4 + 2 * (size_t)M * q->Z + 17 * (size_t)M * 16 + 4 * 256 + 4), st,
                        d, p, g, s, (const float*)dzm_partial, g_mu, g_logvar, eps, dh2);
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(fc2_bwd_kernel, dim3((unsigned)((q->N1 + 15) / 16)), dim3(256), sizeof(float) * ((size_t)M * q->N2 + 17 * (size_t)M * 16), st, d, p, g, s,

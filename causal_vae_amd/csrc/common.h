@@ -39,6 +39,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         default: return v;
     }
 }
+// The same with the activation fixed at compile time where a launch can afford a template instance per code: EPI 0 = none, 1 = ReLU
+// (one v_max), 2 = the runtime code.  A runtime switch inside an unrolled epilogue compiles to a scalar branch PER ELEMENT (~100 taken
+// branches per wave in the single-channel kernels), which costs more than the arithmetic it selects.
+template <int EPI> __device__ __forceinline__ float apply_act_t(float v, int act) {
+    if (EPI == 0) return v;
+    if (EPI == 1) return fmaxf(v, 0.f);
+    return apply_act(v, act);
+}
+#define CVAE_EPI_OF(act) ((act) == CVAE_ACT_NONE ? 0 : ((act) == CVAE_ACT_RELU ? 1 : 2))
 // derivative expressed through the activation OUTPUT y
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     switch (act) {

@@ -55,7 +55,7 @@ template <> struct C1Ops<float> {
     }
 };
 
-template <typename T, int ND, int CS>
+template <typename T, int ND, int CS, int EPI>
 __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, const float* __restrict__ w, const float* __restrict__ bias,
                                                       const T* __restrict__ mask, T* __restrict__ S, int sd, int sh, int sw, int ld, int lh, int lw,
                                                       int tiles_h, int tiles_w, int act) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float x = apply_act(v[j][q] + bv[j][q], act);
+                    float x = apply_act_t<EPI>(v[j][q] + bv[j][q], act);
                     if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
                     ov[q] = from_f32<T>(x);
                 }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
 // fp32 / 8 bf16), i.e. 6 (4) coalesced loads per row instead of 18 two-byte ones, converted to bf16 on the way into LDS.  The tap window of
 // an output starts at an ODD element of that row image, so a lane reads 3 aligned dwords per row and funnel-shifts (v_alignbit) the 4
 // bf16 it needs out of them.  Needs lw % EPV == 0 and a 16-byte aligned image (cvae_conv_image_supported); everything else as above.
-template <typename TL, int ND>
+template <typename TL, int ND, int EPI>
 __global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__ L, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const bf16* __restrict__ mask, bf16* __restrict__ S, int sd, int sh, int sw, int ld, int lh, int lw,
                                                           int tiles_h, int tiles_w, int act) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__
                 if (mask) *(uint4*)mv = *(const uint4*)(mask + pidx + c);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float x = apply_act(v[j][q] + bv[j][q], act);
+                    float x = apply_act_t<EPI>(v[j][q] + bv[j][q], act);
                     if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
                     ov[q] = from_f32<bf16>(x);
                 }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void up_c1_kernel(const T* __restrict__ S, con
 // (r, h) ends with the 2 x 2 (py, px) outputs of voxel r on plane pz = h — two 4-byte stores.
 // LDS: the 32-channel halo as 4 planes of 16-byte pieces (plane = channel piece: consecutive voxels are 16 B apart, conflict-free
 // ds_read_b128), and Wm^T as [chunk = (o, channel half)][h][parity] 16-byte rows built in-kernel from the fp32 master.
-template <int ND>
+template <int ND, int EPI>
 __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
                                                          const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_h,
                                                          int tiles_w, int act) {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
             const size_t idx = (((size_t)b * ld + lz) * lh + 2 * qy + py) * lw + 2 * qx;
-            float v0 = apply_act(acc[ms][2 * py] + bz, act), v1 = apply_act(acc[ms][2 * py + 1] + bz, act);
+            float v0 = apply_act_t<EPI>(acc[ms][2 * py] + bz, act), v1 = apply_act_t<EPI>(acc[ms][2 * py + 1] + bz, act);
             if (mask) {
                 union { uint32_t u; bf16 e[2]; } mk;
                 mk.u = *(const uint32_t*)(mask + idx);
@@ -463,7 +463,10 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
 //   fp32: v_mfma_f32_32x32x2_f32, one element per lane per operand.
 // Each workgroup walks `total / n_split` tiles of 128 positions and leaves with fp32 atomics directly in [Cs][1][taps].
 // TL: the dtype the 1-channel image L is STORED in (fp32 for the network input: read directly, rounded to T on the way into LDS).
-template <typename T, typename TL, int ND, bool LSUM>
+// VEC (bf16 compute only): the halo rows of L are fetched as aligned 16-byte vectors ([2 o0w - EPV, 2 o0w + 2 TW + EPV), EPV = 4 fp32 / 8 bf16
+// elements: 3 loads per thread and tile instead of 8 element loads) and scattered into the four LDS planes element by element; needs
+// lw % EPV == 0 and a 16-byte aligned L (image_vec_ok).
+template <typename T, typename TL, int ND, bool LSUM, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, const TL* __restrict__ L, float* __restrict__ ws, bool want_bias, int B, int sd, int sh, int sw,
                                                        int Cs, int ld, int lh, int lw, int tiles_d, int tiles_h, int tiles_w, int n_split, float* __restrict__ lsum_ws) {
     constexpr int TD = (ND == 3) ? 4 : 1, TH = (ND == 3) ? 4 : 8, TW = (ND == 3) ? 8 : 16;     // 128 positions
@@ -497,8 +500,10 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
     }
     // Software pipeline over the workgroup's tiles: the global loads of tile i+1 are in flight (in registers) while tile i
     // is consumed from LDS, so the HBM latency hides under the barriers, LDS traffic and MFMAs of the previous tile.
+    constexpr int EPV = 16 / sizeof(TL), NV = (2 * TW + 2 * EPV) / EPV, NVEC = LROWS * NV, HNV = VEC ? (NVEC + 255) / 256 : 1;
     uint4 sv[2][NU];
-    T hv[HN];
+    T hv[VEC ? 1 : HN];
+    uint4 hvv[HNV];
     // ConvTranspose bias gradient (the plain sum of L): every L element lies in the non-halo part of exactly one tile (host checks
     // L == 2 S), so the channel block 0 workgroups add up what they load anyway; wgrad_c1_finish sums the per-workgroup partials.
     const bool want_lsum = LSUM && blockIdx.y == 0;
@@ -520,16 +525,38 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
 #pragma unroll
             for (int u = 0; u < NU; ++u) sv[i][u] = ok ? ((const uint4*)src)[u] : make_uint4(0, 0, 0, 0);
         }
+        if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < HN; ++i) {
-            const int pos = t + i * 256;
-            const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
-            const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - 1 + x;
-            const bool ok = pos < NPOS && gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
-            hv[i] = ok ? from_f32<T>(to_f32(L[(((size_t)b * ld + gz) * lh + gy) * lw + gx])) : from_f32<T>(0.f);
-            if (LSUM) {
-                const bool inner = (ND == 2 || (z >= 1 && z <= 2 * TD)) && y >= 1 && y <= 2 * TH && x >= 1 && x <= 2 * TW;
-                if (want_lsum && ok && inner) lacc += to_f32(hv[i]);
+            for (int i = 0; i < HNV; ++i) {
+                const int it = min(t + i * 256, NVEC - 1), row = it / NV, j = it % NV;
+                const int y = row % IH, z = row / IH;
+                const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - EPV + j * EPV;
+                const bool ok = (gz >= 0) & (gz < ld) & (gy >= 0) & (gy < lh) & (gx >= 0) & (gx < lw);
+                const uint4 v = *(const uint4*)(L + (((size_t)b * ld + min(max(gz, 0), ld - 1)) * lh + min(max(gy, 0), lh - 1)) * lw + min(max(gx, 0), lw - EPV));
+                hvv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+                if (LSUM) {
+                    if (want_lsum && ok && (ND == 2 || (z >= 1 && z <= 2 * TD)) && y >= 1 && y <= 2 * TH && t + i * 256 < NVEC) {
+                        const TL* ev = (const TL*)&hvv[i];
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) {
+                            const int x = j * EPV + e - (EPV - 1);                      // column inside the tile's halo row
+                            if (x >= 1 && x <= 2 * TW) lacc += to_f32(from_f32<T>(to_f32(ev[e])));
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < HN; ++i) {
+                const int pos = t + i * 256;
+                const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
+                const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = 2 * o0w - 1 + x;
+                const bool ok = pos < NPOS && gz >= 0 && gz < ld && gy >= 0 && gy < lh && gx >= 0 && gx < lw;
+                hv[i] = ok ? from_f32<T>(to_f32(L[(((size_t)b * ld + gz) * lh + gy) * lw + gx])) : from_f32<T>(0.f);
+                if (LSUM) {
+                    const bool inner = (ND == 2 || (z >= 1 && z <= 2 * TD)) && y >= 1 && y <= 2 * TH && x >= 1 && x <= 2 * TW;
+                    if (want_lsum && ok && inner) lacc += to_f32(hv[i]);
+                }
             }
         }
     };
@@ -542,17 +569,37 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, 
 #pragma unroll
             for (int u = 0; u < NU; ++u) ((uint4*)(s_lds + it * 8))[u] = sv[i][u];       // row-major [pos][32 cs], 16-byte stores
         }
+        if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < HN; ++i) {
-            const int pos = t + i * 256;
-            if (pos < NPOS) {
-                if constexpr (sizeof(T) == 2) {
-                    const int x = pos % IW, row = pos / IW, xi = x >> 1;
-                    T* pl = l_lds + (x & 1) * 2 * LPLANE + row * LPITCH;
-                    pl[xi] = hv[i];                                          // copy 0: slot xi
-                    if (xi > 0) pl[LPLANE + xi - 1] = hv[i];                 // copy 1: shifted left by one slot
-                } else {
-                    l_lds[pos] = hv[i];
+            for (int i = 0; i < HNV; ++i) {
+                const int it = t + i * 256, row = it / NV, j = it % NV;
+                if (it < NVEC) {
+                    const TL* ev = (const TL*)&hvv[i];
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const int x = j * EPV + e - (EPV - 1), xi = x >> 1;
+                        if (x >= 0 && x < IW) {
+                            const T v = from_f32<T>(to_f32(ev[e]));
+                            T* pl = l_lds + (x & 1) * 2 * LPLANE + row * LPITCH;
+                            pl[xi] = v;                                      // copy 0: slot xi
+                            if (xi > 0) pl[LPLANE + xi - 1] = v;             // copy 1: shifted left by one slot
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < HN; ++i) {
+                const int pos = t + i * 256;
+                if (pos < NPOS) {
+                    if constexpr (sizeof(T) == 2) {
+                        const int x = pos % IW, row = pos / IW, xi = x >> 1;
+                        T* pl = l_lds + (x & 1) * 2 * LPLANE + row * LPITCH;
+                        pl[xi] = hv[i];                                          // copy 0: slot xi
+                        if (xi > 0) pl[LPLANE + xi - 1] = hv[i];                 // copy 1: shifted left by one slot
+                    } else {
+                        l_lds[pos] = hv[i];
+                    }
                 }
             }
         }
@@ -675,23 +722,30 @@ int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* b
     const int th = (nd == 3) ? 8 : 16, tw = (nd == 3) ? 8 : 16, td = (nd == 3) ? 4 : 1;
     const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
     dim3 grid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
+    const int epi = CVAE_EPI_OF(act);
     if (dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype)) {          // bf16 output: the 16-byte-load form, image in its own dtype
-#define LAUNCH_DOWN_VEC(TLT, ND)                                                                                                      \
-    hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
+#define LAUNCH_DOWN_VEC_(TLT, ND, EPI)                                                                                                \
+    hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND, EPI>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
                        (int)sw, (int)ld, (int)lh, (int)lw, tiles_h, tiles_w, act)
+#define LAUNCH_DOWN_VEC(TLT, ND)                                                                                                      \
+    do { if (epi == 0) LAUNCH_DOWN_VEC_(TLT, ND, 0); else if (epi == 1) LAUNCH_DOWN_VEC_(TLT, ND, 1); else LAUNCH_DOWN_VEC_(TLT, ND, 2); } while (0)
         if (l_dtype == CVAE_F32) { if (nd == 3) LAUNCH_DOWN_VEC(float, 3); else LAUNCH_DOWN_VEC(float, 2); }
         else { if (nd == 3) LAUNCH_DOWN_VEC(bf16, 3); else LAUNCH_DOWN_VEC(bf16, 2); }
 #undef LAUNCH_DOWN_VEC
+#undef LAUNCH_DOWN_VEC_
         CVAE_CHECK_LAUNCH();
         return CVAE_OK;
     }
     if (l_dtype != dtype) return CVAE_E_UNSUPPORTED;         // the element-wise form reads the image in the compute dtype
-#define LAUNCH_DOWN_C1(T, ND)                                                                                                         \
-    hipLaunchKernelGGL((down_c1_kernel<T, ND, 32>), grid, dim3(256), 0, stream, (const T*)L, w, bias, (const T*)mask, (T*)S, (int)sd, (int)sh, \
+#define LAUNCH_DOWN_C1_(T, ND, EPI)                                                                                                   \
+    hipLaunchKernelGGL((down_c1_kernel<T, ND, 32, EPI>), grid, dim3(256), 0, stream, (const T*)L, w, bias, (const T*)mask, (T*)S, (int)sd, (int)sh, \
                        (int)sw, (int)ld, (int)lh, (int)lw, tiles_h, tiles_w, act)
+#define LAUNCH_DOWN_C1(T, ND)                                                                                                         \
+    do { if (epi == 0) LAUNCH_DOWN_C1_(T, ND, 0); else if (epi == 1) LAUNCH_DOWN_C1_(T, ND, 1); else LAUNCH_DOWN_C1_(T, ND, 2); } while (0)
     if (dtype == CVAE_BF16) { if (nd == 3) LAUNCH_DOWN_C1(bf16, 3); else LAUNCH_DOWN_C1(bf16, 2); }
     else { if (nd == 3) LAUNCH_DOWN_C1(float, 3); else LAUNCH_DOWN_C1(float, 2); }
 #undef LAUNCH_DOWN_C1
+#undef LAUNCH_DOWN_C1_
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
@@ -706,8 +760,11 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
         const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
         if ((int64_t)tiles_d * tiles_h * tiles_w > 0x7fffffff || B > 65535) return CVAE_E_BADSHAPE;
         dim3 mgrid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
-        if (nd == 3) hipLaunchKernelGGL(up_c1_mfma_kernel<3>, mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_h, tiles_w, act);
-        else hipLaunchKernelGGL(up_c1_mfma_kernel<2>, mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_h, tiles_w, act);
+        const int epi = CVAE_EPI_OF(act);
+#define LAUNCH_UP_MFMA(ND, EPI) hipLaunchKernelGGL((up_c1_mfma_kernel<ND, EPI>), mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_h, tiles_w, act)
+        if (nd == 3) { if (epi == 0) LAUNCH_UP_MFMA(3, 0); else if (epi == 1) LAUNCH_UP_MFMA(3, 1); else LAUNCH_UP_MFMA(3, 2); }
+        else { if (epi == 0) LAUNCH_UP_MFMA(2, 0); else if (epi == 1) LAUNCH_UP_MFMA(2, 1); else LAUNCH_UP_MFMA(2, 2); }
+#undef LAUNCH_UP_MFMA
         CVAE_CHECK_LAUNCH();
         return CVAE_OK;
     }
@@ -751,21 +808,23 @@ int cvae_conv_wgrad_c1(const void* S, const void* L, int l_dtype, float* dW, flo
     float* ws = (float*)workspace;
     const int rw = ((nd == 3) ? 64 : 32) + 1;
     float* lsum_ws = dbias_l ? ws + (size_t)2048 * 32 * rw : nullptr;
+    const bool vec = image_vec_ok(L, lw, l_dtype);
 #define LAUNCH_WG_C1(T, ND)                                                                                                           \
     if (lsum_ws) LAUNCH_WG_C1_(T, ND, true); else LAUNCH_WG_C1_(T, ND, false)
+#define LAUNCH_WG_C1__(T, TLT, ND, LS, VEC)                                                                                           \
+    hipLaunchKernelGGL((wgrad_c1_kernel<T, TLT, ND, LS, VEC>), grid, dim3(256), 0, stream, (const T*)S, (const TLT*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
+                       (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split, lsum_ws)
 #define LAUNCH_WG_C1_(T, ND, LS)                                                                                                      \
     do {                                                                                                                              \
-        if (l_dtype == dtype)                                                                                                         \
-            hipLaunchKernelGGL((wgrad_c1_kernel<T, T, ND, LS>), grid, dim3(256), 0, stream, (const T*)S, (const T*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
-                               (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split, lsum_ws);         \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((wgrad_c1_kernel<T, float, ND, LS>), grid, dim3(256), 0, stream, (const T*)S, (const float*)L, ws, dbias != nullptr, (int)B, (int)sd, (int)sh, \
-                               (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, (int)n_split, lsum_ws);         \
+        constexpr bool can_vec = sizeof(T) == 2;                                                                                      \
+        if (l_dtype == dtype) { if (can_vec && vec) LAUNCH_WG_C1__(T, T, ND, LS, can_vec); else LAUNCH_WG_C1__(T, T, ND, LS, false); } \
+        else { if (can_vec && vec) LAUNCH_WG_C1__(T, float, ND, LS, can_vec); else LAUNCH_WG_C1__(T, float, ND, LS, false); }          \
     } while (0)
     if (dtype == CVAE_BF16) { if (nd == 3) { LAUNCH_WG_C1(bf16, 3); } else { LAUNCH_WG_C1(bf16, 2); } }
     else { if (nd == 3) { LAUNCH_WG_C1(float, 3); } else { LAUNCH_WG_C1(float, 2); } }
 #undef LAUNCH_WG_C1
 #undef LAUNCH_WG_C1_
+#undef LAUNCH_WG_C1__
     CVAE_CHECK_LAUNCH();
     const int main_blocks = (32 * rw + 15) / 16;
     dim3 fgrid((unsigned)(main_blocks + (dbias_l ? 1 : 0)), (unsigned)(Cs / 32), 1);

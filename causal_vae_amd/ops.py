@@ -608,7 +608,7 @@ class Linear(torch.autograd.Function):
         N = weight.shape[0]
         y = _empty((M, N), torch.float32, x)
         _t, wp, wb = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 0), x)
-        check(lib.cvae_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()), "linear_fwd")
+        check(L.timed(f"linear_fwd M{M} K{K} N{N}", lib.cvae_linear_fwd, ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()), "linear_fwd")
         ctx.save_for_backward(x, weight, y)
         ctx.cfg = (act, bias is not None)
         return y
@@ -632,13 +632,14 @@ class Linear(torch.autograd.Function):
                 if has_bias and ctx.needs_input_grad[2]:
                     db = _empty((N,), torch.float32, g)
                 _t, wp, wb = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 2), g)
-                check(lib.cvae_linear_bwd_weight(ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, ya, ac, wp, wb, stream()), "linear_bwd_weight")
+                check(L.timed(f"linear_bwd_weight M{M} K{K} N{N}", lib.cvae_linear_bwd_weight, ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, ya, ac, wp, wb, stream()),
+                      "linear_bwd_weight")
             elif has_bias and ctx.needs_input_grad[2]:
                 db = _channel_sum(_act_bwd(g, y, act) if fused else g)
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), torch.float32, g)
             _t2, wp2, wb2 = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 1), g)
-            check(lib.cvae_linear_bwd_data(ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, wp2, wb2, stream()), "linear_bwd_data")
+            check(L.timed(f"linear_bwd_data M{M} K{K} N{N}", lib.cvae_linear_bwd_data, ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, wp2, wb2, stream()), "linear_bwd_data")
         fork.join(dw, db)
         return dx, dw, db, None
 

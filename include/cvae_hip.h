@@ -204,8 +204,9 @@ int cvae_conv_wgrad(const void* S, const void* L, float* dW, float* dbias, int d
  * that the small layers (a few tiles each, launch- and latency-bound alone) run in the shadow of the large ones.  Arrays of `count`
  * entries; dims: count rows of 9 int64 {B, sd, sh, sw, Cs, ld, lh, lw, Cl}; every layer needs its OWN workspace
  * (cvae_conv_wgrad_workspace_bytes) because they run concurrently.  All layers share nd and dtype; Cl != 1, Cs % 64 == 0,
- * Cl % 32 == 0; an entry with dbias_side 1 needs L == 2 S (otherwise use cvae_conv_wgrad for that layer).  Same results, bit for
- * bit, as `count` calls of cvae_conv_wgrad. */
+ * Cl % 32 == 0; an entry with dbias_side 1 needs L == 2 S (otherwise use cvae_conv_wgrad for that layer).  The partial sums of a layer
+ * are split over fewer workgroups than in its own launch (the layers share the chip), so the results equal those of `count` calls of
+ * cvae_conv_wgrad up to the fp32 summation order; they are reproducible bit for bit from run to run (no atomics). */
 int cvae_conv_wgrad_multi(int count, const void* const* S, const void* const* L, float* const* dW, float* const* dbias, const int* dbias_side,
                           void* const* workspace, const size_t* workspace_bytes, const int64_t* dims, int nd, int dtype, void* stream);
 /* out[c] = sum_p x[p, c] over a channels-last [P, C] tensor (bias gradients). out is overwritten.  workspace (optional,
