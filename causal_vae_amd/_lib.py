@@ -9,7 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvae_hip.so")
+# CVAE_HIP_LIB (development only): another build of the same sources, e.g. with different tuning constants (make BUILD=build_x LIB=... EXTRA=-D...),
+# for A/B runs in one GPU session; it must export the same C ABI (checked symbol by symbol below).
+LIB_PATH = os.environ.get("CVAE_HIP_LIB") or os.path.join(_HERE, "libcvae_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY02 = 0, 1, 2, 3

@@ -871,8 +871,17 @@ static bool dims_ok(const cvae_bottleneck_dims* q) {
 static TailDims tail_dims(const cvae_bottleneck_dims* q, int KS, int P) {
     return TailDims{(int)q->M, (int)q->N1, (int)q->N2, (int)q->Z, (int)q->t_dim, (int)q->HM, (int)q->m_dim, KS, P, (int)(q->C * q->OD * q->OH * q->OW / 64)};
 }
-static int fwd_ksplit(int64_t K1) { int ks = (int)(K1 / 4096); return ks < 1 ? 1 : (ks > 8 ? 8 : ks); }
-static int bwd_nsplit(int64_t N1) { int ns = (int)(N1 / 16); return ns < 1 ? 1 : (ns > 32 ? 32 : ns); }
+// Split factors of the two passes over enc_fc.0's weight.  Many light workgroups stream faster than few heavy ones (a 64 KB slice per workgroup
+// ran at 1.9 TB/s, kernels whose workgroups move a few KB each at 5-6 TB/s): the forward slices K into <= 8 parts of >= 2048 columns, the backward
+// gives a workgroup 1024 columns x N1 / 64 rows (the partial d(xcat) slabs it costs are 2 x 8.4 MB, read back by pool_bwd).
+#ifndef CVAE_BN_FWD_SLICE
+#define CVAE_BN_FWD_SLICE 2048
+#endif
+#ifndef CVAE_BN_BWD_ROWS
+#define CVAE_BN_BWD_ROWS 8
+#endif
+static int fwd_ksplit(int64_t K1) { int ks = (int)(K1 / CVAE_BN_FWD_SLICE); return ks < 1 ? 1 : (ks > 8 ? 8 : ks); }
+static int bwd_nsplit(int64_t N1) { int ns = (int)(N1 / CVAE_BN_BWD_ROWS); return ns < 1 ? 1 : (ns > 64 ? 64 : ns); }
 
 extern "C" int cvae_bottleneck_sizes(const cvae_bottleneck_dims* q, int64_t* K1, int64_t* K4, int64_t* fwd_partial_floats, int64_t* dzm_partial_floats,
                                      int64_t* dx_partial_floats) {

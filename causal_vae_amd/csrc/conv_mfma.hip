@@ -1270,7 +1270,10 @@ static int wgrad_multi_t(int count, const void* const* S, const void* const* L, 
         units[i] = tiles[i] * (d[4] / 64) * (d[8] / 32) * ((ND == 3) ? 4 : 1);
         total_units += units[i];
     }
-    const long long per_wg = count > 1 ? (total_units + 1023) / 1024 : 0;          // tiles per workgroup (0: single layer, its own heuristic)
+#ifndef CVAE_WG_MULTI_TARGET
+#define CVAE_WG_MULTI_TARGET 1024
+#endif
+    const long long per_wg = count > 1 ? (total_units + CVAE_WG_MULTI_TARGET - 1) / CVAE_WG_MULTI_TARGET : 0;   // tiles per workgroup (0: single layer, its own heuristic)
     for (int i = 0; i < count; ++i) {
         const int64_t* d = dims + 9 * i;
         ConvGeom g{(int)d[0], (int)d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], (int)d[6], (int)d[7], (int)d[8], 0, 0, 0};

@@ -19,6 +19,13 @@ from ._lib import CvaeError
 from .optim import FusedAdam
 
 
+def _capture(graph, **kw):
+    """torch.cuda.graph(...) in "thread_local" capture-error mode: other threads of the process keep working during the capture.  With a
+    process group alive, RCCL's watchdog thread polls its events (hipEventQuery) at any time; under the default "global" mode such a call
+    from another thread invalidates the capture (hipErrorStreamCaptureUnsupported — seen intermittently with a one-rank RCCL group)."""
+    return torch.cuda.graph(graph, capture_error_mode="thread_local", **kw)
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, batch, loss_fn=None, reducer=None, warmup=3, overlap_exchange=False):
         """batch: (x, m, t) example tensors on the GPU (their storage becomes the static input buffers).
@@ -43,15 +50,15 @@ class GraphedTrainStep:
         if overlap_exchange:
             self._capture_split()
         elif reducer is None or not reducer.active():
-            with torch.cuda.graph(self.g1):
+            with _capture(self.g1):
                 self.out = self._fwd_bwd()
                 self.opt.step()
         else:
-            with torch.cuda.graph(self.g1):
+            with _capture(self.g1):
                 self.out = self._fwd_bwd()
                 reducer.pack()
             self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+            with _capture(self.g2, pool=self.g1.pool()):
                 reducer.unpack()
                 self.opt.step()
 
@@ -79,7 +86,7 @@ class GraphedTrainStep:
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # the warm-up ran on another side stream: harmless here
         cap = torch.cuda.Stream()                            # ONE capture stream: the autograd nodes built in A1 run again in A2
-        with torch.cuda.graph(self.g1, stream=cap):
+        with _capture(self.g1, stream=cap):
             self.opt.zero_grad(set_to_none=True)
             res = self.model.forward_elbo(self.x, self.m, self.t)
             h = self.model._enc_out
@@ -92,7 +99,7 @@ class GraphedTrainStep:
             self.out = tuple(r.detach() for r in res)
             self.red_a.pack()
         self.g1b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1b, pool=self.g1.pool(), stream=cap):
+        with _capture(self.g1b, pool=self.g1.pool(), stream=cap):
             gb = torch.autograd.grad(h, params_b, grad_outputs=gh, allow_unused=True)
             for p, g in zip(params_b, gb):
                 p.grad = g
@@ -100,7 +107,7 @@ class GraphedTrainStep:
         self.model._enc_out = None
         del h, gh, ga, gb, res
         self.g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g2, pool=self.g1.pool(), stream=cap):
+        with _capture(self.g2, pool=self.g1.pool(), stream=cap):
             self.red_a.bind_views()                          # Adam reads the reduced buckets in place: no copy back
             self.red_b.bind_views()
             self.opt.step()
@@ -147,7 +154,7 @@ class GraphedCallable:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _capture(self.graph):
             self.out = fn()
 
     def __call__(self):
