@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # for A/B runs in one GPU session; it must export the same C ABI (checked symbol by symbol below).
 LIB_PATH = os.environ.get("CVAE_HIP_LIB") or os.path.join(_HERE, "libcvae_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY02 = 0, 1, 2, 3
 _ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "leaky02": ACT_LEAKY02}
 
@@ -46,6 +46,9 @@ SIGNATURES = {
     "cvae_conv_data_workspace_bytes": [_i64] * 9 + [_i, _i],
     "cvae_conv_down": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
     "cvae_conv_up": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
+    "cvae_quantize_fp8": [_p, _i, _p, _i64, _f, _p],
+    "cvae_conv_pack_weight_fp8": [_p, _p, _i64, _i64, _i, _i, _f, _p],
+    "cvae_conv_up_fp8": [_p, _p, _p, _p, _i, _f, _f] + [_i64] * 9 + [_i, _i, _p],
     "cvae_conv_image_supported": [_p, _i64, _i, _i],
     "cvae_conv_down_image": [_p, _i, _p, _p, _p, _p] + [_i64] * 8 + [_i, _i, _i, _p],
     "cvae_conv_wgrad_image": [_p, _p, _i, _p, _p, _p, _sz] + [_i64] * 8 + [_i, _i, _p],

@@ -67,12 +67,24 @@ class CausalBioVAE(nn.Module):
         x_feat = self.dec_input(z_m_input).view(-1, 256, *([4] * self._ND))
         return self.dec_conv.forward_cl(x_feat)              # channels-last [B, D, H, W, C], compute dtype
 
-    def decode(self, z, m_hat, size=None):
+    def calibrate_fp8_decoder(self, z, m_hat, headroom=1.0):
+        """Scales + fp8 weight panels for decode(..., fp8_plan=...) from one bf16 pass over calibration rows (DeconvStack.calibrate_fp8)."""
+        with torch.no_grad():
+            x_feat = self.dec_input(ops.cat([z, m_hat])).view(-1, 256, *([4] * self._ND))
+            return self.dec_conv.calibrate_fp8(ops.ToChannelsLast.apply(x_feat, torch.bfloat16), headroom)
+
+    def decode(self, z, m_hat, size=None, fp8_plan=None):
         """Decoder half only: [z, m_hat] -> dec_input -> dec_conv -> resize to `size` (default: the native 64^nd).
         Rows are independent, so a whole counterfactual sweep (abduct z once, stack every intervened m') decodes in ONE call
-        instead of the reference's per-value loop (vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:77-99)."""
+        instead of the reference's per-value loop (vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:77-99).
+        fp8_plan (from calibrate_fp8_decoder; inference only): the ConvTranspose layers with C_out > 1 run on fp8 (e4m3) operands."""
         nd = self._ND
-        out_cl = self.decode_cl(ops.cat([z, m_hat]))
+        if fp8_plan is not None:
+            with torch.no_grad():
+                x_feat = self.dec_input(ops.cat([z, m_hat])).view(-1, 256, *([4] * nd))
+                out_cl = self.dec_conv.forward_fp8(ops.ToChannelsLast.apply(x_feat, torch.bfloat16), fp8_plan)
+        else:
+            out_cl = self.decode_cl(ops.cat([z, m_hat]))
         native = tuple(out_cl.shape[1:4])
         size = native if size is None else (tuple(size) if nd == 3 else (1,) + tuple(size))
         rec = ops.Cast.apply(out_cl, torch.float32) if size == native else ops.UpsampleLinear.apply(out_cl, size)

@@ -21,12 +21,13 @@ def sweep_inputs(z, m, features, values):
 
 
 @torch.no_grad()
-def batched_counterfactual(model, z, m, features, values, size=None):
+def batched_counterfactual(model, z, m, features, values, size=None, fp8_plan=None):
     """Decode every intervention do(m_f = v) in one call.  Works with CausalBioVAE / CausalBioVAE3D (decode(z, m, size)) and
-    CausalMorphVAE12 (decode(m, z)).  Returns [B, n_features, n_values, C, (D,) H, W]."""
+    CausalMorphVAE12 (decode(m, z)).  Returns [B, n_features, n_values, C, (D,) H, W].  fp8_plan (CausalBioVAE only, from
+    model.calibrate_fp8_decoder): the fp8 (e4m3) conv path of BASELINE.json configs[4]."""
     z_rep, m_cf = sweep_inputs(z, m, features, values)
     if hasattr(model, "dec_input"):
-        out = model.decode(z_rep, m_cf, size)
+        out = model.decode(z_rep, m_cf, size, fp8_plan=fp8_plan) if fp8_plan is not None else model.decode(z_rep, m_cf, size)
     else:
         out = model.decode(m_cf, z_rep)
     return out.view(z.shape[0], len(features), len(values), *out.shape[1:])

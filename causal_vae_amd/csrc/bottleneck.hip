@@ -871,14 +871,14 @@ static bool dims_ok(const cvae_bottleneck_dims* q) {
 static TailDims tail_dims(const cvae_bottleneck_dims* q, int KS, int P) {
     return TailDims{(int)q->M, (int)q->N1, (int)q->N2, (int)q->Z, (int)q->t_dim, (int)q->HM, (int)q->m_dim, KS, P, (int)(q->C * q->OD * q->OH * q->OW / 64)};
 }
-// Split factors of the two passes over enc_fc.0's weight.  Many light workgroups stream faster than few heavy ones (a 64 KB slice per workgroup
-// ran at 1.9 TB/s, kernels whose workgroups move a few KB each at 5-6 TB/s): the forward slices K into <= 8 parts of >= 2048 columns, the backward
-// gives a workgroup 1024 columns x N1 / 64 rows (the partial d(xcat) slabs it costs are 2 x 8.4 MB, read back by pool_bwd).
+// Split factors of the two passes over enc_fc.0's weight: the forward slices K into parts of >= 4096 columns (<= 8), the backward gives a
+// workgroup 1024 columns x 16 rows (32 partial d(xcat) slabs).  Measured in the step (A/B of two builds in one session): halving both
+// (2048 columns / 8 rows: twice the workgroups, half the bytes each) costs +10 us per step, the extra partial slabs outweigh the parallelism.
 #ifndef CVAE_BN_FWD_SLICE
-#define CVAE_BN_FWD_SLICE 2048
+#define CVAE_BN_FWD_SLICE 4096
 #endif
 #ifndef CVAE_BN_BWD_ROWS
-#define CVAE_BN_BWD_ROWS 8
+#define CVAE_BN_BWD_ROWS 16
 #endif
 static int fwd_ksplit(int64_t K1) { int ks = (int)(K1 / CVAE_BN_FWD_SLICE); return ks < 1 ? 1 : (ks > 8 ? 8 : ks); }
 static int bwd_nsplit(int64_t N1) { int ns = (int)(N1 / CVAE_BN_BWD_ROWS); return ns < 1 ? 1 : (ns > 64 ? 64 : ns); }

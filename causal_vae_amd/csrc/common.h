@@ -25,11 +25,21 @@ static inline int cvae_grid_1d(int64_t n, int block, int max_blocks = 256 * 8) {
     return (int)g;
 }
 
+// OCP fp8 e4m3 ("e4m3fn": max 448, no infinities) — the gfx950 format (MI300X's fnuz encoding is a different one).  One byte of storage;
+// values carry a per-tensor scale that lives outside the tensor (the inference-only decode path, csrc/conv_mfma.hip).
+struct fp8 { unsigned char b; };
+#define CVAE_FP8_MAX 448.f
+
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+__device__ __forceinline__ float to_f32(fp8 x) { return __builtin_amdgcn_cvt_f32_fp8((int)x.b, 0); }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+template <> __device__ __forceinline__ fp8 from_f32<fp8>(float x) {                       // saturating (the hardware conversion would give NaN past 448)
+    x = fminf(fmaxf(x, -CVAE_FP8_MAX), CVAE_FP8_MAX);
+    return fp8{(unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff)};
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {

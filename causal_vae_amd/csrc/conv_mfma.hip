@@ -49,11 +49,16 @@ struct ConvGeom {
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { bf16x8 v; };
 template <> struct Frag<float> { float v[8]; };
+template <> struct Frag<fp8> { long v; };
 
 __device__ __forceinline__ void lds_load(Frag<bf16>& f, const char* p) { f.v = *(const bf16x8*)p; }
 __device__ __forceinline__ void lds_load(Frag<float>& f, const char* p) {
     const float4 a = *(const float4*)p, b = *(const float4*)(p + 16);
     f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+__device__ __forceinline__ void lds_load(Frag<fp8>& f, const char* p) { f.v = *(const long*)p; }
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<fp8>& a, const Frag<fp8>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a.v, b.v, acc, 0, 0, 0);      // non-scaled fp8: the bf16 instruction's shape and rate, half the operand bytes
 }
 // lane (r = lane & 31, h = lane >> 5) holds elements k = 8h .. 8h+7 of its row/column in both precisions
 __device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
@@ -94,35 +99,41 @@ template <> struct HaloPitch<3, true> { static constexpr int RS = 12; };
 template <> struct HaloPitch<2, false> { static constexpr int RS = 18; };
 template <> struct HaloPitch<2, true> { static constexpr int RS = 20; };
 
-// One 8-element fragment piece (16 B bf16 / 32 B fp32) in flight between a global load and its LDS store.  Staging
+// One 8-element fragment piece (8 B fp8 / 16 B bf16 / 32 B fp32) in flight between a global load and its LDS store.  Staging
 // is always written as "issue ALL loads of a tile, then store them": the loads overlap each other (and, for the weight
 // panels, the MFMA work placed between the two halves) instead of paying one memory latency per piece.
-template <typename T> struct Piece { uint4 v[(8 * sizeof(T)) / 16]; };
+template <typename T> struct PieceW { using type = uint4; static constexpr int N = (8 * sizeof(T)) / 16; };
+template <> struct PieceW<fp8> { using type = uint2; static constexpr int N = 1; };
+__device__ __forceinline__ uint4 piece_sel(bool ok, uint4 v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); }
+__device__ __forceinline__ uint2 piece_sel(bool ok, uint2 v) { return make_uint2(ok ? v.x : 0u, ok ? v.y : 0u); }
+template <typename T> struct Piece { typename PieceW<T>::type v[PieceW<T>::N]; };
 template <typename T>
 __device__ __forceinline__ void piece_load(Piece<T>& p, const T* src, bool ok) {
+    using W = typename PieceW<T>::type;
 #pragma unroll
-    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) {
+    for (int u = 0; u < PieceW<T>::N; ++u) {
         // `src` is always a readable address (callers pass the tensor base when !ok): load unconditionally and select, so the
         // compiler emits one straight-line global_load per piece instead of an exec-masked branch around each of them
-        const uint4 v = ((const uint4*)src)[u];
-        p.v[u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+        p.v[u] = piece_sel(ok, ((const W*)src)[u]);
     }
 }
 template <typename T>
 __device__ __forceinline__ void piece_load_raw(Piece<T>& p, const T* src) {
+    using W = typename PieceW<T>::type;
 #pragma unroll
-    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) p.v[u] = ((const uint4*)src)[u];
+    for (int u = 0; u < PieceW<T>::N; ++u) p.v[u] = ((const W*)src)[u];
 }
 template <typename T>
 __device__ __forceinline__ void piece_store_sel(const Piece<T>& p, bool ok, char* dst) {     // zero when !ok (decided at store time)
+    using W = typename PieceW<T>::type;
 #pragma unroll
-    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u)
-        ((uint4*)dst)[u] = make_uint4(ok ? p.v[u].x : 0u, ok ? p.v[u].y : 0u, ok ? p.v[u].z : 0u, ok ? p.v[u].w : 0u);
+    for (int u = 0; u < PieceW<T>::N; ++u) ((W*)dst)[u] = piece_sel(ok, p.v[u]);
 }
 template <typename T>
 __device__ __forceinline__ void piece_store(const Piece<T>& p, char* dst) {
+    using W = typename PieceW<T>::type;
 #pragma unroll
-    for (int u = 0; u < (int)((8 * sizeof(T)) / 16); ++u) ((uint4*)dst)[u] = p.v[u];
+    for (int u = 0; u < PieceW<T>::N; ++u) ((W*)dst)[u] = p.v[u];
 }
 
 // XCD-aware block -> tile map (cdna_hip_programming.md T1, bijective form): blocks b and b+8 share an XCD (and its L2),
@@ -136,10 +147,13 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // EPI: 0 = bias only, 1 = bias + ReLU, 2 = generic activation code
 // KH: 16-channel k-steps per staged halo (1, or 2 for `up` in bf16: its halo box is small enough to hold 32 channels, which halves
 // the stage / barrier count per MFMA and fetches 64 contiguous bytes per position instead of 32).
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1>
+// TO: output (and mask) dtype, = T except on the fp8 inference path, where an fp8 x fp8 product leaves as fp8 (next fp8 layer) or bf16
+// (the layer in front of the single-channel kernel): out = act(acc * acc_scale + bias) * out_scale, acc_scale = s_in * s_w the product of the
+// operands' per-tensor scales, out_scale = 1 / s_out.
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T>
 __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
-                                                                  const T* __restrict__ mask, T* __restrict__ out, ConvGeom g, int act,
-                                                                  float* __restrict__ ws, int ksplit) {
+                                                                  const TO* __restrict__ mask, TO* __restrict__ out, ConvGeom g, int act,
+                                                                  float* __restrict__ ws, int ksplit, float acc_scale, float out_scale) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
@@ -378,6 +392,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
+                if constexpr (sizeof(T) == 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[j][q] *= acc_scale;
+                }
                 if (bias) {
                     const float4 b0 = *(const float4*)(bias + c), b1 = *(const float4*)(bias + c + 4);
                     v[j][0] += b0.x; v[j][1] += b0.y; v[j][2] += b0.z; v[j][3] += b0.w;
@@ -390,18 +408,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
                 }
                 if (!ok) continue;
                 if (mask) {
-                    Piece<T> mp;
-                    piece_load<T>(mp, mask + pidx + c, true);
-                    const T* mv = (const T*)&mp;
+                    Piece<TO> mp;
+                    piece_load<TO>(mp, mask + pidx + c, true);
+                    const TO* mv = (const TO*)&mp;
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                         if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
                 }
-                Piece<T> op;
-                T* ov = (T*)&op;
+                Piece<TO> op;
+                TO* ov = (TO*)&op;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ov[q] = from_f32<T>(v[j][q]);
-                piece_store<T>(op, (char*)(out + pidx + c));
+                for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(sizeof(T) == 1 ? v[j][q] * out_scale : v[j][q]);
+                piece_store<TO>(op, (char*)(out + pidx + c));
             }
         }
     }
@@ -455,9 +473,9 @@ static int pick_ksplit(bool up, long long nwg, int nchunks) {
     return best;
 }
 
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1>
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T>
 int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
-                    size_t workspace_bytes, hipStream_t stream) {
+                    size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
     constexpr int ID = (ND == 3) ? (UP ? TL::TD + 1 : 2 * TL::TD + 2) : 1;
@@ -466,7 +484,7 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     static_assert(IW >= 0, "");
     constexpr size_t LDS = (size_t)2 * KH * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (size_t)2 * 4 * KH * 2 * BN * FB;
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
-    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH>;
+    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
@@ -481,12 +499,14 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     const int64_t total = (int64_t)g.B * (UP ? (int64_t)g.ld * g.lh * g.lw : (int64_t)g.sd * g.sh * g.sw) * Cout;
     int ksplit = pick_ksplit(UP, tiles * gy * g.B, Cin / (16 * KH));
     if (!workspace || workspace_bytes < (size_t)ksplit * total * sizeof(float)) ksplit = 1;     // no (or too small a) workspace: unsplit
+    if (sizeof(T) == 1) ksplit = 1;                          // fp8: forward `up` only, never split
     gy *= ksplit;
     if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
     dim3 grid((unsigned)tiles, (unsigned)gy, (unsigned)g.B);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const T*)mask, (T*)out, g, act, (float*)workspace, ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const TO*)mask, (TO*)out, g, act, (float*)workspace, ksplit,
+                       acc_scale, out_scale);
     CVAE_CHECK_LAUNCH();
-    if (ksplit > 1) {
+    if constexpr (sizeof(T) != 1) if (ksplit > 1) {
         hipLaunchKernelGGL((conv_splitk_finish_kernel<T, EPI>), dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, bias,
                            (const T*)mask, (T*)out, total, Cout, ksplit, act);
         CVAE_CHECK_LAUNCH();
@@ -523,7 +543,7 @@ size_t data_workspace_bytes(const ConvGeom& g) {
 
 // ---------------------------------------------------------------------------------------------- weight packing
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cs, int Cl, int taps, int for_up) {
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cs, int Cl, int taps, int for_up, float mul = 1.f) {
     const int64_t n = (int64_t)Cs * Cl * taps;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         // i enumerates the OUTPUT so writes are contiguous
@@ -532,7 +552,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
         int cs, cl, tap;
         if (!for_up) { cs = (int)(rr % Cs); rr /= Cs; const int ch = (int)(rr % (Cl / 16)); tap = (int)(rr / (Cl / 16)); cl = ch * 16 + e; }
         else { cl = (int)(rr % Cl); rr /= Cl; const int ch = (int)(rr % (Cs / 16)); tap = (int)(rr / (Cs / 16)); cs = ch * 16 + e; }
-        out[i] = from_f32<T>(w[((int64_t)cs * Cl + cl) * taps + tap]);
+        out[i] = from_f32<T>(sizeof(T) == 1 ? w[((int64_t)cs * Cl + cl) * taps + tap] * mul : w[((int64_t)cs * Cl + cl) * taps + tap]);
     }
 }
 
@@ -1271,7 +1291,7 @@ static int wgrad_multi_t(int count, const void* const* S, const void* const* L, 
         total_units += units[i];
     }
 #ifndef CVAE_WG_MULTI_TARGET
-#define CVAE_WG_MULTI_TARGET 1024
+#define CVAE_WG_MULTI_TARGET 512
 #endif
     const long long per_wg = count > 1 ? (total_units + CVAE_WG_MULTI_TARGET - 1) / CVAE_WG_MULTI_TARGET : 0;   // tiles per workgroup (0: single layer, its own heuristic)
     for (int i = 0; i < count; ++i) {
@@ -1310,4 +1330,59 @@ extern "C" int cvae_conv_wgrad_multi(int count, const void* const* S, const void
     if (dtype == CVAE_BF16)
         return nd == 3 ? wgrad_multi_t<bf16, 3>(count, S, L, dW, dbias, dbias_side, workspace, dims, st) : wgrad_multi_t<bf16, 2>(count, S, L, dW, dbias, dbias_side, workspace, dims, st);
     return nd == 3 ? wgrad_multi_t<float, 3>(count, S, L, dW, dbias, dbias_side, workspace, dims, st) : wgrad_multi_t<float, 2>(count, S, L, dW, dbias, dbias_side, workspace, dims, st);
+}
+
+// ---------------------------------------------------------------------------------------------- fp8 (e4m3) inference path
+// The decoder-only counterfactual sweep (BASELINE.json configs[4]) decodes hundreds of stacked rows with frozen weights:
+// the ConvTranspose layers with C_in >= 32 and C_out > 1 run with fp8 operands (per-tensor scales from a calibration pass, fp32
+// accumulate) on v_mfma_f32_32x32x16_fp8_fp8 — the bf16 instruction's shape and rate, half the LDS / L2 bytes per operand, which is what
+// bounds these kernels.  Same tiles, same halo staging, same epilogue as the bf16 kernel (conv_data_kernel<fp8, .., TO>).
+__global__ void quantize_fp8_kernel(const void* __restrict__ src, int src_dtype, fp8* __restrict__ dst, int64_t n, float inv_scale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = src_dtype == CVAE_BF16 ? to_f32(((const bf16*)src)[i]) : ((const float*)src)[i];
+        dst[i] = from_f32<fp8>(v * inv_scale);
+    }
+}
+extern "C" int cvae_quantize_fp8(const void* src, int src_dtype, void* dst, int64_t n, float inv_scale, void* stream) {
+    if (n < 0 || !(inv_scale > 0.f)) return CVAE_E_BADSHAPE;
+    if (src_dtype != CVAE_F32 && src_dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (n == 0) return CVAE_OK;
+    if (!src || !dst) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, (fp8*)dst, n, inv_scale);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+extern "C" int cvae_conv_pack_weight_fp8(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, float inv_scale, void* stream) {
+    if ((nd != 2 && nd != 3) || Cs <= 0 || Cl <= 0 || !(inv_scale > 0.f)) return CVAE_E_BADSHAPE;
+    if ((!for_up && Cl % 16) || (for_up && Cs % 16)) return CVAE_E_UNSUPPORTED;
+    if (!w || !packed) return CVAE_E_NULLPTR;
+    const int taps = (nd == 3) ? 64 : 16;
+    const int64_t n = Cs * Cl * taps;
+    hipLaunchKernelGGL(pack_weight_kernel<fp8>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (fp8*)packed, (int)Cs, (int)Cl, taps, for_up, inv_scale);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+template <int ND, typename TO>
+static int conv_up_fp8_t(const void* S, const void* w, const float* bias, void* L, ConvGeom g, int act, float acc_scale, float out_scale, hipStream_t st) {
+    const bool wide = (g.Cl % 64) == 0;
+#define UPF8(WM, WN, EPI) launch_data_epi<fp8, ND, true, WM, WN, 2, 1, EPI, 1, TO>(S, w, bias, nullptr, L, g, act, nullptr, 0, st, acc_scale, out_scale)
+    if (wide) { if (act == CVAE_ACT_NONE) return UPF8(2, 2, 0); if (act == CVAE_ACT_RELU) return UPF8(2, 2, 1); return UPF8(2, 2, 2); }
+    if (act == CVAE_ACT_NONE) return UPF8(4, 1, 0);
+    if (act == CVAE_ACT_RELU) return UPF8(4, 1, 1);
+    return UPF8(4, 1, 2);
+#undef UPF8
+}
+extern "C" int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
+                                int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
+                                void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || !(acc_scale > 0.f)) return CVAE_E_BADSHAPE;
+    if (out_dtype != CVAE_FP8 && out_dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (out_dtype == CVAE_FP8 && !(out_inv_scale > 0.f)) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!S || !w || !L) return CVAE_E_NULLPTR;
+    if (Cl == 1 || Cs % 16 || Cl % 32) return CVAE_E_UNSUPPORTED;
+    GEOM_INIT();
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == CVAE_FP8) return nd == 3 ? conv_up_fp8_t<3, fp8>(S, w, bias, L, g, act, acc_scale, out_inv_scale, st) : conv_up_fp8_t<2, fp8>(S, w, bias, L, g, act, acc_scale, out_inv_scale, st);
+    return nd == 3 ? conv_up_fp8_t<3, bf16>(S, w, bias, L, g, act, acc_scale, 1.f, st) : conv_up_fp8_t<2, bf16>(S, w, bias, L, g, act, acc_scale, 1.f, st);
 }

@@ -237,6 +237,50 @@ class DeconvStack(nn.Sequential):
         require_gpu(h)
         return ops.FromChannelsLast.apply(self.forward_cl(h), h.dim() - 2)
 
+    # ---- fp8 (e4m3) inference: the batched counterfactual decode ----
+    def calibrate_fp8(self, x_cl, headroom=1.0):
+        """Per-tensor scales and fp8 weight panels for the ConvTranspose layers with more than one output channel, from ONE bf16 pass over the
+        calibration rows x_cl [B, .., C] (channels-last, any float dtype): scale = headroom * amax / 448 for every fp8 layer's input and weight.
+        Returns the plan forward_fp8 takes.  Host syncs here (amax readbacks): call it once, outside any timed or captured region."""
+        mods = list(self)
+        convs = [(i, m) for i, m in enumerate(mods) if isinstance(m, _ConvBase)]
+        nd = convs[0][1]._nd
+        plan, x = [], x_cl.to(torch.bfloat16)
+        with torch.no_grad():
+            for j, (i, conv) in enumerate(convs):
+                act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
+                if conv.weight.shape[1] > 1 and conv.weight.shape[0] % 16 == 0 and conv.weight.shape[1] % 32 == 0:
+                    sx = max(float(x.float().abs().max()), 1e-12) * headroom / ops.FP8_MAX
+                    sw = max(float(conv.weight.abs().max()), 1e-12) / ops.FP8_MAX
+                    plan.append(dict(index=i, act=act, sx=sx, sw=sw, wq=ops.pack_weight_fp8(conv.weight.detach(), nd, True, sw)))
+                else:
+                    plan.append(dict(index=i, act=act, sx=None))
+                x = ops.ConvUp.apply(x, conv.weight.detach(), conv.bias.detach() if conv.bias is not None else None, nd, act, False, False, None)
+        return plan
+
+    def forward_fp8(self, x_cl, plan):
+        """The deconv chain on fp8 operands where the plan has scales (bf16 for the remaining layers, i.e. the single-channel output layer):
+        activations travel as fp8 codes between consecutive fp8 layers.  Inference only (no autograd)."""
+        mods = list(self)
+        nd = mods[plan[0]["index"]]._nd
+        with torch.no_grad():
+            x, x_is_q = x_cl, False
+            for j, e in enumerate(plan):
+                conv = mods[e["index"]]
+                bias = conv.bias.detach() if conv.bias is not None else None
+                if e["sx"] is None:
+                    if x_is_q:
+                        raise CvaeError("forward_fp8: an fp8 layer cannot feed a non-fp8 layer without its output scale")
+                    x = ops.ConvUp.apply(x.to(torch.bfloat16), conv.weight.detach(), bias, nd, e["act"], False, False, None)
+                    continue
+                if not x_is_q:
+                    x = ops.quantize_fp8(x, e["sx"])
+                nxt = plan[j + 1] if j + 1 < len(plan) else None
+                out_scale = nxt["sx"] if (nxt is not None and nxt["sx"] is not None) else None
+                x = ops.conv_up_fp8(x, e["wq"], bias, conv.weight.shape[1], nd, e["act"], e["sx"] * e["sw"], out_scale)
+                x_is_q = out_scale is not None
+        return x
+
 
 class MLP(nn.Sequential):
     """Sequential of Linear / BatchNorm1d / activation layers; Linear + activation pairs run as one kernel."""

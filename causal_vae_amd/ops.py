@@ -520,6 +520,38 @@ class ConvUp(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------ fp8 inference (decode only)
+FP8_MAX = 448.0      # OCP e4m3
+
+
+def quantize_fp8(x, scale):
+    """fp8 (e4m3) codes of x / scale as a uint8 tensor of x's shape (x: fp32 or bf16, contiguous)."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib.cvae_quantize_fp8(ptr(x), L.dtype_code(x.dtype), ptr(q), x.numel(), 1.0 / float(scale), stream()), "quantize_fp8")
+    return q
+
+
+def pack_weight_fp8(w, nd, for_up, scale):
+    """fp32 [Cs][Cl][k..] -> the MFMA operand panels of pack_weight as fp8 codes of w / scale."""
+    w = w.contiguous()
+    out = torch.empty(w.numel(), dtype=torch.uint8, device=w.device)
+    check(lib.cvae_conv_pack_weight_fp8(ptr(w), ptr(out), w.shape[0], w.shape[1], nd, int(for_up), 1.0 / float(scale), stream()), "conv_pack_weight_fp8")
+    return out
+
+
+def conv_up_fp8(Sq, wq, bias, Cl, nd, act, acc_scale, out_scale=None):
+    """nn.ConvTranspose{2,3}d(k4, s2, p1) + bias + activation on fp8 operands (forward only).  Sq: uint8 codes [B, sd, sh, sw, Cs]; result bf16
+    (out_scale None) or fp8 codes of result / out_scale."""
+    B, sd, sh, sw, Cs = _cl_dims(Sq)
+    ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
+    Lt = torch.empty((B, ld, lh, lw, Cl), dtype=torch.bfloat16 if out_scale is None else torch.uint8, device=Sq.device)
+    check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up_fp8, ptr(Sq), ptr(wq), ptr(bias), ptr(Lt), L.BF16 if out_scale is None else L.FP8,
+                  float(acc_scale), 0.0 if out_scale is None else 1.0 / float(out_scale), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.act_code(act), stream()), "conv_up_fp8")
+    return Lt
+
+
 class Activation(torch.autograd.Function):
     """Stand-alone ReLU / Sigmoid / LeakyReLU(0.2) (used where no producer kernel can fuse it, e.g. after BatchNorm1d)."""
 

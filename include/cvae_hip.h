@@ -51,6 +51,7 @@ extern "C" {
 
 #define CVAE_F32  0
 #define CVAE_BF16 1
+#define CVAE_FP8  2          /* OCP e4m3 with a per-tensor scale kept by the caller: inference-only entry points (cvae_conv_up_fp8 ...) */
 
 #define CVAE_ACT_NONE    0
 #define CVAE_ACT_RELU    1
@@ -112,6 +113,19 @@ int cvae_conv_down_image(const void* L, int l_dtype, const float* w, const float
                          int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, void* stream);
 int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                           int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, void* stream);
+/* ---- fp8 (OCP e4m3) inference path of the ConvTranspose layers: the batched counterfactual decode (BASELINE.json configs[4]; replaces the
+ * per-value decode loop of vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:77-99) ----
+ * A tensor x is held as fp8 codes q with a per-tensor scale s kept by the caller: x ~ s * q, s = amax(x) / 448 from a calibration pass.
+ *   cvae_quantize_fp8          dst[i] = fp8(src[i] * inv_scale)               (src fp32 or bf16; saturating)
+ *   cvae_conv_pack_weight_fp8  cvae_conv_pack_weight with fp8 codes fp8(w * inv_scale)
+ *   cvae_conv_up_fp8           L = act(scatter(S_q, w_q) * acc_scale + bias) with acc_scale = s_S * s_w, fp32 accumulate on
+ *                              v_mfma_f32_32x32x16_fp8_fp8; L written as bf16 (out_dtype CVAE_BF16) or as fp8 codes fp8(L * out_inv_scale)
+ *                              (out_dtype CVAE_FP8) for the next fp8 layer.  Cs % 16 == 0, Cl % 32 == 0, Cl > 1; forward only. */
+int cvae_quantize_fp8(const void* src, int src_dtype, void* dst, int64_t n, float inv_scale, void* stream);
+int cvae_conv_pack_weight_fp8(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, float inv_scale, void* stream);
+int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
+                     int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
+                     void* stream);
 /* ---- Exact-2x linear resize (decoder output d x h x w, one channel -> 2d x 2h x 2w; D == d == 1 for 2D) fused with the ELBO ----
  * causal_cascade/models.py:84-87 + train.py:5-17: the resized volume is recomputed from the small tensor wherever it is needed
  * instead of being written and re-read (csrc/recon_loss.hip).  cvae_up2x_supported: 1 when the shapes qualify (w % 4 == 0). */
