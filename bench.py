@@ -433,7 +433,8 @@ def run_decode(args, rank, world, dev):
     from causal_vae_amd import _lib
     from causal_vae_amd.causal_cascade import CausalBioVAE3D
     from causal_vae_amd.counterfactual import sweep_inputs
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    fp8 = args.dtype == "fp8"
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     torch.manual_seed(42)
     model = CausalBioVAE3D().to(dev).eval().set_compute_dtype(dtype)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -441,10 +442,17 @@ def run_decode(args, rank, world, dev):
     z_rep, m_cf = sweep_inputs(z, m, list(range(12)), [0.0, 0.25, 0.5, 0.75, 1.0])      # 60 decodes per sample
     rows = z_rep.shape[0]
     size = None if args.decode_native else (args.size,) * 3
+    plan, fp8_err = None, None
+    if fp8:                                                   # static per-tensor scales from one bf16 pass over the first sample's 60 rows
+        plan = model.calibrate_fp8_decoder(z_rep[:60], m_cf[:60])
+        with torch.no_grad():
+            a, b = model.decode(z_rep[-60:], m_cf[-60:], None, fp8_plan=plan), model.decode(z_rep[-60:], m_cf[-60:], None)
+            fp8_err = float(((a - b).norm() / b.norm()).item())
+        del a, b
 
     def step():
         with torch.no_grad():
-            return (model.decode(z_rep, m_cf, size),)
+            return (model.decode(z_rep, m_cf, size, fp8_plan=plan),)
     reps, out = timed_region(step, args.steps, max(args.warmup, 1), world, dev, args.min_timed_s)
     shape = tuple(out[0].shape)
     del out
@@ -466,9 +474,13 @@ def run_decode(args, rank, world, dev):
                      "rows_per_rank": rows, "output_shape": list(shape)}
     fl = 2.0 * rows * 64 * (4 ** 3 * 256 * 128 + 8 ** 3 * 128 * 64 + 16 ** 3 * 64 * 32 + 32 ** 3 * 32 * 1) + 2.0 * rows * 76 * 16384
     A = rows * (8 ** 3 * 128 + 16 ** 3 * 64 + 32 ** 3 * 32 + 64 ** 3)
-    esz = 2 if args.dtype == "bf16" else 4
-    byt = 2 * A * esz + rows * 16384 * esz + (rows * args.size ** 3 * 4 if size is not None else rows * 64 ** 3 * 4)
-    roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, res["ms_per_step"], fl, byt)
+    esz = {"bf16": 2, "f32": 4, "fp8": 1}[args.dtype]
+    A_io = 2 * A * esz if not fp8 else rows * (16384 * 2 + 16384 + 2 * (8 ** 3 * 128 + 16 ** 3 * 64) + 32 ** 3 * 32 * (1 + 2) + 64 ** 3 * 2)   # fp8 codes between fp8 layers; bf16 into the 1-channel layer
+    byt = A_io + rows * 16384 * esz + (rows * args.size ** 3 * 4 if size is not None else rows * 64 ** 3 * 4)
+    if fp8:
+        res["fp8"] = {"format": "OCP e4m3, static per-tensor scales (calibrated on the first sample's 60 rows), fp32 accumulate; dec_input linear and the 1-channel output "
+                                "layer stay bf16", "rel_l2_vs_bf16_decode_on_last_60_rows": fp8_err}
+    roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, "bf16" if fp8 else args.dtype, res["ms_per_step"], fl, byt)
     res["roofline"], res["families"], res["kernels"] = roof, fams, kernels
     return res
 
@@ -481,7 +493,7 @@ def main():
     ap.add_argument("--workload", default="vol128", choices=["vol128", "vol64-f32", "mnist", "decode", "vol128-vessel"])
     ap.add_argument("--size", type=int, default=None, help="volume edge (default: the workload's)")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8"], help="fp8: decode workload only (e4m3 conv operands)")
     ap.add_argument("--min-timed-s", type=float, default=0.2, help="repeat the K-step timed region until this much has been timed; the median repetition is reported")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = the box's CPU share: min(affinity, 16 per GPU))")
@@ -503,6 +515,8 @@ def main():
     args.size = args.size or dsz
     args.batch = args.batch or dB
     args.dtype = args.dtype or ddt
+    if args.dtype == "fp8" and args.workload != "decode":
+        raise SystemExit("--dtype fp8 is the inference decode path only (--workload decode)")
 
     from causal_vae_amd import ops as _ops
     from causal_vae_amd.parallel import init_distributed

@@ -1058,7 +1058,7 @@ extern "C" size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, 
 
 extern "C" int cvae_conv_pack_weight(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, int dtype, void* stream) {
     if ((nd != 2 && nd != 3) || Cs <= 0 || Cl <= 0) return CVAE_E_BADSHAPE;
-    if ((!for_up && Cl % 16) || (for_up && Cs % 16)) return CVAE_E_UNSUPPORTED;
+    if ((!for_up && Cl % 16) || (for_up && (Cs % 16 || Cl % 32))) return CVAE_E_UNSUPPORTED;      // what cvae_conv_up_fp8 accepts
     if (!w || !packed) return CVAE_E_NULLPTR;
     const int taps = (nd == 3) ? 64 : 16;
     const int64_t n = Cs * Cl * taps;
@@ -1354,7 +1354,7 @@ extern "C" int cvae_quantize_fp8(const void* src, int src_dtype, void* dst, int6
 }
 extern "C" int cvae_conv_pack_weight_fp8(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, float inv_scale, void* stream) {
     if ((nd != 2 && nd != 3) || Cs <= 0 || Cl <= 0 || !(inv_scale > 0.f)) return CVAE_E_BADSHAPE;
-    if ((!for_up && Cl % 16) || (for_up && Cs % 16)) return CVAE_E_UNSUPPORTED;
+    if ((!for_up && Cl % 16) || (for_up && (Cs % 16 || Cl % 32))) return CVAE_E_UNSUPPORTED;      // what cvae_conv_up_fp8 accepts
     if (!w || !packed) return CVAE_E_NULLPTR;
     const int taps = (nd == 3) ? 64 : 16;
     const int64_t n = Cs * Cl * taps;

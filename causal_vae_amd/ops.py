@@ -544,7 +544,13 @@ def pack_weight_fp8(w, nd, for_up, scale):
 def conv_up_fp8(Sq, wq, bias, Cl, nd, act, acc_scale, out_scale=None):
     """nn.ConvTranspose{2,3}d(k4, s2, p1) + bias + activation on fp8 operands (forward only).  Sq: uint8 codes [B, sd, sh, sw, Cs]; result bf16
     (out_scale None) or fp8 codes of result / out_scale."""
+    L.require_gpu(Sq)
     B, sd, sh, sw, Cs = _cl_dims(Sq)
+    if Sq.dtype != torch.uint8 or wq.dtype != torch.uint8:
+        raise L.CvaeError("conv_up_fp8: activations and weight panels must be fp8 codes (uint8 tensors from quantize_fp8 / pack_weight_fp8)")
+    if wq.numel() != Cs * Cl * 4 ** nd:
+        raise L.CvaeError(f"conv_up_fp8: weight panels hold {wq.numel()} codes, expected Cs * Cl * 4^nd = {Cs * Cl * 4 ** nd}")
+    Sq = Sq.contiguous()
     ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
     Lt = torch.empty((B, ld, lh, lw, Cl), dtype=torch.bfloat16 if out_scale is None else torch.uint8, device=Sq.device)
     check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up_fp8, ptr(Sq), ptr(wq), ptr(bias), ptr(Lt), L.BF16 if out_scale is None else L.FP8,

@@ -524,6 +524,49 @@ def test_batched_counterfactual_decode_equals_per_value_loop():
     torch.testing.assert_close(outm.reshape(-1, 1, 28, 28).cpu(), ofn.morph_decode(sdm, m_cf, z_rep), rtol=1e-4, atol=1e-5)
 
 
+def test_fp8_and_bf16_sweep_decode_close_to_fp32_decode():
+    """BASELINE.json configs[4] at its full size: 4 samples x 12 features x 5 values = 240 stacked rows decoded in ONE call, in bf16 and on the
+    fp8 (e4m3) conv path, against the fp32 HIP decode of the same rows (itself checked against the oracle on three rows here and in
+    test_batched_counterfactual_decode_equals_per_value_loop).  Measured (tools/fp8_probe.py, random-init weights): rel-L2 1.4e-3 bf16,
+    3.0e-3 fp8 (3.0e-3 on the 180 rows the scales were NOT calibrated on); per-row SSE against a binary target differs by < 8e-5 relative.
+    Bounds: 3x those.  The fp8 scales are static per tensor, from the first sample's 60 rows only."""
+    from causal_vae_amd.counterfactual import batched_counterfactual, sweep_inputs
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).eval()
+    sd = oracle.init_state_dict("bio3d", seed=42)
+    g = torch.Generator().manual_seed(8)
+    z, m = torch.randn(4, 64, generator=g), torch.rand(4, 12, generator=g)
+    feats, vals = list(range(12)), [0.0, 0.25, 0.5, 0.75, 1.0]
+    x = (torch.rand(240, 1, 64, 64, 64, generator=g) < 0.1).float().to(DEV)
+    zd, md = z.to(DEV), m.to(DEV)
+    ref = batched_counterfactual(model, zd, md, feats, vals)
+    assert ref.shape == (4, 12, 5, 1, 64, 64, 64)
+    for b, fi, vi in ((3, 11, 4), (2, 6, 1), (0, 0, 0)):
+        m1 = m[b:b + 1].clone(); m1[0, feats[fi]] = vals[vi]
+        torch.testing.assert_close(ref[b, fi, vi].cpu(), ofn.bio_decode(sd, z[b:b + 1], m1, nd=3)[0], rtol=1e-4, atol=1e-5)
+    model.set_compute_dtype(torch.bfloat16)
+    b16 = batched_counterfactual(model, zd, md, feats, vals)
+    z_rep, m_cf = sweep_inputs(zd, md, feats, vals)
+    plan = model.calibrate_fp8_decoder(z_rep[:60], m_cf[:60])
+    assert [e["sx"] is not None for e in plan] == [True, True, True, False]       # the single-channel output layer stays bf16
+    f8 = batched_counterfactual(model, zd, md, feats, vals, fp8_plan=plan)
+    assert f8.shape == ref.shape and f8.dtype == ref.dtype
+    sse = lambda a: ((a.reshape(240, -1) - x.reshape(240, -1)) ** 2).sum(1)
+    rl2 = lambda a, b: float((a - b).norm() / b.norm())
+    for name, got, bound in (("bf16", b16, 4.5e-3), ("fp8", f8, 9e-3)):
+        assert rl2(got, ref) < bound, (name, rl2(got, ref))
+        assert rl2(got[1:], ref[1:]) < bound, (name, "rows outside the calibration set")
+        d = float(((sse(got) - sse(ref)).abs() / sse(ref)).max())
+        assert d < 2.5e-4, (name, "per-row SSE", d)
+    # the fp8 result is a different computation from the bf16 one, not an alias of it
+    assert rl2(f8, b16) > 1e-4
+    # resize stage after the fp8 convs, and the eager per-row form gives the same rows (static scales: no batch dependence)
+    up = batched_counterfactual(model, zd[:1], md[:1], [3], [0.1, 0.9], size=(96, 80, 72), fp8_plan=plan)
+    assert up.shape == (1, 1, 2, 1, 96, 80, 72)
+    one = model.decode(z_rep[77:78], m_cf[77:78], fp8_plan=plan)
+    torch.testing.assert_close(one[0], f8.reshape(240, 1, 64, 64, 64)[77], rtol=0, atol=0)
+
+
 def test_gaussian_head_adversarial_step_matches_oracle():
     """06_model_experiment train loop body (D step, then VAE step with the Gaussian-NLL morph term) vs the oracle's step."""
     from causal_vae_amd.mnist_gaussian import CausalMorphVAE12 as GaussVAE, train_step as gauss_step

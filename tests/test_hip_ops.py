@@ -139,6 +139,70 @@ def test_conv_transpose_forward_backward(nd, B, Cl, Cs, size, dtype, split_k):
     close(bg.grad.cpu(), gb_ref, torch.float32, "db", scale=float(gb_ref.abs().max()) * 3)
 
 
+# --------------------------------------------------------------------------------------------- fp8 (e4m3) inference path
+def _e4m3_decode(codes):
+    """uint8 OCP e4m3 codes -> fp32 (the CPU checker's own decode: torch.float8_e4m3fn is that format)."""
+    return codes.cpu().view(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_quantize_fp8_codes_bit_exact(dtype):
+    """cvae_quantize_fp8: round-to-nearest-even e4m3 codes of x / scale, saturating at +-448 — bit-exact against torch's CPU cast of the clamped values."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.cat([torch.randn(4099, generator=g) * 3, torch.tensor([0.0, -0.0, 1e-4, -2e-3, 447.0, 448.0, 1e4, -1e4, 2.0 ** -9, 2.0 ** -10 * 1.5])])
+    scale = 0.37
+    xg = x.to(DEV).to(dtype)
+    q = ops.quantize_fp8(xg, scale)
+    assert q.dtype == torch.uint8 and q.shape == xg.shape
+    ref = (xg.float().cpu() * (1.0 / scale)).clamp(-ops.FP8_MAX, ops.FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    got = q.cpu()
+    same = (got == ref) | ((got & 0x7f) == 0) & ((ref & 0x7f) == 0)                # +0 and -0 are the same value
+    assert bool(same.all()), f"{int((~same).sum())} codes differ"
+
+
+@pytest.mark.parametrize("nd,B,Cl,Cs,ssize,act,q_out", [(3, 2, 128, 256, (4, 4, 4), "relu", True), (3, 3, 64, 128, (8, 8, 8), "relu", False), (3, 1, 32, 64, (5, 6, 9), None, True),
+                                                        (2, 2, 32, 64, (12, 20), "relu", False)])
+def test_conv_up_fp8_matches_dequantised_reference(nd, B, Cl, Cs, ssize, act, q_out):
+    """cvae_conv_up_fp8 on fp8 codes == conv_transpose (fp32, CPU) of the DEQUANTISED operands: the kernel adds no error beyond the quantisation it is
+    given (fp32 accumulation; the result is rounded once to bf16, 2^-8, or to e4m3 codes, 2^-4 relative)."""
+    g = torch.Generator().manual_seed(5)
+    convT = F.conv_transpose2d if nd == 2 else F.conv_transpose3d
+    x = torch.randn(B, Cs, *ssize, generator=g).abs()                     # post-ReLU activations
+    w = torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cs * 2 ** nd)
+    b = torch.randn(Cl, generator=g) * 0.1
+    sx, sw = float(x.abs().max()) / ops.FP8_MAX, float(w.abs().max()) / ops.FP8_MAX
+    xq = ops.quantize_fp8(to_cl(x, torch.bfloat16), sx)
+    wq_codes = ops.quantize_fp8(w.to(DEV), sw)
+    wq = ops.pack_weight_fp8(w.to(DEV), nd, True, sw)
+    x_deq = from_cl(_e4m3_decode(xq) * sx, nd)
+    w_deq = _e4m3_decode(wq_codes) * sw
+    ref = convT(x_deq, w_deq, b, stride=2, padding=1)
+    if act:
+        ref = F.relu(ref)
+    so = float(ref.abs().max()) / ops.FP8_MAX if q_out else None
+    y = ops.conv_up_fp8(xq, wq, b.to(DEV), Cl, nd, act, sx * sw, so)
+    if q_out:
+        assert y.dtype == torch.uint8
+        got = from_cl(_e4m3_decode(y) * so, nd)
+        torch.testing.assert_close(got, ref, rtol=2.0 ** -3, atol=so * 2.0 ** -9 * 1.01)      # e4m3: 3 mantissa bits; a sum that lands next to a rounding boundary may go to
+        assert float((got - ref).norm() / ref.norm()) < 2.0 ** -5                              # either neighbour (1 ulp = 2^-3 relative, 2^-9 * scale in the subnormals)
+    else:
+        assert y.dtype == torch.bfloat16
+        close(from_cl(y, nd), ref, torch.bfloat16, "y")
+
+
+def test_conv_up_fp8_bad_arguments_fail_loudly():
+    xq = torch.zeros(1, 4, 4, 4, 64, dtype=torch.uint8, device=DEV)
+    w = torch.zeros(64, 32, 4, 4, 4, device=DEV)
+    with pytest.raises(L.CvaeError):
+        ops.pack_weight_fp8(torch.zeros(64, 1, 4, 4, 4, device=DEV), 3, True, 1.0)     # single-channel layers stay bf16
+    wq = ops.pack_weight_fp8(w, 3, True, 1.0)
+    with pytest.raises(L.CvaeError):
+        ops.conv_up_fp8(xq.float(), wq, None, 32, 3, None, 1.0)                         # codes must be uint8
+    with pytest.raises(L.CvaeError):
+        ops.conv_up_fp8(xq[..., :48].contiguous(), wq, None, 32, 3, None, 1.0)          # channel count does not match the panels
+
+
 def test_conv_relu_mask_fusion_matches_unfused():
     """in_is_relu_out / grad_premasked only move the ReLU mask into neighbouring kernels: gradients must not change."""
     g = torch.Generator().manual_seed(3)
