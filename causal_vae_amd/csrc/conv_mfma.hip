@@ -38,6 +38,28 @@ __device__ unsigned long long g_stamp[(size_t)CVAE_STAMP_WGS * CVAE_STAMP_SLOTS]
 
 namespace {
 
+#ifndef CVAE_BDIRECT
+#define CVAE_BDIRECT 1                  // bf16 data kernels fetch their weight fragments per wave (BD, below): 0.867 -> 0.832 ms/step at 128^3 B=4
+#endif
+#ifndef CVAE_BD_GS
+#define CVAE_BD_GS 8
+#endif
+#ifndef CVAE_BD_HPRE
+#define CVAE_BD_HPRE 0
+#endif
+#ifndef CVAE_APIPE
+#define CVAE_APIPE 3
+#endif
+#ifndef CVAE_UPFULL
+#define CVAE_UPFULL 0
+#endif
+#ifndef CVAE_UPFULL_WIDE
+#define CVAE_UPFULL_WIDE 0
+#endif
+#ifndef CVAE_UPFULL_MIN_WG
+#define CVAE_UPFULL_MIN_WG 512
+#endif
+
 struct ConvGeom {
     int B;
     int sd, sh, sw, Cs;
@@ -150,8 +172,11 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // TO: output (and mask) dtype, = T except on the fp8 inference path, where an fp8 x fp8 product leaves as fp8 (next fp8 layer) or bf16
 // (the layer in front of the single-channel kernel): out = act(acc * acc_scale + bias) * out_scale, acc_scale = s_in * s_w the product of the
 // operands' per-tensor scales, out_scale = 1 / s_out.
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T>
-__global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
+// BD ("B direct"): every wave fetches its weight fragments straight from the packed global panels into a two-group register ring (the panels are
+// laid out so that one fragment of a wave is 1 KB contiguous) instead of all waves staging them through LDS: no weight traffic on the LDS
+// pipe, which the activation fragments already load to ~2/3 of the MFMA time, and no barrier inside a channel chunk's tap loop.
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = false>
+__global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                   const TO* __restrict__ mask, TO* __restrict__ out, ConvGeom g, int act,
                                                                   float* __restrict__ ws, int ksplit, float acc_scale, float out_scale) {
     constexpr int NT = WM * WN * 64;
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
     auto hslot = [](int z, int y, int x) -> int {
         return UP ? (z * IH + y) * RS + x : ((x & 1) * NROWS + z * IH + y) * RS + (x >> 1);
     };
-    constexpr int BT_BYTES = 4 * KH * 2 * BN * FB;       // one B buffer: [4 taps][KH k-steps][2 halves][BN]
+    constexpr int BT_BYTES = BD ? 0 : 4 * KH * 2 * BN * FB;       // one B buffer: [4 taps][KH k-steps][2 halves][BN]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* bt = smem + HALO_BYTES;
@@ -277,12 +302,82 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
         }
     };
 
+    // ---- BD: k-steps of a chunk in the order the LDS form walks them (tap group, tap, k-step), cut into NGRP groups of GS steps; group g + 1
+    // (or the next chunk's group 0) is in flight while group g feeds the MFMAs ----
+    constexpr int STEPS = NG * 4 * KH, GS = STEPS >= 64 ? CVAE_BD_GS : (STEPS >= 16 ? 8 : STEPS / 2), NGRP = STEPS / GS;
+    static_assert(!BD || (NGRP % 2 == 0 && GS * NGRP == STEPS && GS % KH == 0), "BD walks the groups in pairs");
+    const T* wl = wp + ((size_t)(n0 + wn * NI * 32 + r)) * 16 + 8 * h;
+    Frag<T> qa[BD ? GS : 1][NI], qb[BD ? GS : 1][NI];
+    auto load_q = [&](Frag<T> (&q)[BD ? GS : 1][NI], int chunk, int gidx) {
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            const int kk = i % KH, tj = gidx * (GS / KH) + i / KH;
+            const int wt = tap_weight_idx(tj >> 2, tj & 3);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) lds_load(q[i][ni], (const char*)(wl + ((size_t)(wt * nch16 + chunk * KH + kk) * Cout + ni * 32) * 16));
+        }
+    };
+    auto compute_q = [&](const Frag<T> (&q)[BD ? GS : 1][NI], int gidx) {
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            const int kk = i % KH, tj = gidx * (GS / KH) + i / KH;
+            const int toff = tap_halo_off(tj >> 2, tj & 3);
+            Frag<T> a[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], q[i][ni], a[mi]);
+        }
+    };
     STAMP(1);
     const int chunk_per = nchunks / ksplit;                 // host guarantees ksplit divides nchunks
     // UP with 32-channel stages (long K loops on small grids): the NEXT stage's halo is requested right after this stage's LDS image is
     // complete and lands under the tap loop (-5 %).  Elsewhere the prefetch loses: DOWN stages 14 pieces per thread (registers), and the
     // Cin = 64 `up` launches fill the chip, where the co-resident workgroups already hide the stage (+4 % measured).
-    constexpr bool HPRE = UP && KH == 2;
+    constexpr bool HPRE = (UP && KH == 2) || (BD && CVAE_BD_HPRE);
+    // Groups gp (weights in qa) and gp + 1 (qb) as ONE run of 2 GS k-steps; the group after them goes back into qa once qa is spent.  The activation
+    // fragments are software-pipelined by hand: the ds_reads of step i + APD are issued in front of the MFMAs of step i (APD + 1 register slots), so an
+    // MFMA never waits for a read issued right before it — left to itself the compiler emits read / s_waitcnt / MFMA per step and the loop runs at
+    // LDS latency (~35 % of the MFMA rate by the stamp probes, one wave per SIMD).
+    auto bd_pair = [&](int chunk, int gp) {
+        constexpr int NS = 2 * GS, APD = CVAE_APIPE < NS ? CVAE_APIPE : NS - 1;
+        load_q(qb, chunk, gp + 1);
+        Frag<T> ar[APD + 1][MI];
+        auto lda = [&](int slot, int i) {
+            const int gidx = gp + i / GS, ii = i % GS;
+            const int kk = ii % KH, tj = gidx * (GS / KH) + ii / KH;
+            const int toff = tap_halo_off(tj >> 2, tj & 3);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) lds_load(ar[slot][mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
+        };
+#pragma unroll
+        for (int d = 0; d < APD; ++d) lda(d, d);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (i + APD < NS) lda((i + APD) % (APD + 1), i + APD);
+            if (i == GS) {
+                const bool wrap = gp + 2 >= NGRP;
+                if (!wrap || chunk + 1 < (ks + 1) * chunk_per) load_q(qa, wrap ? chunk + 1 : chunk, wrap ? 0 : gp + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // keep the reads where they are written: the scheduler would sink them back to their uses
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], (i < GS ? qa[i % GS] : qb[i % GS])[ni], ar[i % (APD + 1)][mi]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto bd_chunk = [&](int chunk) {
+        if constexpr (NGRP > 2) {                           // 3D down: 64 taps; rolled, or the unrolled LDS reads spill
+#pragma unroll 1
+            for (int gp = 0; gp < NGRP; gp += 2) bd_pair(chunk, gp);
+        } else {
+            bd_pair(chunk, 0);
+        }
+    };
+    if constexpr (BD) load_q(qa, ks * chunk_per, 0);
     Piece<T> hp[HN];
     if (HPRE) {
 #pragma unroll
@@ -295,7 +390,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
                 for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + chunk * (16 * KH), hoff[i] >= 0);
             }
-            load_b(pb0, chunk, 0);
+            if constexpr (!BD) load_b(pb0, chunk, 0);
             __syncthreads();                               // previous chunk's readers are done with halo + B buffers
             if (chunk - ks * chunk_per < 8) STAMP(2 + 3 * (chunk - ks * chunk_per));
 #pragma unroll
@@ -303,7 +398,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
                 const int it = t + i * NT, pos = it / PPP;
                 if (it < NPOS * PPP) piece_store<T>(hp[i], halo + ((size_t)(it % PPP) * PLANE + hslot(pos / (IW * IH), (pos / IW) % IH, pos % IW)) * FB);
             }
-            store_b(pb0, 0);
+            if constexpr (!BD) store_b(pb0, 0);
         }
         __syncthreads();
         if (chunk - ks * chunk_per < 8) STAMP(3 + 3 * (chunk - ks * chunk_per));
@@ -311,40 +406,44 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_data_kernel(const T* __rest
 #pragma unroll
             for (int i = 0; i < HN; ++i) piece_load<T>(hp[i], in_b + (hoff[i] < 0 ? 0 : hoff[i]) + (chunk + 1) * (16 * KH), hoff[i] >= 0);
         }
-        // Weight panels ride a 2-deep ring: the panel of group g+2 is loaded into registers at the start of group g and
-        // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
-        // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
-        auto taps = [&](int grp, const char* btb) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int toff = tap_halo_off(grp, j);
-#pragma unroll
-                for (int kk = 0; kk < KH; ++kk) {
-                    Frag<T> a[MI], bf[NI];
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) lds_load(bf[ni], btb + (((j * KH + kk) * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
+        if constexpr (BD) {
+            bd_chunk(chunk);
+        } else {
+            // Weight panels ride a 2-deep ring: the panel of group g+2 is loaded into registers at the start of group g and
+            // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
+            // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
+            auto taps = [&](int grp, const char* btb) {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int toff = tap_halo_off(grp, j);
+    #pragma unroll
+                    for (int kk = 0; kk < KH; ++kk) {
+                        Frag<T> a[MI], bf[NI];
+    #pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
+    #pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) lds_load(bf[ni], btb + (((j * KH + kk) * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
+    #pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
+                    }
                 }
-            }
-        };
-        Piece<T> pbA[BP], pbB[BP];
-        if (NG > 1) load_b(pbA, chunk, 1);
-#pragma unroll 1
-        for (int grp = 0; grp < NG; grp += 2) {
-            if (grp + 2 < NG) load_b(pbB, chunk, grp + 2);
-            taps(grp, bt);
-            if (grp + 1 < NG) store_b(pbA, 1);
-            __syncthreads();
-            if (grp + 1 < NG) {
-                if (grp + 3 < NG) load_b(pbA, chunk, grp + 3);
-                taps(grp + 1, bt + BT_BYTES);
-                if (grp + 2 < NG) store_b(pbB, 0);
+            };
+            Piece<T> pbA[BP], pbB[BP];
+            if (NG > 1) load_b(pbA, chunk, 1);
+    #pragma unroll 1
+            for (int grp = 0; grp < NG; grp += 2) {
+                if (grp + 2 < NG) load_b(pbB, chunk, grp + 2);
+                taps(grp, bt);
+                if (grp + 1 < NG) store_b(pbA, 1);
                 __syncthreads();
+                if (grp + 1 < NG) {
+                    if (grp + 3 < NG) load_b(pbA, chunk, grp + 3);
+                    taps(grp + 1, bt + BT_BYTES);
+                    if (grp + 2 < NG) store_b(pbB, 0);
+                    __syncthreads();
+                }
             }
         }
         if (chunk - ks * chunk_per < 8) STAMP(4 + 3 * (chunk - ks * chunk_per));
@@ -473,7 +572,7 @@ static int pick_ksplit(bool up, long long nwg, int nchunks) {
     return best;
 }
 
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T>
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = (CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2)>
 int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
                     size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -482,9 +581,9 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     constexpr int IH = UP ? TL::TH + 1 : 2 * TL::TH + 2, IW = UP ? TL::TW + 1 : 2 * TL::TW + 2;
     constexpr int FB = 8 * sizeof(T);
     static_assert(IW >= 0, "");
-    constexpr size_t LDS = (size_t)2 * KH * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (size_t)2 * 4 * KH * 2 * BN * FB;
+    constexpr size_t LDS = (size_t)2 * KH * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (BD ? 0 : (size_t)2 * 4 * KH * 2 * BN * FB);
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
-    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO>;
+    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
@@ -539,6 +638,318 @@ size_t data_workspace_bytes(const ConvGeom& g) {
     const int ksplit = pick_ksplit(UP, tiles * (Cout / BN) * npar * g.B, Cin / 16);
     if (ksplit <= 1) return 0;
     return (size_t)ksplit * g.B * (UP ? (size_t)g.ld * g.lh * g.lw : (size_t)g.sd * g.sh * g.sw) * Cout * sizeof(float);
+}
+
+
+// ---------------------------------------------------------------------------------------------- up, whole-K halo ("up_full")
+// The transposed conv has only 2^nd taps per output parity, so one 16- or 32-channel stage of conv_data_kernel<UP> feeds 16-32 MFMAs per wave
+// between two barriers and a global->LDS round trip: the layers with few input channels spend more time staging than multiplying (stamp probes:
+// ~3.7 k cycles per stage for 2.7 k cycles of taps on dec1's forward; enc2's backward-data ran at 480 TFLOP/s).  Here the (T + 2)^nd halo of the
+// q tile is staged ONCE for ALL input channels (Cin = 16 KCH) and serves every parity class the workgroup owns (`ppw` of the 2^nd; the rest go to
+// sibling workgroups when the grid is small).  The weights of a parity come through LDS in half panels (2^nd / 2 taps x all k-steps, two
+// buffers, ONE barrier per half panel, fetched two half panels ahead: a per-wave fetch of the same fragments by every wave ran into the
+// L2 -> L1 bandwidth, 22 B/clk/CU).  What the stamp probes and the ISA showed about the inner loop, with one wave per SIMD:
+//   * the compiler sinks every ds_read to just in front of the MFMA that uses it (read / s_waitcnt / MFMA per step): the reads are issued
+//     CVAE_APIPE steps ahead by hand and pinned with sched_barrier;
+//   * with in-order issue every non-MFMA instruction between two MFMAs costs issue time the MFMA pipe idles for once there are more than
+//     ~6 per MFMA: the LDS image is position-major ([halo slot][8-channel piece], pitch NPC + 1 pieces: the odd pitch keeps the reads
+//     conflict-free exactly as the plane-major image did, and the pieces of one position, stored by consecutive lanes, hit different banks),
+//     so that every read of a parity is `ds_read_b128 base, offset:imm` off two per-parity base registers — no address VALU in the loop;
+//   * bias and the ReLU mask of a parity are fetched before its taps, not in the epilogue.
+template <typename T, int ND, int WM, int WN, int MI, int NI, int KCH, int EPI, typename TO = T>
+__global__ __launch_bounds__(WM * WN * 64) void conv_up_full_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
+                                                                     const TO* __restrict__ mask, TO* __restrict__ out, ConvGeom g, int act, int ppw,
+                                                                     float acc_scale, float out_scale) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    using TL = Tile<ND, BM>;
+    constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
+    constexpr int ID = (ND == 3) ? TD + 2 : 1, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
+    constexpr int FB = 8 * sizeof(T);
+    using ST = SubTile<ND>;
+    constexpr int RS = HaloPitch<ND, true>::RS, NROWS = ID * IH, NSLOT = NROWS * RS;
+    static_assert(RS >= IW, "halo pitch too small");
+    constexpr int NPC = 2 * KCH, SPITCH = NPC + 1;           // 8-channel pieces per position; slot pitch in pieces (odd)
+    constexpr int NTAP = (ND == 3) ? 8 : 4;                  // taps per parity class (= number of parity classes)
+    constexpr int HTAP = NTAP / 2, PT = KCH * 2 * BN, HP_PIECES = HTAP * PT, HP_BYTES = HP_PIECES * FB, HPP = HP_PIECES / NT;
+    static_assert(PT % NT == 0, "a tap's weight pieces must be a whole number of workgroup passes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wbuf = smem + (size_t)NSLOT * SPITCH * FB;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef CVAE_STAMP
+    const unsigned stamp_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (t == 0 && stamp_wg < CVAE_STAMP_WGS) {
+        g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 30] = wall_clock64();
+        g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 29] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    }
+#endif
+    STAMP(0);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int Cin = g.Cs, Cout = g.Cl;
+    const int nblocks = Cout / BN;
+    const int nb = blockIdx.y % nblocks, pg = blockIdx.y / nblocks;
+    const int n0 = nb * BN;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
+    const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
+    const int o0d = tile * TD, o0h = th_i * TH, o0w = tw_i * TW;
+    const int g0d = (ND == 3) ? o0d - 1 : 0, g0h = o0h - 1, g0w = o0w - 1;
+    static_assert(ST::SW == TW && TH % ST::SH == 0, "sub-tile must tile the workgroup tile");
+    constexpr int HB = TH / ST::SH;
+    int pbase[MI];                                           // halo slot of this lane's position in each M sub-tile, parity (0, 0, 0), tap (0, 0, 0)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int ms = wm * MI + mi;
+        pbase[mi] = ((ms / HB) * IH + (ms % HB) * ST::SH + ST::h_of(r)) * RS + ST::w_of(r);
+    }
+    const int par0 = pg * ppw, nhp = 2 * ppw;
+    auto tap_abc = [](int tap, int& a, int& bb, int& c) { a = (ND == 3) ? (tap >> 2) : 0; bb = (tap >> 1) & 1; c = tap & 1; };
+    // ---- weight half panels: hpi -> (parity par0 + hpi / 2, taps (hpi & 1) * HTAP ..); LDS image [tap][k-step][half][n] ----
+    const unsigned w_lane = (unsigned)((((t / (2 * BN)) * Cout + (t >> 1) % BN) * 16 + 8 * (t & 1)) * sizeof(T));     // the thread's piece inside a pass
+    const int w_slot = (t / (2 * BN)) * (2 * BN) + (t & 1) * BN + (t >> 1) % BN;
+    struct HalfPanel { Piece<T> p[HPP]; };                   // by value: as reference parameters of the lambdas the two register sets ended up in scratch
+    auto load_hp = [&](int hpi) -> HalfPanel {
+        HalfPanel wr;
+        const int par = par0 + (hpi >> 1), th = hpi & 1;
+        const int prd = (ND == 3) ? ((par >> 2) & 1) : 0, prh = (par >> 1) & 1, prw = par & 1;
+#pragma unroll
+        for (int i = 0; i < HPP; ++i) {
+            const int tl = (i * NT) / PT, k0 = ((i * NT) % PT) / (2 * BN);       // pass i: tap tl of the half, k-steps k0 .. k0 + NT / (2 BN) - 1
+            int a, bb, c;
+            tap_abc(th * HTAP + tl, a, bb, c);
+            const int kd = (ND == 3) ? (3 - prd - 2 * a) : 0, kh = 3 - prh - 2 * bb, kw = 3 - prw - 2 * c;
+            const T* wu = wp + ((size_t)(((kd * 4 + kh) * 4 + kw) * KCH + k0) * Cout + n0) * 16;     // uniform
+            piece_load_raw<T>(wr.p[i], (const T*)((const char*)wu + w_lane));
+        }
+        return wr;
+    };
+    auto store_hp = [&](const HalfPanel& wr, int buf) {
+#pragma unroll
+        for (int i = 0; i < HPP; ++i) piece_store<T>(wr.p[i], wbuf + (size_t)buf * HP_BYTES + (size_t)(i * NT + w_slot) * FB);
+    };
+    f32x16 acc[MI][NI];
+    const char* abase[MI];                                   // per parity: LDS address of (lane position + parity shift, piece h)
+    auto compute_hp = [&](const char* wb, int th) {          // HTAP * KCH k-steps, both operands from LDS, reads APD steps ahead of their MFMAs
+        constexpr int NS = HTAP * KCH, APD = CVAE_APIPE < NS ? CVAE_APIPE : NS - 1;
+        Frag<T> ar[APD + 1][MI], br[APD + 1][NI];
+        const char* bb0 = wb + (size_t)(h * BN + wn * NI * 32 + r) * FB;
+        auto ld = [&](int slot, int i) {
+            const int tl = i / KCH, kk = i % KCH;
+            int a, bb, c;
+            tap_abc(tl, a, bb, c);                            // th * HTAP + tl: the half only moves the first tap coordinate (a in 3D, bb in 2D)
+            const int tapc = (ND == 3) ? ((a + th) * IH + bb) * RS + c : (bb + th) * RS + c;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) lds_load(ar[slot][mi], abase[mi] + (size_t)(tapc * SPITCH + 2 * kk) * FB);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) lds_load(br[slot][ni], bb0 + (size_t)((tl * KCH + kk) * 2 * BN + ni * 32) * FB);
+        };
+#pragma unroll
+        for (int d = 0; d < APD; ++d) ld(d, d);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (i + APD < NS) ld((i + APD) % (APD + 1), i + APD);
+            __builtin_amdgcn_sched_barrier(0);              // keep the reads where they are written: the scheduler would sink them back to their uses
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], br[i % (APD + 1)][ni], ar[i % (APD + 1)][mi]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    STAMP(1);
+    HalfPanel wra = load_hp(0), wrb = wra;
+    // ---- stage the whole halo (all channels), once: thread t moves piece t % NPC of positions t / NPC + i * (NT / NPC) ----
+    {
+        static_assert(NT % NPC == 0, "pieces of a position must stay in one pass");
+        constexpr int PSTEP = NT / NPC, HN = (NPOS + PSTEP - 1) / PSTEP;
+        constexpr int DX = PSTEP % IW, DY = (PSTEP / IW) % IH, DZ = PSTEP / (IW * IH);
+        const T* in_b = in + (size_t)b * g.sd * g.sh * g.sw * Cin;
+        const int pc = t % NPC, pos0 = t / NPC;
+        int x = pos0 % IW, y = (pos0 / IW) % IH, z = pos0 / (IW * IH);
+        Piece<T> hp[HN];
+        int hs[HN];
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
+            const bool in_tile = z < ID;
+            const bool ok = in_tile & (gz >= 0) & (gz < g.sd) & (gy >= 0) & (gy < g.sh) & (gx >= 0) & (gx < g.sw);
+            piece_load<T>(hp[i], in_b + (ok ? (((size_t)gz * g.sh + gy) * g.sw + gx) * Cin + 8 * pc : 0), ok);
+            hs[i] = in_tile ? ((z * IH + y) * RS + x) * SPITCH + pc : -1;
+            x += DX; if (x >= IW) { x -= IW; y += 1; }
+            y += DY; if (y >= IH) { y -= IH; z += 1; }
+            z += DZ;
+        }
+        STAMP(2);
+#pragma unroll
+        for (int i = 0; i < HN; ++i)
+            if (hs[i] >= 0) piece_store<T>(hp[i], halo + (size_t)hs[i] * FB);
+    }
+    store_hp(wra, 0);
+    wra = load_hp(1);
+    __syncthreads();
+    STAMP(3);
+
+    const int out_d = g.ld, out_h = g.lh, out_w = g.lw;
+    Piece<TO> mpre[MI][NI][2];
+    float bpre[NI][2][8];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bpre[ni][j][q] = bias ? bias[c + q] : 0.f;
+        }
+    auto parity_begin = [&](int par) {                       // accumulators, LDS base of the parity's reads, its mask pieces
+        const int prd = (ND == 3) ? ((par >> 2) & 1) : 0, prh = (par >> 1) & 1, prw = par & 1;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            abase[mi] = halo + (size_t)((pbase[mi] + (prd * IH + prh) * RS + prw) * SPITCH + h) * FB;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        }
+        if (!mask) return;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ms = wm * MI + mi;
+            const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
+            const int od = (ND == 3) ? 2 * (o0d + d) + prd : 0, oh = 2 * (o0h + hh) + prh, ow = 2 * (o0w + w) + prw;
+            const bool ok = od < out_d && oh < out_h && ow < out_w;
+            const size_t pidx = ok ? ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout : 0;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) piece_load_raw<TO>(mpre[mi][ni][j], mask + pidx + n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h);
+        }
+    };
+    auto epilogue = [&](int par) {                           // conv_data_kernel's: permlane32_swap regroup, 16-byte stores
+        const int prd = (ND == 3) ? ((par >> 2) & 1) : 0, prh = (par >> 1) & 1, prw = par & 1;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ms = wm * MI + mi;
+            const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
+            const int od = (ND == 3) ? 2 * (o0d + d) + prd : 0, oh = 2 * (o0h + hh) + prh, ow = 2 * (o0w + w) + prw;
+            const bool ok = od < out_d && oh < out_h && ow < out_w;
+            const size_t pidx = ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float v[2][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][i]), __float_as_uint(acc[mi][ni][4 + i]), false, false);
+                    const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 + i]), __float_as_uint(acc[mi][ni][12 + i]), false, false);
+                    v[0][i] = __uint_as_float(lo[0]); v[0][4 + i] = __uint_as_float(lo[1]);
+                    v[1][i] = __uint_as_float(hi[0]); v[1][4 + i] = __uint_as_float(hi[1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float x = (sizeof(T) == 1 ? v[j][q] * acc_scale : v[j][q]) + bpre[ni][j][q];
+                        if (EPI == 1) x = fmaxf(x, 0.f);
+                        else if (EPI == 2) x = apply_act(x, act);
+                        v[j][q] = x;
+                    }
+                    if (!ok) continue;
+                    if (mask) {
+                        const TO* mv = (const TO*)&mpre[mi][ni][j];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
+                    }
+                    Piece<TO> op;
+                    TO* ov = (TO*)&op;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(sizeof(T) == 1 ? v[j][q] * out_scale : v[j][q]);
+                    piece_store<TO>(op, (char*)(out + pidx + c));
+                }
+            }
+        }
+    };
+    // half panels in pairs = one parity per iteration; panel hpi + 1 sits in wra, hpi + 2 is requested into wrb at the top
+    for (int hpi = 0; hpi < nhp; hpi += 2) {
+        const int par = par0 + (hpi >> 1);
+        if (hpi + 2 < nhp) wrb = load_hp(hpi + 2);
+        parity_begin(par);
+        compute_hp(wbuf, 0);
+        store_hp(wra, 1);
+        __syncthreads();
+        if (hpi + 3 < nhp) wra = load_hp(hpi + 3);
+        compute_hp(wbuf + HP_BYTES, 1);
+        if (hpi + 2 < nhp) store_hp(wrb, 0);
+        STAMP(4 + hpi);
+        epilogue(par);
+        STAMP(5 + hpi);
+        __syncthreads();
+    }
+#ifdef CVAE_STAMP
+    __builtin_amdgcn_s_waitcnt(0);
+    STAMP(27);
+    if (t == 0 && stamp_wg < CVAE_STAMP_WGS) g_stamp[(size_t)stamp_wg * CVAE_STAMP_SLOTS + 31] = wall_clock64();
+#endif
+}
+
+template <typename T, int ND, int WM, int WN, int MI, int NI, int KCH> constexpr size_t up_full_lds_bytes() {
+    using TL = Tile<ND, WM * MI * 32>;
+    constexpr int ID = (ND == 3) ? TL::TD + 2 : 1, IH = TL::TH + 2;
+    return ((size_t)(ID * IH * HaloPitch<ND, true>::RS) * (2 * KCH + 1) + (size_t)2 * (((ND == 3) ? 8 : 4) / 2) * KCH * 2 * (WN * NI * 32)) * 8 * sizeof(T);
+}
+
+// Launch of conv_up_full_kernel; CVAE_E_UNSUPPORTED when this (tile, channel count) pair does not fit the LDS (the caller falls back to launch_data<UP>).
+template <typename T, int ND, int WM, int WN, int MI, int NI, int KCH, typename TO = T>
+int launch_up_full(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream,
+                   float acc_scale = 1.f, float out_scale = 1.f) {
+    constexpr size_t LDS = up_full_lds_bytes<T, ND, WM, WN, MI, NI, KCH>();
+    if constexpr (LDS > 160 * 1024 || (KCH * 2 * WN * NI * 32) % (WM * WN * 64) != 0) {
+        return CVAE_E_UNSUPPORTED;
+    } else {
+        constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+        using TL = Tile<ND, BM>;
+        const int md = (ND == 3) ? (g.ld + 1) / 2 : 1, mh = (g.lh + 1) / 2, mw = (g.lw + 1) / 2;
+        g.tiles_d = (md + TL::TD - 1) / TL::TD; g.tiles_h = (mh + TL::TH - 1) / TL::TH; g.tiles_w = (mw + TL::TW - 1) / TL::TW;
+        const long long tiles = (long long)g.tiles_d * g.tiles_h * g.tiles_w;
+        const int npar = (ND == 3) ? 8 : 4, nblocks = g.Cl / BN;
+        // parity classes per workgroup: all of them (one halo stage per tile) once the grid has ~2 workgroups per CU without splitting them
+        int psplit = 1;
+        while (psplit < npar && tiles * nblocks * g.B * psplit < CVAE_UPFULL_MIN_WG) psplit *= 2;
+        const long long gy = (long long)nblocks * psplit;
+        if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
+        const int e = (act == CVAE_ACT_NONE) ? 0 : (act == CVAE_ACT_RELU ? 1 : 2);
+        dim3 grid((unsigned)tiles, (unsigned)gy, (unsigned)g.B), block(WM * WN * 64);
+#define UPFULL_LAUNCH(EPI)                                                                                                                          \
+        {                                                                                                                                           \
+            auto kern = conv_up_full_kernel<T, ND, WM, WN, MI, NI, KCH, EPI, TO>;                                                                   \
+            static bool attr_set = false;                                                                                                           \
+            if (!attr_set) {                                                                                                                        \
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH; \
+                attr_set = true;                                                                                                                    \
+            }                                                                                                                                       \
+            hipLaunchKernelGGL(kern, grid, block, LDS, stream, (const T*)in, (const T*)wp, bias, (const TO*)mask, (TO*)out, g, act, npar / psplit,   \
+                               acc_scale, out_scale);                                                                                               \
+        }
+        if (e == 0) UPFULL_LAUNCH(0) else if (e == 1) UPFULL_LAUNCH(1) else UPFULL_LAUNCH(2)
+#undef UPFULL_LAUNCH
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
+}
+
+// `up` through the whole-K kernel when the input channel count is one it is built for (64 / 128 / 256 where the halo fits): CVAE_E_UNSUPPORTED otherwise.
+template <typename T, int ND, int WM, int WN, int MI, int NI, typename TO = T>
+int try_up_full(const void* in, const void* wp, const float* bias, const void* mask, void* out, const ConvGeom& g, int act, hipStream_t stream,
+                float acc_scale = 1.f, float out_scale = 1.f) {
+    if (!CVAE_UPFULL || (WN * NI > 1 && !CVAE_UPFULL_WIDE)) return CVAE_E_UNSUPPORTED;
+    if (g.Cs == 64) return launch_up_full<T, ND, WM, WN, MI, NI, 4, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+    if (g.Cs == 128) return launch_up_full<T, ND, WM, WN, MI, NI, 8, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+    if (g.Cs == 256) return launch_up_full<T, ND, WM, WN, MI, NI, 16, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+    return CVAE_E_UNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -1214,6 +1625,10 @@ extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, con
     GEOM_INIT();
     const bool wide = (Cl % 64) == 0;     // N tile 64 (2x2 waves, 128 rows) else N tile 32 (4x1 waves, 256 rows)
     if (dtype == CVAE_BF16) {
+        int rc;
+        if (nd == 3) rc = wide ? try_up_full<bf16, 3, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : try_up_full<bf16, 3, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+        else rc = wide ? try_up_full<bf16, 2, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : try_up_full<bf16, 2, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+        if (rc != CVAE_E_UNSUPPORTED) return rc;
         if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
         return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
     }
@@ -1279,30 +1694,42 @@ static int wgrad_multi_t(int count, const void* const* S, const void* const* L, 
     WgradTable mt;
     WgradReduceTable rt;
     int mb = 0, rb = 0;
-    // Together the layers need ~4 workgroups per CU, not 2 each: every workgroup ends with a 128 KB slab, and 6 x 512 slabs (384 MB) no longer fit
+    // Together the layers need ~2-3 workgroups per CU, not 2 each: every workgroup ends with a 128 KB slab, and 6 x 512 slabs (384 MB) no longer fit
     // the 256 MB Infinity Cache between the main pass and the reduction (measured: the grouped reduction 77 us against 64 us for six separate
-    // ones).  Work is counted in (tile, channel block, kd) units; each workgroup gets the same number of units, so the launch ends together.
+    // ones).  The slab count of a layer depends on THAT layer only — ~CVAE_WG_TILES tiles of 128 positions per slab, at least CVAE_WG_MIN_WG
+    // workgroups — never on what else rides in the launch: the split-backward capture flushes decoder and encoder separately, and its
+    // gradients must have the summation order (the bits) of the single-launch step.
     using TLm = Tile<ND, 128>;
-    long long units[WG_MULTI_MAX], tiles[WG_MULTI_MAX], total_units = 0;
+#ifndef CVAE_WG_TILES
+#define CVAE_WG_TILES 16
+#endif
+#ifndef CVAE_WG_MIN_WG
+#define CVAE_WG_MIN_WG 64
+#endif
+    // longest workgroups first (tiles per slab, descending): the launch is ~2.5 rounds of workgroups, and a long one started last is the tail
+    long long req[WG_MULTI_MAX], key[WG_MULTI_MAX];
+    int order[WG_MULTI_MAX];
     for (int i = 0; i < count; ++i) {
         const int64_t* d = dims + 9 * i;
-        tiles[i] = d[0] * ((d[1] + TLm::TD - 1) / TLm::TD) * ((d[2] + TLm::TH - 1) / TLm::TH) * ((d[3] + TLm::TW - 1) / TLm::TW);
-        units[i] = tiles[i] * (d[4] / 64) * (d[8] / 32) * ((ND == 3) ? 4 : 1);
-        total_units += units[i];
+        const long long tiles = d[0] * ((d[1] + TLm::TD - 1) / TLm::TD) * ((d[2] + TLm::TH - 1) / TLm::TH) * ((d[3] + TLm::TW - 1) / TLm::TW);
+        const long long groups = (d[4] / 64) * (d[8] / 32) * ((ND == 3) ? 4 : 1);            // workgroups per slab index
+        req[i] = (tiles + CVAE_WG_TILES - 1) / CVAE_WG_TILES;
+        if (req[i] * groups < CVAE_WG_MIN_WG) req[i] = (CVAE_WG_MIN_WG + groups - 1) / groups;
+        if (req[i] > tiles) req[i] = tiles;
+        key[i] = (tiles + req[i] - 1) / req[i];
+        int k = i;
+        while (k > 0 && key[order[k - 1]] < key[i]) { order[k] = order[k - 1]; --k; }
+        order[k] = i;
     }
-#ifndef CVAE_WG_MULTI_TARGET
-#define CVAE_WG_MULTI_TARGET 512
-#endif
-    const long long per_wg = count > 1 ? (total_units + CVAE_WG_MULTI_TARGET - 1) / CVAE_WG_MULTI_TARGET : 0;   // tiles per workgroup (0: single layer, its own heuristic)
-    for (int i = 0; i < count; ++i) {
+    for (int k = 0; k < count; ++k) {
+        const int i = order[k];
         const int64_t* d = dims + 9 * i;
         ConvGeom g{(int)d[0], (int)d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], (int)d[6], (int)d[7], (int)d[8], 0, 0, 0};
         const int bias_mode = dbias[i] ? (dbias_side[i] ? 2 : 1) : 0;
         int m1, r1;
-        const long long req = per_wg > 0 ? (tiles[i] + per_wg - 1) / per_wg : 0;
-        const int rc = plan_wgrad<T, ND>(S[i], L[i], (float*)workspace[i], dW[i], dbias[i], bias_mode, g, &mt.e[i], &rt.e[i], &m1, &r1, req);
+        const int rc = plan_wgrad<T, ND>(S[i], L[i], (float*)workspace[i], dW[i], dbias[i], bias_mode, g, &mt.e[k], &rt.e[k], &m1, &r1, req[i]);
         if (rc != CVAE_OK) return rc;
-        mt.blk_start[i] = mb; rt.blk_start[i] = rb;
+        mt.blk_start[k] = mb; rt.blk_start[k] = rb;
         mb += m1; rb += r1;
     }
     mt.blk_start[count] = mb; rt.blk_start[count] = rb;

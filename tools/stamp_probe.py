@@ -45,6 +45,10 @@ print("WG lifetime cycles: median", np.median(cyc), " => clock GHz ~", np.median
 labels = {0: "start", 1: "index math done", 26: "mainloop done", 27: "stores drained"}
 for c in range(8):
     labels[2 + 3 * c] = f"chunk{c}: loads issued + barrier"; labels[3 + 3 * c] = f"chunk{c}: LDS filled + barrier"; labels[4 + 3 * c] = f"chunk{c}: taps done"
+if os.environ.get("STAMP_UPFULL"):
+    labels = {0: "start", 1: "index math done", 2: "halo loads issued", 3: "halo in LDS + barrier", 27: "stores drained"}
+    for c in range(8):
+        labels[4 + 2 * c] = f"parity{c}: taps done"; labels[5 + 2 * c] = f"parity{c}: epilogue issued"
 order = [i for i in [0, 1] + list(range(2, 26)) + [26, 27] if st[:, i].any()]
 prev = order[0]
 for i in order[1:]:
