@@ -504,6 +504,7 @@ def main():
     ap.add_argument("--fork-max-positions", type=int, default=0, help="with --fork: only layers with at most this many S positions per batch fork (0 = all)")
     ap.add_argument("--defer-join", action="store_true", help="with --fork: join the side stream once before the optimizer instead of after every layer")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--no-splitk", action="store_true", help="conv data kernels without their split-K scratch (A/B)")
     ap.add_argument("--no-defer-wgrad", action="store_true", help="compute every conv weight gradient in its own launch (A/B of the grouped end-of-backward launch)")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")
     ap.add_argument("--force-overlap-exchange", action="store_true", help="take the split-backward capture also at N = 1 (no exchange happens)")
@@ -523,6 +524,8 @@ def main():
     import torch.distributed as dist
     if args.no_defer_wgrad:
         _ops.DEFER_WGRAD = False
+    if args.no_splitk:
+        _ops.SPLIT_K = False
     if args.fork:
         _ops.FORK_BACKWARD, _ops.FORK_MAX_POSITIONS, _ops.DEFER_JOIN = True, args.fork_max_positions, args.defer_join
     rank, world, local_rank = init_distributed()

@@ -36,6 +36,14 @@ __device__ __forceinline__ float to_f32(fp8 x) { return __builtin_amdgcn_cvt_f32
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+// two floats -> one dword of two bf16 (lo = a): ONE v_cvt_pk_bf16_f32, where two scalar casts cost two conversions and a v_perm to join them
+typedef __bf16 cvae_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float cvae_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    const cvae_f32x2 f = {a, b};
+    const cvae_bf16x2 r = __builtin_convertvector(f, cvae_bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
 template <> __device__ __forceinline__ fp8 from_f32<fp8>(float x) {                       // saturating (the hardware conversion would give NaN past 448)
     x = fminf(fmaxf(x, -CVAE_FP8_MAX), CVAE_FP8_MAX);
     return fp8{(unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff)};
@@ -52,9 +60,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // The same with the activation fixed at compile time where a launch can afford a template instance per code: EPI 0 = none, 1 = ReLU
 // (one v_max), 2 = the runtime code.  A runtime switch inside an unrolled epilogue compiles to a scalar branch PER ELEMENT (~100 taken
 // branches per wave in the single-channel kernels), which costs more than the arithmetic it selects.
+// ReLU as ONE instruction: fmaxf(v, 0) on a value the compiler cannot prove canonical (an MFMA result read back from an AGPR, a lane swap) costs
+// a second v_max that quietens a possible signalling NaN first (and it folds v_med3(v, 0, inf) back into that pair), hence the asm.  NaN -> 0.
+__device__ __forceinline__ float relu_f32(float v) {
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 template <int EPI> __device__ __forceinline__ float apply_act_t(float v, int act) {
     if (EPI == 0) return v;
-    if (EPI == 1) return fmaxf(v, 0.f);
+    if (EPI == 1) return relu_f32(v);
     return apply_act(v, act);
 }
 #define CVAE_EPI_OF(act) ((act) == CVAE_ACT_NONE ? 0 : ((act) == CVAE_ACT_RELU ? 1 : 2))

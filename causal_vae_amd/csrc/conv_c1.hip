@@ -24,8 +24,9 @@ template <> struct C1Ops<bf16> {
     struct BFrag { bf16x8 v; };
     static __device__ __forceinline__ void load_b(BFrag& f, const float* wrow, int kb, int h) {       // wrow = W[cs = r][.]
         const float4 a = *(const float4*)(wrow + kb * 16 + 8 * h), b = *(const float4*)(wrow + kb * 16 + 8 * h + 4);
-        f.v[0] = (bf16)a.x; f.v[1] = (bf16)a.y; f.v[2] = (bf16)a.z; f.v[3] = (bf16)a.w;
-        f.v[4] = (bf16)b.x; f.v[5] = (bf16)b.y; f.v[6] = (bf16)b.z; f.v[7] = (bf16)b.w;
+        union { uint32_t u[4]; bf16x8 v; } o;
+        o.u[0] = pack2_bf16(a.x, a.y); o.u[1] = pack2_bf16(a.z, a.w); o.u[2] = pack2_bf16(b.x, b.y); o.u[3] = pack2_bf16(b.z, b.w);
+        f.v = o.v;
     }
     template <int IW>
     static __device__ __forceinline__ void mma_block(f32x16& acc, const bf16* halo, int pb, int h, const BFrag& bfr) {
@@ -149,108 +150,157 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
 // a gradient image) in 16-BYTE pieces: a halo row is the aligned window [2 o0w - EPV, 2 o0w + 2 TW + EPV) of EPV-element vectors (EPV = 4
 // fp32 / 8 bf16), i.e. 6 (4) coalesced loads per row instead of 18 two-byte ones, converted to bf16 on the way into LDS.  The tap window of
 // an output starts at an ODD element of that row image, so a lane reads 3 aligned dwords per row and funnel-shifts (v_alignbit) the 4
-// bf16 it needs out of them.  Needs lw % EPV == 0 and a 16-byte aligned image (cvae_conv_image_supported); everything else as above.
-template <typename TL, int ND, int EPI>
+// bf16 it needs out of them.  Needs lw % EPV == 0 and a 16-byte aligned image (cvae_conv_image_supported).
+// The layer moves 100 MB (128^3, B = 4) for 4 GFLOP, but its first form issued ~1000 instructions per wave for 8 MFMAs (64 positions) and ran at
+// the VALU issue rate (45 us in the step): so MS = 4 sub-tiles of 32 positions per wave (512 per workgroup: the weight fragments, the bias and
+// the staging index arithmetic are paid once per 128 positions of a wave), the bias rides in as the accumulators' initial value, the ReLU-mask
+// code exists only in the MASKED instantiation, and the staging loop steps its (row, vector) coordinates instead of dividing.
+// 3D tile of the single-channel weight gradient: 2 x 2 x 32 positions — its image rows are 72 contiguous elements, not 24
+// 3D tile of the single-channel transposed conv: 4 x 8 x 8 voxels (a 2 x 4 x 32 tile measured no faster at B = 4 and 2 % slower at 240 rows: 36 % more halo)
+#define C1U_TD3 4
+#define C1U_TH3 8
+#define C1U_TW3 8
+#define C1W_TD3 2
+#define C1W_TH3 2
+#define C1W_TW3 32
+#ifndef CVAE_C1_MAX_WG
+#define CVAE_C1_MAX_WG 1024
+#endif
+template <int ND, int MS> struct TileC1V;
+template <int MS> struct TileC1V<3, MS> { static constexpr int TD = MS / 2, TH = 8, TW = 32; };   // wide in x: a halo row is 160-288 contiguous bytes, an output row 2 KB
+template <int MS> struct TileC1V<2, MS> { static constexpr int TD = 1, TH = 8 * MS, TW = 16; };
+
+template <typename TL, int ND, int EPI, bool MASKED, int MS>
 __global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__ L, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const bf16* __restrict__ mask, bf16* __restrict__ S, int sd, int sh, int sw, int ld, int lh, int lw,
-                                                          int tiles_h, int tiles_w, int act) {
-    using TLE = TileC1<ND>;
+                                                          int tiles_d, int tiles_h, int tiles_w, int ntiles, int act) {
+    using TLE = TileC1V<ND, MS>;
     using OP = C1Ops<bf16>;
     constexpr int CS = 32;
     constexpr int TD = TLE::TD, TH = TLE::TH, TW = TLE::TW;
+    static_assert(TD * TH * TW == 128 * MS, "4 waves x MS sub-tiles of 32 positions");
     constexpr int EPV = 16 / sizeof(TL), NV = (2 * TW + 2 * EPV) / EPV, IWP = NV * EPV;
     constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, NROW = ID * IH, NVEC = NROW * NV;
     constexpr int TAPS = (ND == 3) ? 64 : 16, NKB = TAPS / 16, HN = (NVEC + 255) / 256;
     __shared__ __attribute__((aligned(16))) bf16 halo[NROW * IWP + 8];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5, b = blockIdx.z;
-    int tile = blockIdx.x;
-    const int tw_i = tile % tiles_w; tile /= tiles_w;
-    const int th_i = tile % tiles_h; tile /= tiles_h;
-    const int o0d = tile * TD, o0h = th_i * TH, o0w = tw_i * TW;
-    const int gx0 = 2 * o0w - EPV;
-    // ---- all halo vectors in flight at once, weights into B fragments meanwhile ----
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    // A workgroup walks tiles blockIdx.x, + gridDim.x, ...: the halo vectors of the NEXT tile are requested before the current tile is multiplied
+    // and stored.  With one tile per workgroup the whole chip read, then multiplied, then wrote in lockstep (one round of workgroups): 8 us of
+    // reads, then 16 us of writes, neither using the other's HBM time (kbench: 34.7 us for 84 MB).
     uint4 hv[HN];
+    auto issue_loads = [&](int tile) {
+        const int tw_i = tile % tiles_w; tile /= tiles_w;
+        const int th_i = tile % tiles_h; tile /= tiles_h;
+        const int td_i = tile % tiles_d, b = tile / tiles_d;
+        const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
+        const int gx0 = 2 * o0w - EPV;
+        constexpr int DJ = 256 % NV, DROW = 256 / NV, DY = DROW % IH, DZ = DROW / IH;
+        int j = t % NV, row = t / NV;
+        int y = row % IH, z = row / IH;
+        const TL* Lb = L + (size_t)b * ld * lh * lw;
 #pragma unroll
-    for (int i = 0; i < HN; ++i) {
-        const int it = min(t + i * 256, NVEC - 1), row = it / NV, j = it % NV;
-        const int y = row % IH, z = row / IH;
-        const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = gx0 + j * EPV;
-        const bool ok = (gz >= 0) & (gz < ld) & (gy >= 0) & (gy < lh) & (gx >= 0) & (gx < lw);      // lw % EPV == 0: a vector is inside or outside as a whole
-        const uint4 v = *(const uint4*)(L + (((size_t)b * ld + min(max(gz, 0), ld - 1)) * lh + min(max(gy, 0), lh - 1)) * lw + min(max(gx, 0), lw - EPV));   // clamped: unconditional load
-        hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-    }
+        for (int i = 0; i < HN; ++i) {                         // vector t + 256 i = (row, j): stepped, not divided
+            const int gz = (ND == 3) ? 2 * o0d - 1 + z : 0, gy = 2 * o0h - 1 + y, gx = gx0 + j * EPV;
+            const bool ok = (z < ID) & (gz >= 0) & (gz < ld) & (gy >= 0) & (gy < lh) & (gx >= 0) & (gx < lw);      // lw % EPV == 0: a vector is inside or outside as a whole
+            const uint4 v = *(const uint4*)(Lb + ((size_t)min(max(gz, 0), ld - 1) * lh + min(max(gy, 0), lh - 1)) * lw + min(max(gx, 0), lw - EPV));   // clamped: unconditional load
+            hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+            j += DJ; if (j >= NV) { j -= NV; y += 1; }
+            y += DY; if (y >= IH) { y -= IH; z += 1; }
+            if (y >= IH) { y -= IH; z += 1; }
+            z += DZ;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int it = t + i * 256;
+            if (it < NVEC) {
+                if constexpr (sizeof(TL) == 4) {
+                    const float* f = (const float*)&hv[i];
+                    *(uint2*)(halo + it * EPV) = make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]));           // row * IWP + j * EPV == it * EPV
+                } else {
+                    *(uint4*)(halo + it * EPV) = hv[i];
+                }
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    issue_loads(tile);
     typename OP::BFrag bfr[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) OP::load_b(bfr[kb], w + (size_t)r * TAPS, kb, h);
+    // bias as the accumulators' initial value: D row (channel) of register e on lane (., h) is (e & 3) + 8 (e >> 2) + 4 h
+    float4 bq[4];
 #pragma unroll
-    for (int i = 0; i < HN; ++i) {
-        const int it = t + i * 256;
-        if (it < NVEC) {
-            if constexpr (sizeof(TL) == 4) {
-                const float* f = (const float*)&hv[i];
-                union { uint2 u; bf16 e[4]; } o;
-                o.e[0] = (bf16)f[0]; o.e[1] = (bf16)f[1]; o.e[2] = (bf16)f[2]; o.e[3] = (bf16)f[3];
-                *(uint2*)(halo + it * EPV) = o.u;           // row * IWP + j * EPV == it * EPV
-            } else {
-                *(uint4*)(halo + it * EPV) = hv[i];
-            }
-        }
-    }
+    for (int q = 0; q < 4; ++q) bq[q] = bias ? *(const float4*)(bias + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    store_lds();
     __syncthreads();
-    float bv[2][8];                                          // bias of this lane's two 8-channel pieces (channels 16 j + 8 h + q)
+    while (true) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) issue_loads(next);
+        int tt = tile;
+        const int tw_i = tt % tiles_w; tt /= tiles_w;
+        const int th_i = tt % tiles_h; tt /= tiles_h;
+        const int td_i = tt % tiles_d, b = tt / tiles_d;
+        const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
+        const size_t tile_org = ((((size_t)b * sd + o0d) * sh + o0h) * sw + o0w) * CS;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-        if (bias) { b0 = *(const float4*)(bias + 16 * j + 8 * h); b1 = *(const float4*)(bias + 16 * j + 8 * h + 4); }
-        bv[j][0] = b0.x; bv[j][1] = b0.y; bv[j][2] = b0.z; bv[j][3] = b0.w; bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
-    }
+        for (int ms = 0; ms < MS; ++ms) {
+            const int m = (wave * MS + ms) * 32 + r;
+            const int w0 = m % TW, hh = m / TW % TH, d = m / (TW * TH);
+            // element index of the aligned dword that holds tap kw = 0 in its upper half: x = 2 w0 - 1 - gx0 = 2 w0 + EPV - 1 (odd)
+            const int pb = ((2 * d) * IH + 2 * hh) * IWP + 2 * w0 + EPV - 2;
+            f32x16 acc;
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        const int m = (wave * 2 + ms) * 32 + r;
-        const int w0 = m % TW, hh = m / TW % TH, d = m / (TW * TH);
-        // element index of the aligned dword that holds tap kw = 0 in its upper half: x = 2 w0 - 1 - gx0 = 2 w0 + EPV - 1 (odd)
-        const int pb = ((2 * d) * IH + 2 * hh) * IWP + 2 * w0 + EPV - 2;
-        f32x16 acc;
+            for (int q = 0; q < 4; ++q) { acc[4 * q] = bq[q].x; acc[4 * q + 1] = bq[q].y; acc[4 * q + 2] = bq[q].z; acc[4 * q + 3] = bq[q].w; }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int kb = 0; kb < NKB; ++kb) {
+                union { uint32_t u[4]; bf16x8 v; } a;
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            union { uint32_t u[4]; bf16x8 v; } a;
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {                 // rows kh = 2 h + rr
-                const uint32_t* p = (const uint32_t*)(halo + pb + (kb * IH + 2 * h + rr) * IWP);
-                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-                a.u[2 * rr] = __builtin_amdgcn_alignbit(d1, d0, 16);
-                a.u[2 * rr + 1] = __builtin_amdgcn_alignbit(d2, d1, 16);
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kb].v, a.v, acc, 0, 0, 0);       // D = W x im2col^T: rows = channels, columns = positions
-        }
-        const int ow = o0w + w0, oh = o0h + hh, od = o0d + d;
-        const bool ok = od < sd && oh < sh && ow < sw;
-        const size_t pidx = ((((size_t)b * sd + od) * sh + oh) * sw + ow) * CS;
-        float v[2][8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[4 + i]), false, false);
-            const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 + i]), __float_as_uint(acc[12 + i]), false, false);
-            v[0][i] = __uint_as_float(lo[0]); v[0][4 + i] = __uint_as_float(lo[1]);
-            v[1][i] = __uint_as_float(hi[0]); v[1][4 + i] = __uint_as_float(hi[1]);
-        }
-        if (ok) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = 16 * j + 8 * h;
-                __attribute__((aligned(16))) bf16 mv[8], ov[8];
-                if (mask) *(uint4*)mv = *(const uint4*)(mask + pidx + c);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float x = apply_act_t<EPI>(v[j][q] + bv[j][q], act);
-                    if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
-                    ov[q] = from_f32<bf16>(x);
+                for (int rr = 0; rr < 2; ++rr) {                 // rows kh = 2 h + rr
+                    const uint32_t* p = (const uint32_t*)(halo + pb + (kb * IH + 2 * h + rr) * IWP);
+                    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                    a.u[2 * rr] = __builtin_amdgcn_alignbit(d1, d0, 16);
+                    a.u[2 * rr + 1] = __builtin_amdgcn_alignbit(d2, d1, 16);
                 }
-                *(uint4*)(S + pidx + c) = *(const uint4*)ov;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kb].v, a.v, acc, 0, 0, 0);       // D = W x im2col^T: rows = channels, columns = positions
+            }
+            const int ow = o0w + w0, oh = o0h + hh, od = o0d + d;
+            const bool ok = od < sd && oh < sh && ow < sw;
+            const int loff = ((d * sh + hh) * sw + w0) * CS;      // 32-bit offset inside the tile; the tile's origin is uniform (scalar registers)
+            // the activation on the MFMA's own registers, then two v_permlane32_swap per register pair regroup D (rows = channels) into channels
+            // 8h..8h+7 and 16+8h..23+8h of this lane's position
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = apply_act_t<EPI>(acc[e], act);
+            float v[2][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[4 + i]), false, false);
+                const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 + i]), __float_as_uint(acc[12 + i]), false, false);
+                v[0][i] = __uint_as_float(lo[0]); v[0][4 + i] = __uint_as_float(lo[1]);
+                v[1][i] = __uint_as_float(hi[0]); v[1][4 + i] = __uint_as_float(hi[1]);
+            }
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = 16 * j + 8 * h;
+                    if constexpr (MASKED) {
+                        __attribute__((aligned(16))) bf16 mv[8];
+                        *(uint4*)mv = *(const uint4*)(mask + tile_org + loff + c);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
+                    }
+                    *(uint4*)(S + tile_org + loff + c) = make_uint4(pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3]), pack2_bf16(v[j][4], v[j][5]), pack2_bf16(v[j][6], v[j][7]));
+                }
             }
         }
+        if (!has_next) break;
+        __syncthreads();                                     // every wave is done with this tile's LDS image
+        store_lds();
+        __syncthreads();
+        tile = next;
     }
 }
 
@@ -359,7 +409,7 @@ template <int ND, int EPI>
 __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
                                                          const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_h,
                                                          int tiles_w, int act) {
-    constexpr int TD = (ND == 3) ? 4 : 1, TH = (ND == 3) ? 8 : 16, TW = (ND == 3) ? 8 : 16;     // 256 voxels
+    constexpr int TD = (ND == 3) ? C1U_TD3 : 1, TH = (ND == 3) ? C1U_TH3 : 16, TW = (ND == 3) ? C1U_TW3 : 16;     // 256 voxels; 3D: wide in x, an output row of the tile is 128 contiguous bytes
     constexpr int ID = (ND == 3) ? TD + 2 : 1, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
     constexpr int NNB = (ND == 3) ? 27 : 9, NCH = NNB * 2, TAPS = (ND == 3) ? 64 : 16, NPAR = (ND == 3) ? 8 : 4;
     constexpr int HN = (NPOS * 4 + 255) / 256;
@@ -469,7 +519,7 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
 template <typename T, typename TL, int ND, bool LSUM, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ S, const TL* __restrict__ L, float* __restrict__ ws, bool want_bias, int B, int sd, int sh, int sw,
                                                        int Cs, int ld, int lh, int lw, int tiles_d, int tiles_h, int tiles_w, int n_split, float* __restrict__ lsum_ws) {
-    constexpr int TD = (ND == 3) ? 4 : 1, TH = (ND == 3) ? 4 : 8, TW = (ND == 3) ? 8 : 16;     // 128 positions
+    constexpr int TD = (ND == 3) ? C1W_TD3 : 1, TH = (ND == 3) ? C1W_TH3 : 8, TW = (ND == 3) ? C1W_TW3 : 16;     // 128 positions; 3D: wide in x (see TileC1V)
     constexpr int ID = (ND == 3) ? 2 * TD + 2 : 1, IH = 2 * TH + 2, IW = 2 * TW + 2, NPOS = ID * IH * IW;
     constexpr int TAPS = (ND == 3) ? 64 : 16, NTS = (TAPS + 31) / 32;
     constexpr int NU = (8 * sizeof(T)) / 16, HN = (NPOS + 255) / 256;
@@ -719,23 +769,34 @@ static bool image_vec_ok(const void* L, int64_t lw, int l_dtype) {
 int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                       int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream) {
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
-    const int th = (nd == 3) ? 8 : 16, tw = (nd == 3) ? 8 : 16, td = (nd == 3) ? 4 : 1;
-    const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
-    dim3 grid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
     const int epi = CVAE_EPI_OF(act);
     if (dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype)) {          // bf16 output: the 16-byte-load form, image in its own dtype
-#define LAUNCH_DOWN_VEC_(TLT, ND, EPI)                                                                                                \
-    hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND, EPI>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
-                       (int)sw, (int)ld, (int)lh, (int)lw, tiles_h, tiles_w, act)
-#define LAUNCH_DOWN_VEC(TLT, ND)                                                                                                      \
-    do { if (epi == 0) LAUNCH_DOWN_VEC_(TLT, ND, 0); else if (epi == 1) LAUNCH_DOWN_VEC_(TLT, ND, 1); else LAUNCH_DOWN_VEC_(TLT, ND, 2); } while (0)
-        if (l_dtype == CVAE_F32) { if (nd == 3) LAUNCH_DOWN_VEC(float, 3); else LAUNCH_DOWN_VEC(float, 2); }
-        else { if (nd == 3) LAUNCH_DOWN_VEC(bf16, 3); else LAUNCH_DOWN_VEC(bf16, 2); }
+        // 512 positions per workgroup once that still leaves ~4 workgroups per CU, else 256
+        const bool big = B * ((sd + 1) / 2) * ((sh + 7) / 8) * ((sw + 31) / 32) >= 1024 || nd == 2;
+        const int ms = (nd == 3 && !big) ? 2 : 4;
+        const int td = (nd == 3) ? ms / 2 : 1, th = (nd == 3) ? 8 : 8 * ms, tw = (nd == 3) ? 32 : 16;
+        const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
+        const long long ntiles_ll = (long long)B * tiles_d * tiles_h * tiles_w;
+        if (ntiles_ll > 0x7fffffff) return CVAE_E_BADSHAPE;
+        const int ntiles = (int)ntiles_ll;
+        dim3 grid((unsigned)(ntiles < CVAE_C1_MAX_WG ? ntiles : CVAE_C1_MAX_WG), 1, 1);       // <= 4 resident workgroups per CU; each walks ntiles / grid tiles
+#define LAUNCH_DOWN_VEC__(TLT, ND, EPI, MASKED, MS)                                                                                                    \
+    hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND, EPI, MASKED, MS>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
+                       (int)sw, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, ntiles, act)
+#define LAUNCH_DOWN_VEC_(TLT, ND, EPI, MS) do { if (mask) LAUNCH_DOWN_VEC__(TLT, ND, EPI, true, MS); else LAUNCH_DOWN_VEC__(TLT, ND, EPI, false, MS); } while (0)
+#define LAUNCH_DOWN_VEC(TLT, ND, MS)                                                                                                      \
+    do { if (epi == 0) LAUNCH_DOWN_VEC_(TLT, ND, 0, MS); else if (epi == 1) LAUNCH_DOWN_VEC_(TLT, ND, 1, MS); else LAUNCH_DOWN_VEC_(TLT, ND, 2, MS); } while (0)
+        if (l_dtype == CVAE_F32) { if (nd == 2) LAUNCH_DOWN_VEC(float, 2, 4); else if (ms == 4) LAUNCH_DOWN_VEC(float, 3, 4); else LAUNCH_DOWN_VEC(float, 3, 2); }
+        else { if (nd == 2) LAUNCH_DOWN_VEC(bf16, 2, 4); else if (ms == 4) LAUNCH_DOWN_VEC(bf16, 3, 4); else LAUNCH_DOWN_VEC(bf16, 3, 2); }
 #undef LAUNCH_DOWN_VEC
 #undef LAUNCH_DOWN_VEC_
+#undef LAUNCH_DOWN_VEC__
         CVAE_CHECK_LAUNCH();
         return CVAE_OK;
     }
+    const int th = (nd == 3) ? 8 : 16, tw = (nd == 3) ? 8 : 16, td = (nd == 3) ? 4 : 1;
+    const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
+    dim3 grid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
     if (l_dtype != dtype) return CVAE_E_UNSUPPORTED;         // the element-wise form reads the image in the compute dtype
 #define LAUNCH_DOWN_C1_(T, ND, EPI)                                                                                                   \
     hipLaunchKernelGGL((down_c1_kernel<T, ND, 32, EPI>), grid, dim3(256), 0, stream, (const T*)L, w, bias, (const T*)mask, (T*)S, (int)sd, (int)sh, \
@@ -756,7 +817,7 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
     const int64_t n = B * sd * sh * sw;                     // one thread per (source voxel, channel half)
     if (n >= ((int64_t)1 << 30) || (nd == 3 && ld != 2 * sd) || lh != 2 * sh || lw != 2 * sw) return CVAE_E_UNSUPPORTED;   // exact 2x only (depth counts in 3D)
     if (dtype == CVAE_BF16) {                               // MFMA form
-        const int td = (nd == 3) ? 4 : 1, th = (nd == 3) ? 8 : 16, tw = (nd == 3) ? 8 : 16;
+        const int td = (nd == 3) ? C1U_TD3 : 1, th = (nd == 3) ? C1U_TH3 : 16, tw = (nd == 3) ? C1U_TW3 : 16;
         const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
         if ((int64_t)tiles_d * tiles_h * tiles_w > 0x7fffffff || B > 65535) return CVAE_E_BADSHAPE;
         dim3 mgrid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
@@ -791,7 +852,7 @@ int cvae_conv_wgrad_c1(const void* S, const void* L, int l_dtype, float* dW, flo
     if (Cs % 32 || Cs > 1024 * 32) return CVAE_E_UNSUPPORTED;
     if (!workspace) return CVAE_E_NULLPTR;
     if (workspace_bytes < cvae_conv_wgrad_c1_workspace_bytes(Cs, nd)) return CVAE_E_WORKSPACE;
-    const int td = (nd == 3) ? 4 : 1, th = (nd == 3) ? 4 : 8, tw = (nd == 3) ? 8 : 16;
+    const int td = (nd == 3) ? C1W_TD3 : 1, th = (nd == 3) ? C1W_TH3 : 8, tw = (nd == 3) ? C1W_TW3 : 16;
     const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
     const long long total = (long long)B * tiles_d * tiles_h * tiles_w;
     // 2 workgroups per CU (256 CUs): measured in the step at 256 / 384 / 512 / 640 / 768 / 1024 / 2048 workgroups: 58 / 45 / 36 / 49 / 43 / 39 / 44 us

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if (EPI == 1) v[j][q] = fmaxf(v[j][q], 0.f);
+                    if (EPI == 1) v[j][q] = relu_f32(v[j][q]);
                     else if (EPI == 2) v[j][q] = apply_act(v[j][q], act);
                 }
                 if (!ok) continue;
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_up_full_kernel(const T* __r
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         float x = (sizeof(T) == 1 ? v[j][q] * acc_scale : v[j][q]) + bpre[ni][j][q];
-                        if (EPI == 1) x = fmaxf(x, 0.f);
+                        if (EPI == 1) x = relu_f32(x);
                         else if (EPI == 2) x = apply_act(x, act);
                         v[j][q] = x;
                     }

@@ -6,9 +6,10 @@
 // backward, and its gradient written and re-read by the resize backward, it made ~240 MB of traffic around 2 MB of information.
 // Here the 2x resize is recomputed where it is needed from the small tensor:
 //   up2x_block_kernel<MODE 0>  recon = up(src)                     (model.forward: the volume a caller asked for)
-//   up2x_block_kernel<MODE 1>  sum (up(src) - x)^2                 (ELBO forward: reads x once, never writes the volume)
-//   up2x_block_kernel<MODE 2>  t1 = U_w^T [2 g (up(src) - x)]      (ELBO backward, stage a: reads x once)
-//   up2x_bwd_b_kernel          d src = U_d^T U_h^T t1              (stage b)
+//   up2x_block_kernel<MODE 1>  sum (up(src) - x)^2                 (ELBO forward without a backward to follow: reads x once, never writes the volume)
+//   up2x_block_kernel<MODE 3>  the same sum AND t1 = U_w^T (up(src) - x)   (ELBO forward of a training step: x is read ONCE per step; the
+//                              backward used to re-read it, 33.5 MB, in a launch of its own)
+//   up2x_bwd_b_kernel          d src = 2 g U_d^T U_h^T t1          (ELBO backward; g = the incoming loss gradient, read on the device)
 // A thread owns 4 consecutive source voxels along w and their 2 x 2 x 8 block of outputs; the 3 x 3 x 6 source neighbourhood is
 // loaded once (1.7 loads per output instead of 8).  The tap weights are the values lin_tap() of the generic kernels produces and the
 // interpolation keeps aten's association (w, then h, then d), so MODE 0 returns the same numbers as cvae_upsample_linear_fwd.
@@ -54,9 +55,9 @@ __device__ __forceinline__ Win4 win4(int i, int in, int out, float scale, bool s
 // at o = 0 (0*v0 + 1*v0 == 1*v0 + 0*v1); odd -> (v[i], v[i+1]) x (0.75, 0.25).  No per-output index arithmetic is left.
 __device__ __forceinline__ float2 even_w(int o) { return o == 0 ? make_float2(0.f, 1.f) : make_float2(0.25f, 0.75f); }
 
-// MODE 0: dst = up(src).  MODE 1: *acc_out += sum (up(src) - xin)^2.  MODE 2: t1[b][od][oh][x] = sum_ow Ww(ow -> x) gs (up(src) - xin),
-// gs = 2 * (*gout) * gscale.  D == d (2D tensors) leaves the depth axis untouched.
-struct SmallBwd {                                            // the ELBO's small terms, ridden along the backward launch (MODE 2)
+// MODE 0: dst = up(src).  MODE 1: acc_out[block] = sum (up(src) - xin)^2.  MODE 3: MODE 1 and dst = t1[b][od][oh][x] = sum_ow Ww(ow -> x) (up(src) - xin).
+// D == d (2D tensors) leaves the depth axis untouched.
+struct SmallBwd {                                            // the ELBO's small terms, ridden along the backward launch
     const float *m_hat, *m, *mu, *logvar;
     float *d_mhat, *dmu, *dlv;
     float gamma;
@@ -66,14 +67,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ src, const float* __restrict__ xin, float* __restrict__ dst,
                                                          float* __restrict__ acc_out, const float* __restrict__ gout, float gscale,
                                                          int B, int d, int h, int w, int D, int H, int W, SmallBwd sb) {
-    if (MODE == 2 && sb.dmu && (int)blockIdx.x == sb.main_blocks) {     // extra block of the backward launch: the small ELBO terms' gradients
-        // d m_hat = 2 g gamma (m_hat - m); d mu = g mu; d logvar = 0.5 g (exp(logvar) - 1), g = *gout (1 when null)
-        const float g = gout ? *gout : 1.f;
-        for (int i = threadIdx.x; i < sb.n_m; i += 256) sb.d_mhat[i] = 2.f * g * sb.gamma * (sb.m_hat[i] - sb.m[i]);
-        for (int i = threadIdx.x; i < sb.n_z; i += 256) { sb.dmu[i] = g * sb.mu[i]; sb.dlv[i] = 0.5f * g * (expf(sb.logvar[i]) - 1.f); }
-        return;
-    }
-    constexpr int J0 = (MODE == 2) ? -1 : 0, NJ = (MODE == 2) ? 10 : 8;     // outputs along w per row: local j <-> ow = ow0 + J0 + j
+    constexpr int J0 = (MODE == 3) ? -1 : 0, NJ = (MODE == 3) ? 10 : 8;     // outputs along w per row: local j <-> ow = ow0 + J0 + j
     const bool sdz = D != d;
     const float sw = (float)w / (float)W;
     const int wg = w >> 2, n = B * d * h * wg;
@@ -114,11 +108,10 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
             }
         }
         Win4 wx[4];
-        if (MODE == 2) {
+        if (MODE == 3) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) wx[q] = win4(x0 + q, w, W, sw, true);
         }
-        const float gs = (MODE == 2) ? 2.f * (gout ? *gout : 1.f) * gscale : 0.f;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             if (!sdz && a == 1) break;
@@ -149,10 +142,10 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
                         for (int j = 0; j < 8; ++j) { const float df = o[j] - xv[j]; sse += df * df; }
                     } else {
                         float g[10];
-                        g[0] = (ow0 > 0) ? gs * (o[0] - xin[rowoff + ow0 - 1]) : 0.f;
+                        g[0] = (ow0 > 0) ? o[0] - xin[rowoff + ow0 - 1] : 0.f;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) g[1 + j] = gs * (o[1 + j] - xv[j]);
-                        g[9] = (ow0 + 8 < W) ? gs * (o[9] - xin[rowoff + ow0 + 8]) : 0.f;
+                        for (int j = 0; j < 8; ++j) { g[1 + j] = o[1 + j] - xv[j]; sse += g[1 + j] * g[1 + j]; }
+                        g[9] = (ow0 + 8 < W) ? o[9] - xin[rowoff + ow0 + 8] : 0.f;
                         float t1v[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {                // outputs 2 (x0 + q) - 1 + c  ->  local g index 2 q + c
@@ -167,7 +160,7 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
             }
         }
     }
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
         __shared__ float red[4];
         sse = wave_sum(sse);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sse;
@@ -176,9 +169,19 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
     }
 }
 
-// d src[b][z][y][x .. x + 3] = sum_{od, oh} Wd(od -> z) Wh(oh -> y) t1[b][od][oh][x ..]
+// d src[b][z][y][x .. x + 3] = gs sum_{od, oh} Wd(od -> z) Wh(oh -> y) t1[b][od][oh][x ..], gs = 2 * (*gout) (1 when null).  One extra block
+// (blockIdx.x == sb.main_blocks) writes the gradients of the ELBO's small terms.
 template <typename T>
-__global__ __launch_bounds__(256) void up2x_bwd_b_kernel(const float* __restrict__ t1, T* __restrict__ dsrc, int B, int d, int h, int w, int D, int H) {
+__global__ __launch_bounds__(256) void up2x_bwd_b_kernel(const float* __restrict__ t1, T* __restrict__ dsrc, const float* __restrict__ gout, int B, int d, int h, int w,
+                                                         int D, int H, SmallBwd sb) {
+    const float g = gout ? *gout : 1.f;
+    if (sb.dmu && (int)blockIdx.x == sb.main_blocks) {
+        // d m_hat = 2 g gamma (m_hat - m); d mu = g mu; d logvar = 0.5 g (exp(logvar) - 1)
+        for (int i = threadIdx.x; i < sb.n_m; i += 256) sb.d_mhat[i] = 2.f * g * sb.gamma * (sb.m_hat[i] - sb.m[i]);
+        for (int i = threadIdx.x; i < sb.n_z; i += 256) { sb.dmu[i] = g * sb.mu[i]; sb.dlv[i] = 0.5f * g * (expf(sb.logvar[i]) - 1.f); }
+        return;
+    }
+    const float gs = 2.f * g;
     const float sd = (float)d / (float)D, sh = (float)h / (float)H;
     const int wg = w >> 2, n = B * d * h * wg;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void up2x_bwd_b_kernel(const float* __restrict
     }
     T* o = dsrc + ((size_t)(b * d + z) * h + y) * w + 4 * xg;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(acc[q]);
+    for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(gs * acc[q]);
 }
 
 // out4 = {loss, recon, m_loss, kld}: recon = sum of the per-block partial sums of up2x_block_kernel<MODE 1> (fixed order: the loss is
@@ -250,39 +253,34 @@ extern "C" int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, 
 extern "C" int64_t cvae_elbo_up2x_partials(int64_t B, int64_t d, int64_t h, int64_t w) { return (B * d * h * (w / 4) + 255) / 256; }
 
 extern "C" int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                                  float* out4, float* partial, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
+                                  float* out4, float* partial, float* t1, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
                                   int64_t n_z, int dtype, void* stream) {
     if (!up2x_ok(B, d, h, w, D, H, W) || n_m < 0 || n_z < 0 || n_m > (1 << 24) || n_z > (1 << 24)) return CVAE_E_UNSUPPORTED;
     if (!src || !x || !m_hat || !m || !mu || !logvar || !out4 || !partial) return CVAE_E_NULLPTR;
     if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)cvae_elbo_up2x_partials(B, d, h, w);
-    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 1>), dim3(grid), dim3(256), 0, st, (const bf16*)src, x, nullptr, partial, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
-    else hipLaunchKernelGGL((up2x_block_kernel<float, 1>), dim3(grid), dim3(256), 0, st, (const float*)src, x, nullptr, partial, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
+#define ELBO_FWD(T, MODE) hipLaunchKernelGGL((up2x_block_kernel<T, MODE>), dim3(grid), dim3(256), 0, st, (const T*)src, x, t1, partial, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{})
+    if (dtype == CVAE_BF16) { if (t1) ELBO_FWD(bf16, 3); else ELBO_FWD(bf16, 1); }
+    else { if (t1) ELBO_FWD(float, 3); else ELBO_FWD(float, 1); }
+#undef ELBO_FWD
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(elbo_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, (int)grid, m_hat, m, mu, logvar, gamma, out4, (int)n_m, (int)n_z);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
 
-extern "C" int cvae_elbo_up2x_bwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                                  const float* g_loss, float* t1, void* dsrc, float* d_mhat, float* dmu, float* dlv, int64_t B, int64_t d, int64_t h, int64_t w,
-                                  int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z, int dtype, void* stream) {
+extern "C" int cvae_elbo_up2x_bwd(const float* t1, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma, const float* g_loss,
+                                  void* dsrc, float* d_mhat, float* dmu, float* dlv, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W,
+                                  int64_t n_m, int64_t n_z, int dtype, void* stream) {
     if (!up2x_ok(B, d, h, w, D, H, W) || n_m < 0 || n_z < 0 || n_m > (1 << 24) || n_z > (1 << 24)) return CVAE_E_UNSUPPORTED;
-    if (!src || !x || !m_hat || !m || !mu || !logvar || !t1 || !dsrc || !d_mhat || !dmu || !dlv) return CVAE_E_NULLPTR;
+    if (!t1 || !m_hat || !m || !mu || !logvar || !dsrc || !d_mhat || !dmu || !dlv) return CVAE_E_NULLPTR;
     if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
     const SmallBwd sb{m_hat, m, mu, logvar, d_mhat, dmu, dlv, gamma, (int)n_m, (int)n_z, (int)grid};
-    if (dtype == CVAE_BF16) {
-        hipLaunchKernelGGL((up2x_block_kernel<bf16, 2>), dim3(grid + 1), dim3(256), 0, st, (const bf16*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, sb);
-        CVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(up2x_bwd_b_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const float*)t1, (bf16*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H);
-    } else {
-        hipLaunchKernelGGL((up2x_block_kernel<float, 2>), dim3(grid + 1), dim3(256), 0, st, (const float*)src, x, t1, nullptr, g_loss, 1.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, sb);
-        CVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(up2x_bwd_b_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)t1, (float*)dsrc, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H);
-    }
+    if (dtype == CVAE_BF16) hipLaunchKernelGGL(up2x_bwd_b_kernel<bf16>, dim3(grid + 1), dim3(256), 0, st, t1, (bf16*)dsrc, g_loss, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, sb);
+    else hipLaunchKernelGGL(up2x_bwd_b_kernel<float>, dim3(grid + 1), dim3(256), 0, st, t1, (float*)dsrc, g_loss, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, sb);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

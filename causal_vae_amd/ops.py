@@ -986,24 +986,25 @@ class ElboUp2x(torch.autograd.Function):
             raise RuntimeError(f"The size of tensor a {tuple(m_hat.shape)} must match the size of tensor b {tuple(m.shape)}")
         B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
         buf = torch.empty(4 + lib.cvae_elbo_up2x_partials(B, d, h, w), dtype=torch.float32, device=x.device)
-        check(lib.cvae_elbo_up2x_fwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), float(gamma), ptr(buf), buf.data_ptr() + 16, B, d, h, w, D, H, W,
+        # a backward will follow: the forward launch also leaves t1 = U_w^T (up(src) - x), so the step reads x (33.5 MB at 128^3, B = 4) once
+        t1 = torch.empty(B * D * H * w, dtype=torch.float32, device=x.device) if any(ctx.needs_input_grad[i] for i in (0, 2, 4, 5)) else None
+        check(lib.cvae_elbo_up2x_fwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), float(gamma), ptr(buf), buf.data_ptr() + 16, ptr(t1), B, d, h, w, D, H, W,
                                      m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_fwd")
-        ctx.save_for_backward(src, x, m_hat, m, mu, logvar)
+        ctx.save_for_backward(src, x, m_hat, m, mu, logvar, t1)
         ctx.gamma = float(gamma)
         ctx.set_materialize_grads(False)
         return buf[0], buf[1], buf[2], buf[3]
 
     @staticmethod
     def backward(ctx, g_loss, g_recon, g_m, g_kld):
-        src, x, m_hat, m, mu, logvar = ctx.saved_tensors
+        src, x, m_hat, m, mu, logvar, t1 = ctx.saved_tensors
         if g_recon is not None or g_m is not None or g_kld is not None:
             raise L.CvaeError("ElboUp2x back-propagates the total loss only; for a single term use loss_function on the model's recon_x")
         if g_loss is None:
             return None, None, None, None, None, None, None
         B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
-        t1 = torch.empty(B * D * H * w, dtype=torch.float32, device=x.device)
         dsrc, d_mhat, dmu, dlv = torch.empty_like(src), torch.empty_like(m_hat), torch.empty_like(mu), torch.empty_like(mu)
-        check(lib.cvae_elbo_up2x_bwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), ctx.gamma, ptr(g_loss.contiguous()), ptr(t1), ptr(dsrc),
+        check(lib.cvae_elbo_up2x_bwd(ptr(t1), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), ctx.gamma, ptr(g_loss.contiguous()), ptr(dsrc),
                                      ptr(d_mhat), ptr(dmu), ptr(dlv), B, d, h, w, D, H, W, m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_bwd")
         return dsrc, None, d_mhat, None, dmu, dlv, None
 

@@ -137,13 +137,14 @@ int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, 
  * partial: scratch of cvae_elbo_up2x_partials(B, d, h, w) floats (per-workgroup sums, added in a fixed order: no atomics). */
 int64_t cvae_elbo_up2x_partials(int64_t B, int64_t d, int64_t h, int64_t w);
 int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                       float* out4, float* partial, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
+                       float* out4, float* partial, float* t1, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
                        int64_t n_z, int dtype, void* stream);
-/* Gradients of `loss` scaled by the device scalar *g_loss (NULL = 1): dsrc (src's dtype), d_mhat, dmu, dlv.
- * t1: scratch of B*D*H*w floats. */
-int cvae_elbo_up2x_bwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                       const float* g_loss, float* t1, void* dsrc, float* d_mhat, float* dmu, float* dlv, int64_t B, int64_t d, int64_t h, int64_t w,
-                       int64_t D, int64_t H, int64_t W, int64_t n_m, int64_t n_z, int dtype, void* stream);
+/* t1 (B*D*H*w floats, or NULL when no backward follows): the same launch also leaves U_w^T (up(src) - x), the part of the backward that needs x,
+ * so that a training step reads x once.  cvae_elbo_up2x_bwd turns it into the gradients of `loss` scaled by the device scalar *g_loss (NULL = 1):
+ * dsrc (dtype), d_mhat, dmu, dlv. */
+int cvae_elbo_up2x_bwd(const float* t1, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma, const float* g_loss,
+                       void* dsrc, float* d_mhat, float* dmu, float* dlv, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W,
+                       int64_t n_m, int64_t n_z, int dtype, void* stream);
 
 /* ---- CausalVesselVAE extras (vessel_analysis/00_core/models.py:9-166): BatchNorm2d, clamp, Upsample(nearest x2) + Conv2d(k3, s1, p1) ----
  * nn.Upsample(scale_factor=2, 'nearest') followed by nn.Conv2d(Cin, Cout, 3, 1, 1) equals the transposed k4/s2/p1 product of

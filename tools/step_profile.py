@@ -2,7 +2,7 @@
 """Summarise one replayed train step from a rocprofv3 --kernel-trace CSV: kernel count, span, per-kernel totals."""
 import collections, csv, glob, os, sys
 d = sys.argv[1]
-f = max(glob.glob(os.path.join(d, "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+f = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adam_multi" in r["Kernel_Name"]]
 step = rows[idx[-3] + 1: idx[-2] + 1]
