@@ -259,9 +259,11 @@ def test_bio3d_bf16_elbo_vs_fp32_oracle(B, size):
 
 def test_bio3d_bf16_matches_bf16_rounding_oracle():
     """The same bf16 step against the oracle run with conv_dtype=bfloat16 (fp32 CPU arithmetic that rounds exactly where the bf16 build stores
-    bf16: conv operands, conv activations and their gradients).  Against THAT the kernels agree an order of magnitude tighter than against the
-    pure-fp32 oracle, for every weight gradient: the several-percent gaps of test_bio3d_bf16_elbo_vs_fp32_oracle are bf16 storage on noise-like
-    gradients, not kernel error."""
+    bf16: conv operands, conv activations and their gradients).  Against THAT every weight gradient agrees 3-5x tighter than against the pure-fp32
+    oracle (bound 5e-2 here, 0.09-0.22 there): the several-percent gaps of test_bio3d_bf16_elbo_vs_fp32_oracle are bf16 storage on noise-like
+    gradients, not kernel error.  It is not tighter still because two bf16 implementations that sum in different orders flip different ReLU
+    masks and diverge chaotically to 2-3 % in the first-layer gradients; kernel by kernel they match the rounded reference at 1e-5
+    (tools/debug_bf16_chain.py)."""
     B, size = 2, 64
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, 1, size, size, size, generator=g)
