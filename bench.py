@@ -391,6 +391,10 @@ def run_mnist(args, rank, world, dev):
     t = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float().to(dev)
     torch.manual_seed(42)
     vae, disc = CausalMorphVAE12().to(dev).train().set_compute_dtype(dtype), LatentDiscriminator().to(dev).train()
+    lin_bf16 = args.dtype == "bf16" and not args.fp32_linears
+    if lin_bf16:                                            # the config is named bf16: the large linears (1024 x 3158 x 512, ...) on bf16 MFMA operands too
+        from causal_vae_amd.layers import set_linear_math
+        set_linear_math(vae, torch.bfloat16); set_linear_math(disc, torch.bfloat16)
     ov, od = FusedAdam(vae.parameters(), lr=1e-3, device_step=True), FusedAdam(disc.parameters(), lr=1e-3, device_step=True)
     eager = lambda: mnist_step(vae, disc, ov, od, x, m, t)
     n_pre = 0
@@ -412,7 +416,7 @@ def run_mnist(args, rank, world, dev):
            "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
     res.update(timing_fields(reps, args.steps, B))
     res["config"] = {"workload": f"MNIST CausalMorphVAE12 adversarial step (D step + VAE step, mnist_test/01_baseline_causal_vae/train.py:34-93), batch {B}, "
-                                 f"{args.dtype} convs" + (" and large linears" if getattr(vae, "linear_dtype", None) == torch.bfloat16 else ", fp32 linears"),
+                                 f"{args.dtype} convs" + (" and large linears (bf16 MFMA operands, fp32 accumulate; small heads fp32)" if lin_bf16 else ", fp32 linears"),
                      "global_batch": B, "params": sum(p.numel() for p in vae.parameters()) + sum(p.numel() for p in disc.parameters())}
     res["final_loss"] = float(out[0])
     res["hip_graph"] = not args.no_graph
@@ -421,7 +425,7 @@ def run_mnist(args, rank, world, dev):
     fwd = 2.0 * B * (14 * 14 * 32 * 16 + 7 * 7 * 64 * 32 * 16 + 3158 * 512 + 512 * 20 + 10 * 128 + 128 * 12 + 22 * 3136 + 7 * 7 * 64 * 32 * 16 + 14 * 14 * 32 * 16)
     step_fl = fwd * (1 + 3)
     step_by = 28 * n_params + 3 * 4 * n_params + B * 4 * (2 * 784 * 3 + 6 * (6272 + 3136 + 3136 + 6272))
-    lin_dt = "bf16" if getattr(vae, "linear_dtype", None) == torch.bfloat16 else "f32"
+    lin_dt = "bf16" if lin_bf16 else "f32"
     roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, res["ms_per_step"], step_fl, step_by, linear_dtype=lin_dt)
     roof["linear_arithmetic"] = lin_dt
     res["roofline"], res["families"], res["kernels"] = roof, fams, kernels
@@ -504,6 +508,7 @@ def main():
     ap.add_argument("--fork-max-positions", type=int, default=0, help="with --fork: only layers with at most this many S positions per batch fork (0 = all)")
     ap.add_argument("--defer-join", action="store_true", help="with --fork: join the side stream once before the optimizer instead of after every layer")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--fp32-linears", action="store_true", help="mnist workload: keep every Linear on the exact-fp32 MFMA (default with bf16: large ones on bf16 operands)")
     ap.add_argument("--no-splitk", action="store_true", help="conv data kernels without their split-K scratch (A/B)")
     ap.add_argument("--no-defer-wgrad", action="store_true", help="compute every conv weight gradient in its own launch (A/B of the grouped end-of-backward launch)")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")

@@ -67,6 +67,9 @@ SIGNATURES = {
     "cvae_linear_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
     "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
     "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
+    "cvae_linear_fwd_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
+    "cvae_linear_bwd_data_bf16": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
+    "cvae_linear_bwd_weight_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
     "cvae_bn1d_train_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _p],
     "cvae_bn1d_train_bwd": [_p] * 8 + [_i64, _i64, _p],
     "cvae_bn1d_eval_fwd": [_p] * 6 + [_i64, _i64, _f, _p],

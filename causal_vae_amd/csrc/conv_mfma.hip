@@ -275,13 +275,26 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     constexpr int PPP = 2 * KH;                            // 8-channel pieces per position per stage
     constexpr int HN = (NPOS * PPP + NT - 1) / NT;
     int hoff[HN];                                          // element offset of the piece at chunk 0, or -1 (zero fill)
+    int hdst[HN];                                          // its LDS byte offset, or -1 (past the halo box)
+    {
+        // piece t + i NT = (position t / PPP + i PSTEP, half t % PPP): the position's (x, y, z) is stepped, not divided (the divisions were
+        // ~3 k cycles at the head of every workgroup, 10-15 % of the lifetime of the small layers' workgroups)
+        static_assert(NT % PPP == 0, "a position's pieces stay in one pass");
+        constexpr int PSTEP = NT / PPP, DX = PSTEP % IW, DY = (PSTEP / IW) % IH, DZ = PSTEP / (IW * IH);
+        const int half = t % PPP, pos0 = t / PPP;
+        int x = pos0 % IW, y = (pos0 / IW) % IH, z = pos0 / (IW * IH);
 #pragma unroll
-    for (int i = 0; i < HN; ++i) {
-        const int it = t + i * NT, half = it % PPP, pos = it / PPP;
-        const int x = pos % IW, y = (pos / IW) % IH, z = pos / (IW * IH);
-        const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
-        const bool ok = (it < NPOS * PPP) & (gz >= 0) & (gz < in_d) & (gy >= 0) & (gy < in_h) & (gx >= 0) & (gx < in_w);
-        hoff[i] = ok ? (((gz * in_h + gy) * in_w + gx) * Cin + 8 * half) : -1;
+        for (int i = 0; i < HN; ++i) {
+            const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
+            const bool inbox = z < ID;
+            const bool ok = inbox & (gz >= 0) & (gz < in_d) & (gy >= 0) & (gy < in_h) & (gx >= 0) & (gx < in_w);
+            hoff[i] = ok ? (((gz * in_h + gy) * in_w + gx) * Cin + 8 * half) : -1;
+            hdst[i] = inbox ? (half * PLANE + hslot(z, y, x)) * FB : -1;
+            x += DX; if (x >= IW) { x -= IW; y += 1; }
+            y += DY; if (y >= IH) { y -= IH; z += 1; }
+            if (y >= IH) { y -= IH; z += 1; }
+            z += DZ;
+        }
     }
     const T* in_b = in + (size_t)b * in_d * in_h * in_w * Cin;
     constexpr int BP = (4 * KH * 2 * BN) / NT;             // weight pieces per thread per tap group
@@ -333,6 +346,37 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     };
     STAMP(1);
     const int chunk_per = nchunks / ksplit;                 // host guarantees ksplit divides nchunks
+    // what the epilogue needs from memory — this lane's bias values and ReLU-mask pieces — is requested now, not in the epilogue, where each was
+    // an exposed global round trip at the end of every workgroup
+    float bpre[NI][2][8];
+    Piece<TO> mpre[MI][NI][2];
+    const int out_d = UP ? g.ld : g.sd, out_h = UP ? g.lh : g.sh, out_w = UP ? g.lw : g.sw;
+    if (ksplit == 1) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bpre[ni][j][q] = bias ? bias[c + q] : 0.f;
+            }
+        if (mask) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ms = wm * MI + mi;
+                const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
+                int od, oh, ow;
+                if (UP) { od = (ND == 3) ? 2 * (o0d + d) + prd : 0; oh = 2 * (o0h + hh) + prh; ow = 2 * (o0w + w) + prw; }
+                else { od = o0d + d; oh = o0h + hh; ow = o0w + w; }
+                const bool ok = od < out_d && oh < out_h && ow < out_w;
+                const size_t pidx = ok ? ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout : 0;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) piece_load_raw<TO>(mpre[mi][ni][j], mask + pidx + n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h);
+            }
+        }
+    }
     // UP with 32-channel stages (long K loops on small grids): the NEXT stage's halo is requested right after this stage's LDS image is
     // complete and lands under the tap loop (-5 %).  Elsewhere the prefetch loses: DOWN stages 14 pieces per thread (registers), and the
     // Cin = 64 `up` launches fill the chip, where the co-resident workgroups already hide the stage (+4 % measured).
@@ -394,10 +438,8 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
             __syncthreads();                               // previous chunk's readers are done with halo + B buffers
             if (chunk - ks * chunk_per < 8) STAMP(2 + 3 * (chunk - ks * chunk_per));
 #pragma unroll
-            for (int i = 0; i < HN; ++i) {
-                const int it = t + i * NT, pos = it / PPP;
-                if (it < NPOS * PPP) piece_store<T>(hp[i], halo + ((size_t)(it % PPP) * PLANE + hslot(pos / (IW * IH), (pos / IW) % IH, pos % IW)) * FB);
-            }
+            for (int i = 0; i < HN; ++i)
+                if (hdst[i] >= 0) piece_store<T>(hp[i], halo + hdst[i]);
             if constexpr (!BD) store_b(pb0, 0);
         }
         __syncthreads();
@@ -454,7 +496,6 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     // positions: lane (r, h) holds, for position r of each M sub-tile, channels (e & 3) + 8 (e >> 2) + 4 h of each 32-channel N
     // sub-tile.  Two v_permlane32_swap per register pair regroup them so that the lane owns channels 8h..8h+7 and 16+8h..23+8h:
     // two 8-channel pieces, each ONE 16-byte (bf16) store and ONE 16-byte mask load instead of eight 2-byte ones.
-    const int out_d = UP ? g.ld : g.sd, out_h = UP ? g.lh : g.sh, out_w = UP ? g.lw : g.sw;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int ms = wm * MI + mi;                                            // same lane -> position map as pbase
@@ -491,34 +532,29 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
-                if constexpr (sizeof(T) == 1) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[j][q] *= acc_scale;
-                }
-                if (bias) {
-                    const float4 b0 = *(const float4*)(bias + c), b1 = *(const float4*)(bias + c + 4);
-                    v[j][0] += b0.x; v[j][1] += b0.y; v[j][2] += b0.z; v[j][3] += b0.w;
-                    v[j][4] += b1.x; v[j][5] += b1.y; v[j][6] += b1.z; v[j][7] += b1.w;
-                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if (EPI == 1) v[j][q] = relu_f32(v[j][q]);
-                    else if (EPI == 2) v[j][q] = apply_act(v[j][q], act);
+                    float x = (sizeof(T) == 1 ? v[j][q] * acc_scale : v[j][q]) + bpre[ni][j][q];
+                    if (EPI == 1) x = relu_f32(x);
+                    else if (EPI == 2) x = apply_act(x, act);
+                    v[j][q] = x;
                 }
                 if (!ok) continue;
                 if (mask) {
-                    Piece<TO> mp;
-                    piece_load<TO>(mp, mask + pidx + c, true);
-                    const TO* mv = (const TO*)&mp;
+                    const TO* mv = (const TO*)&mpre[mi][ni][j];
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                         if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
                 }
-                Piece<TO> op;
-                TO* ov = (TO*)&op;
+                if constexpr (sizeof(TO) == 2 && sizeof(T) == 2) {           // bf16: one v_cvt_pk_bf16_f32 per pair
+                    *(uint4*)(out + pidx + c) = make_uint4(pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3]), pack2_bf16(v[j][4], v[j][5]), pack2_bf16(v[j][6], v[j][7]));
+                } else {
+                    Piece<TO> op;
+                    TO* ov = (TO*)&op;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(sizeof(T) == 1 ? v[j][q] * out_scale : v[j][q]);
-                piece_store<TO>(op, (char*)(out + pidx + c));
+                    for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(sizeof(T) == 1 ? v[j][q] * out_scale : v[j][q]);
+                    piece_store<TO>(op, (char*)(out + pidx + c));
+                }
             }
         }
     }

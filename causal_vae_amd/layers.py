@@ -73,9 +73,11 @@ class ConvTranspose3d(_ConvBase, nn.ConvTranspose3d):
 
 
 class Linear(nn.Linear):
+    math = None            # torch.bfloat16 (set_linear_math): bf16 MFMA operands for large-batch products; None / float32: exact fp32
+
     def forward(self, x, act=None):
         require_gpu(x)
-        return ops.Linear.apply(x, self.weight, self.bias, act)
+        return ops.Linear.apply(x, self.weight, self.bias, act, self.math)
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -351,6 +353,18 @@ class UpConvStack(nn.Sequential):
     def forward(self, h):
         require_gpu(h)
         return ops.FromChannelsLast.apply(self.forward_cl(h), 2)
+
+
+def set_linear_math(module, dtype):
+    """torch.bfloat16: every Linear of `module` multiplies with bf16 MFMA operands (fp32 accumulate, fp32 tensors) where the batch is above the
+    skinny range and the product is large enough to be matrix-bound (ops.LINEAR_BF16_MIN_WORK) — the MNIST heads at batch 1024.  torch.float32
+    (default): exact-fp32 MFMA everywhere, which the 3D ELBO target (1e-4) needs.  Independent of set_compute_dtype (the convs)."""
+    if dtype not in (torch.float32, torch.bfloat16, None):
+        raise CvaeError(f"linear math must be float32 or bfloat16, got {dtype}")
+    for m in module.modules():
+        if isinstance(m, Linear):
+            m.math = torch.bfloat16 if dtype == torch.bfloat16 else None
+    return module
 
 
 def set_compute_dtype(module, dtype):

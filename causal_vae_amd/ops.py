@@ -633,28 +633,37 @@ class UpsampleLinear(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ linear / BN
+LINEAR_BF16_MIN_WORK = 1 << 24      # M * K * N below which a bf16-math Linear stays on the fp32 kernels (launch-bound there, and exact)
+
+
 class Linear(torch.autograd.Function):
-    """nn.Linear + optional fused activation (fp32, exact-fp32 MFMA)."""
+    """nn.Linear + optional fused activation.  fp32 tensors always; math = torch.float32: exact-fp32 MFMA (default);
+    math = torch.bfloat16: operands rounded to bf16 inside the GEMM kernels (fp32 accumulate) for batches > 16 and M*K*N >= LINEAR_BF16_MIN_WORK."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, math=None):
         L.require_gpu(x, weight, bias)
         if x.dtype != torch.float32:
             raise L.CvaeError("linear layers run in float32")
         x = x.contiguous()
         M, K = x.shape
         N = weight.shape[0]
+        b16 = math == torch.bfloat16 and M > 16 and M * K * N >= LINEAR_BF16_MIN_WORK
         y = _empty((M, N), torch.float32, x)
         _t, wp, wb = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 0), x)
-        check(L.timed(f"linear_fwd M{M} K{K} N{N}", lib.cvae_linear_fwd, ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()), "linear_fwd")
+        if b16:
+            check(L.timed(f"linear_fwd M{M} K{K} N{N} bf16", lib.cvae_linear_fwd_bf16, ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()),
+                  "linear_fwd_bf16")
+        else:
+            check(L.timed(f"linear_fwd M{M} K{K} N{N}", lib.cvae_linear_fwd, ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()), "linear_fwd")
         ctx.save_for_backward(x, weight, y)
-        ctx.cfg = (act, bias is not None)
+        ctx.cfg = (act, bias is not None, b16)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
-        act, has_bias = ctx.cfg
+        act, has_bias, b16 = ctx.cfg
         g = g.contiguous()
         M, K = x.shape
         N = weight.shape[0]
@@ -670,16 +679,23 @@ class Linear(torch.autograd.Function):
                 if has_bias and ctx.needs_input_grad[2]:
                     db = _empty((N,), torch.float32, g)
                 _t, wp, wb = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 2), g)
-                check(L.timed(f"linear_bwd_weight M{M} K{K} N{N}", lib.cvae_linear_bwd_weight, ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, ya, ac, wp, wb, stream()),
-                      "linear_bwd_weight")
+                if b16:
+                    check(L.timed(f"linear_bwd_weight M{M} K{K} N{N} bf16", lib.cvae_linear_bwd_weight_bf16, ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, wp, wb, stream()),
+                          "linear_bwd_weight_bf16")
+                else:
+                    check(L.timed(f"linear_bwd_weight M{M} K{K} N{N}", lib.cvae_linear_bwd_weight, ptr(g), ptr(x), ptr(dw), ptr(db), M, K, N, N, K, ya, ac, wp, wb, stream()),
+                          "linear_bwd_weight")
             elif has_bias and ctx.needs_input_grad[2]:
                 db = _channel_sum(_act_bwd(g, y, act) if fused else g)
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), torch.float32, g)
             _t2, wp2, wb2 = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 1), g)
-            check(L.timed(f"linear_bwd_data M{M} K{K} N{N}", lib.cvae_linear_bwd_data, ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, wp2, wb2, stream()), "linear_bwd_data")
+            if b16:
+                check(L.timed(f"linear_bwd_data M{M} K{K} N{N} bf16", lib.cvae_linear_bwd_data_bf16, ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, wp2, wb2, stream()), "linear_bwd_data_bf16")
+            else:
+                check(L.timed(f"linear_bwd_data M{M} K{K} N{N}", lib.cvae_linear_bwd_data, ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, wp2, wb2, stream()), "linear_bwd_data")
         fork.join(dw, db)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class BatchNorm1dTrain(torch.autograd.Function):

@@ -333,6 +333,16 @@ int cvae_softmax_ce_bwd(const float* logits, const int64_t* target, const float*
 int cvae_uniform_kl_fwd(const float* logits, float* out, int64_t B, int64_t C, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_uniform_kl_bwd(const float* logits, const float* gout, float* dlogits, int64_t B, int64_t C, void* stream);
 
+/* The same three products with bf16 MFMA operands (fp32 tensors in memory, rounded to bf16 on the way into LDS, fp32 accumulate and output):
+ * 16x the matrix rate of the exact-fp32 form, relative error ~2^-9 per operand.  M > 16 only (smaller batches are HBM-bound skinny kernels:
+ * CVAE_E_UNSUPPORTED); no fused activation gradient; workspace as for the fp32 entry points (cvae_linear_workspace_bytes). */
+int cvae_linear_fwd_bf16(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N, int64_t x_stride, int64_t y_stride,
+                         int act, void* workspace, size_t workspace_bytes, void* stream);
+int cvae_linear_bwd_data_bf16(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N, int64_t dy_stride, int64_t dx_stride,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int cvae_linear_bwd_weight_bf16(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N, int64_t dy_stride,
+                                int64_t x_stride, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------------------------- */
 /* torch.optim.Adam (no weight decay / amsgrad) on flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t
  * computed by the caller.  grad_scale: optional device scalar multiplied into g first (gradient clipping). */

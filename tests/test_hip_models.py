@@ -843,8 +843,9 @@ def test_vessel2d_train_step_clip_and_adam_follow_torch():
         assert float((p - q).abs().mean()) <= 3e-5, k
 
 
-@pytest.mark.parametrize("B,dtype,tol", [(128, torch.float32, 1e-4), (1024, torch.float32, 1e-4), (1024, torch.bfloat16, 2e-3)], ids=["b128-f32", "b1024-f32", "b1024-bf16"])
-def test_mnist_batch_1024_step_matches_oracle(B, dtype, tol):
+@pytest.mark.parametrize("B,dtype,tol,lin", [(128, torch.float32, 1e-4, None), (1024, torch.float32, 1e-4, None), (1024, torch.bfloat16, 2e-3, None),
+                                              (1024, torch.bfloat16, 2e-3, torch.bfloat16)], ids=["b128-f32", "b1024-f32", "b1024-bf16", "b1024-bf16-linears"])
+def test_mnist_batch_1024_step_matches_oracle(B, dtype, tol, lin):
     """BASELINE.json configs[0] (batch 128, fp32: the reference's own mnist_test/01 configuration, config.py BATCH_SIZE) and configs[1] (the MNIST
     CausalMorphVAE12 adversarial step at batch 1024; fp32 parity and bf16 = the configuration named there) against the CPU oracle's step on the
     same batch: every loss term."""
@@ -856,6 +857,9 @@ def test_mnist_batch_1024_step_matches_oracle(B, dtype, tol):
     vae, disc = CausalMorphVAE12().to(DEV).train(), LatentDiscriminator().to(DEV).train()
     vae.load_state_dict(sd_v); disc.load_state_dict(sd_d)
     vae.set_compute_dtype(dtype)
+    if lin is not None:                                      # the large linears (1024 x 3158 x 512, 1024 x 22 x 3136) on bf16 MFMA operands too
+        from causal_vae_amd.layers import set_linear_math
+        set_linear_math(vae, lin); set_linear_math(disc, lin)
     ref = oracle.mnist_adversarial_step(sd_v, sd_d, x, m, t, *eps, apply_update=False)
     opt_vae, opt_d = FusedAdam(vae.parameters(), lr=1e-3), FusedAdam(disc.parameters(), lr=1e-3)
     # the oracle's VAE half uses the UPDATED discriminator; apply_update=False keeps both on the initial weights, so mirror that: lr = 0 for D

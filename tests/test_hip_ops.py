@@ -307,6 +307,39 @@ def test_linear_forward_backward(M, K, N, act):
     close(bg.grad.cpu(), gb_ref, torch.float32, "db")
 
 
+@pytest.mark.parametrize("M,K,N,act", [(1024, 3158, 512, "relu"), (1024, 22, 3136, "relu"), (200, 700, 130, None), (64, 4096, 96, "leaky02")])
+def test_linear_bf16_math_forward_backward(M, K, N, act):
+    """ops.Linear(math=bfloat16): the GEMMs round their operands to bf16 on the way into LDS and accumulate in fp32.  Reference: fp32 CPU products of
+    the ROUNDED operands (x, W for the forward; dy, W for dx; dy, x for dW), so only summation order differs: the fp32 tolerances of `close`.
+    (200, 700, 130) has ragged tiles in every dimension; the bias gradient stays an fp32 column sum of the unrounded dy."""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    f = {"relu": F.relu, "leaky02": lambda v: F.leaky_relu(v, 0.2), None: lambda v: v}[act]
+    xr, wr = rnd(x, torch.bfloat16), rnd(w, torch.bfloat16)
+    y_ref = f(F.linear(xr, wr, b))
+    pre = F.linear(xr, wr, b)
+    gpre = gy * {"relu": (pre > 0).float(), "leaky02": torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.2)), None: torch.ones_like(pre)}[act]
+    gr = rnd(gpre, torch.bfloat16)
+    gx_ref, gw_ref, gb_ref = gr @ wr, gr.t() @ xr, gpre.sum(0)
+    old, ops.LINEAR_BF16_MIN_WORK = ops.LINEAR_BF16_MIN_WORK, 0
+    try:
+        xg, wg, bg = (v.to(DEV).requires_grad_(True) for v in (x, w, b))
+        y = ops.Linear.apply(xg, wg, bg, act, torch.bfloat16)
+        close(y.cpu(), y_ref, torch.float32, "y", scale=float(y_ref.abs().max()) * 4)
+        # the activation mask comes from the GPU's own y: compare the gradients where both agree on it (a pre-activation within rounding of 0 may flip)
+        y.backward(gy.to(DEV))
+    finally:
+        ops.LINEAR_BF16_MIN_WORK = old
+    l2 = lambda a, r: float((a - r).norm() / r.norm())
+    assert l2(xg.grad.cpu(), gx_ref) < 2e-3 and l2(wg.grad.cpu(), gw_ref) < 2e-3, (l2(xg.grad.cpu(), gx_ref), l2(wg.grad.cpu(), gw_ref))
+    close(bg.grad.cpu(), gb_ref, torch.float32, "db", scale=float(gb_ref.abs().max()) * 4)
+    # and against the exact fp32 product: the stated bf16-operand error (2^-9 per operand, random: ~1e-3 relative in L2)
+    assert l2(y.detach().cpu(), f(F.linear(x, w, b))) < 5e-3
+
+
 @pytest.mark.parametrize("B", [2, 4, 100])
 def test_batchnorm1d_train_and_eval(B):
     g = torch.Generator().manual_seed(8)
