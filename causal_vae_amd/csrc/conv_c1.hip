@@ -156,10 +156,6 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
 // the staging index arithmetic are paid once per 128 positions of a wave), the bias rides in as the accumulators' initial value, the ReLU-mask
 // code exists only in the MASKED instantiation, and the staging loop steps its (row, vector) coordinates instead of dividing.
 // 3D tile of the single-channel weight gradient: 2 x 2 x 32 positions — its image rows are 72 contiguous elements, not 24
-// 3D tile of the single-channel transposed conv: 4 x 8 x 8 voxels (a 2 x 4 x 32 tile measured no faster at B = 4 and 2 % slower at 240 rows: 36 % more halo)
-#define C1U_TD3 4
-#define C1U_TH3 8
-#define C1U_TW3 8
 #define C1W_TD3 2
 #define C1W_TH3 2
 #define C1W_TW3 32
@@ -399,110 +395,139 @@ __global__ __launch_bounds__(256) void up_c1_kernel(const T* __restrict__ S, con
 // -------------------------------------------------------------------------------------- up, Cl == 1, bf16 on the MFMA
 // The same product as a GEMM per source voxel q: out[2 q + p] = sum_{o in {-1,0,1}^nd} sum_c S[q + o][c] Wm[(o, c)][p], with
 // Wm[(o, c)][p] = W[c][tap(p, o)] where parity p reaches neighbour o (per dimension o = p - 1 + a, a in {0, 1}, tap k = 3 - p - 2 a)
-// and 0 elsewhere: M = voxels, K = 3^nd * 32, N = 2^nd parities (rows 0..7 of a 32-row MFMA tile; the other rows repeat them and are
-// ignored).  8/27 of Wm is non-zero, but the layer is ~3 us of MFMA time either way, against ~30 us for the scalar form above, which
-// was bound by its 1024 LDS weight reads per thread.  Weights ride as the A operand, so D rows are parities and D columns voxels: lane
-// (r, h) ends with the 2 x 2 (py, px) outputs of voxel r on plane pz = h — two 4-byte stores.
-// LDS: the 32-channel halo as 4 planes of 16-byte pieces (plane = channel piece: consecutive voxels are 16 B apart, conflict-free
-// ds_read_b128), and Wm^T as [chunk = (o, channel half)][h][parity] 16-byte rows built in-kernel from the fp32 master.
-template <int ND, int EPI>
+// and 0 elsewhere: M = voxels, K = 3^nd * 32, N = 2^nd parities.  8/27 of Wm is non-zero, which is cheaper than the 1024 LDS weight reads per
+// thread of the scalar form above (30 -> 14 us at B = 4).  Round 2: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 — the 8 parities fill half of
+// its 16 rows instead of a quarter of 32, and one instruction takes all 32 channels of a neighbour: 27 MFMAs of 16 cycles per 16 voxels where
+// there were 54 of 32 cycles per 32 (the layer is MFMA-bound at the 240-row decode sweep: 0.45 of its 1.2 ms) — and a workgroup builds its
+// weight fragments ONCE and walks several tiles with the next halo in flight.
+//   A (weights): lane l -> row l % 16 (parity; rows 8..15 re-read rows 0..7 and are ignored), k = 8 (l / 16) + j
+//   B (voxels) : lane l -> column l % 16 (voxel), k = 8 (l / 16) + j            D: lane l -> column l % 16, rows 4 (l / 16) + r
+// so lanes 0..15 end with parities 0..3 = the (py, px) block of plane pz = 0 of their voxel, lanes 16..31 with pz = 1 (3D); two 4-byte stores.
+// LDS: the 32-channel halo as 4 planes of 16-byte pieces, plane pitch a multiple of 16 slots and 16 consecutive-x voxels per MFMA column set,
+// so every ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) falls on 16 different bank slots; Wm^T as [neighbour][k group][parity] rows.
+template <int ND> struct TileC1U;
+template <> struct TileC1U<3> { static constexpr int TD = 2, TH = 8, TW = 16; };
+template <> struct TileC1U<2> { static constexpr int TD = 1, TH = 16, TW = 16; };
+
+template <int ND, int EPI, bool MASKED>
 __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_h,
-                                                         int tiles_w, int act) {
-    constexpr int TD = (ND == 3) ? C1U_TD3 : 1, TH = (ND == 3) ? C1U_TH3 : 16, TW = (ND == 3) ? C1U_TW3 : 16;     // 256 voxels; 3D: wide in x, an output row of the tile is 128 contiguous bytes
-    constexpr int ID = (ND == 3) ? TD + 2 : 1, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
-    constexpr int NNB = (ND == 3) ? 27 : 9, NCH = NNB * 2, TAPS = (ND == 3) ? 64 : 16, NPAR = (ND == 3) ? 8 : 4;
+                                                         const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_d, int tiles_h,
+                                                         int tiles_w, int ntiles, int act) {
+    using TLU = TileC1U<ND>;
+    constexpr int TD = TLU::TD, TH = TLU::TH, TW = TLU::TW;     // 256 voxels
+    static_assert(TW == 16 && TD * TH * TW == 256, "a column set is 16 consecutive-x voxels");
+    constexpr int ID = (ND == 3) ? TD + 2 : 1, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW, PPITCH = (NPOS + 15) / 16 * 16;
+    constexpr int NNB = (ND == 3) ? 27 : 9, TAPS = (ND == 3) ? 64 : 16, NPAR = (ND == 3) ? 8 : 4;
     constexpr int HN = (NPOS * 4 + 255) / 256;
-    __shared__ uint4 halo[4][NPOS];
-    __shared__ __attribute__((aligned(16))) bf16 wfr[NCH * 2 * 8 * 8];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5, b = blockIdx.z;
-    int tile = blockIdx.x;
-    const int tw_i = tile % tiles_w; tile /= tiles_w;
-    const int th_i = tile % tiles_h; tile /= tiles_h;
-    const int o0d = tile * TD, o0h = th_i * TH, o0w = tw_i * TW;
-    // ---- halo: all loads in flight, then the weight rows are built while they land ----
+    __shared__ uint4 halo[4 * PPITCH];
+    __shared__ __attribute__((aligned(16))) bf16 wfr[NNB * 4 * 8 * 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, kq = lane >> 4;
     uint4 hv[HN];
+    auto issue_loads = [&](int tile) {                         // halo of `tile`: piece t % 4 of positions t / 4 + 64 i (stepped, not divided)
+        const int tw_i = tile % tiles_w; tile /= tiles_w;
+        const int th_i = tile % tiles_h; tile /= tiles_h;
+        const int td_i = tile % tiles_d, b = tile / tiles_d;
+        const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
+        constexpr int DX = 64 % IW, DY = (64 / IW) % IH, DZ = 64 / (IW * IH);
+        const int piece = t & 3, pos0 = t >> 2;
+        int x = pos0 % IW, y = (pos0 / IW) % IH, z = pos0 / (IW * IH);
+        const bf16* Sb = S + (size_t)b * sd * sh * sw * 32 + piece * 8;
 #pragma unroll
-    for (int i = 0; i < HN; ++i) {
-        const int it = t + i * 256, piece = it & 3, pos = min(it >> 2, NPOS - 1);
-        const int x = pos % IW, y = pos / IW % IH, z = pos / (IW * IH);
-        const int gz = (ND == 3) ? o0d - 1 + z : 0, gy = o0h - 1 + y, gx = o0w - 1 + x;
-        const bool ok = (gz >= 0) & (gz < sd) & (gy >= 0) & (gy < sh) & (gx >= 0) & (gx < sw);
-        const uint4 v = *(const uint4*)(S + ((((size_t)b * sd + min(max(gz, 0), sd - 1)) * sh + min(max(gy, 0), sh - 1)) * sw + min(max(gx, 0), sw - 1)) * 32 + piece * 8);
-        hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-    }
-    for (int row = t; row < NCH * 2 * 8; row += 256) {      // one 16-byte row (8 channels of one (chunk, h, parity)) per pass
-        const int p = row & 7, hh = (row >> 3) & 1, chunk = row >> 4, nb = chunk >> 1, kc = chunk & 1;
-        const int c0 = kc * 16 + 8 * hh;
+        for (int i = 0; i < HN; ++i) {
+            const int gz = (ND == 3) ? o0d - 1 + z : 0, gy = o0h - 1 + y, gx = o0w - 1 + x;
+            const bool ok = (z < ID) & (gz >= 0) & (gz < sd) & (gy >= 0) & (gy < sh) & (gx >= 0) & (gx < sw);
+            const uint4 v = *(const uint4*)(Sb + (((size_t)min(max(gz, 0), sd - 1) * sh + min(max(gy, 0), sh - 1)) * sw + min(max(gx, 0), sw - 1)) * 32);
+            hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+            x += DX; if (x >= IW) { x -= IW; y += 1; }
+            y += DY; if (y >= IH) { y -= IH; z += 1; }
+            if (y >= IH) { y -= IH; z += 1; }
+            z += DZ;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int it = t + i * 256;
+            if (it < NPOS * 4) halo[(it & 3) * PPITCH + (it >> 2)] = hv[i];
+        }
+    };
+    int tile = blockIdx.x;
+    issue_loads(tile);
+    for (int row = t; row < NNB * 4 * 8; row += 256) {       // Wm^T, once per workgroup: one 16-byte row = 8 channels of (neighbour, k group, parity)
+        const int p = row & 7, q = (row >> 3) & 3, nb = row >> 5;
+        const int c0 = 8 * q;
         const int ox = nb % 3 - 1, oy = nb / 3 % 3 - 1, oz = (ND == 3) ? nb / 9 - 1 : 0;
         const int px = p & 1, py = (p >> 1) & 1, pz = (ND == 3) ? (p >> 2) : 0;
         const int ax = ox - px + 1, ay = oy - py + 1, az = oz - pz + 1;
         const bool valid = (p < NPAR) & (ax >= 0) & (ax <= 1) & (ay >= 0) & (ay <= 1) & ((ND == 2) | ((az >= 0) & (az <= 1)));
         const int kw = 3 - px - 2 * ax, kh = 3 - py - 2 * ay, kd = (ND == 3) ? 3 - pz - 2 * az : 0;
-        union { uint4 u; bf16 e[8]; } o;
-        o.u = make_uint4(0u, 0u, 0u, 0u);
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
         if (valid) {
             const float* wp = w + c0 * TAPS + (kd * 4 + kh) * 4 + kw;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o.e[j] = from_f32<bf16>(wp[j * TAPS]);
+            o = make_uint4(pack2_bf16(wp[0], wp[TAPS]), pack2_bf16(wp[2 * TAPS], wp[3 * TAPS]), pack2_bf16(wp[4 * TAPS], wp[5 * TAPS]), pack2_bf16(wp[6 * TAPS], wp[7 * TAPS]));
         }
-        *(uint4*)(wfr + row * 8) = o.u;
+        *(uint4*)(wfr + row * 8) = o;
     }
-#pragma unroll
-    for (int i = 0; i < HN; ++i) {
-        const int it = t + i * 256;
-        if (it < NPOS * 4) halo[it & 3][it >> 2] = hv[i];
-    }
-    __syncthreads();
-    // ---- each wave: 2 sub-tiles of 32 voxels, 2 * 3^nd k-chunks of 16 channels ----
-    int pb[2];
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        const int m = (wave * 2 + ms) * 32 + r;
-        pb[ms] = ((m / (TW * TH)) * IH + m / TW % TH) * IW + m % TW;
-    }
-    f32x16 acc[2];
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[ms][e] = 0.f;
-#pragma unroll
-    for (int nb = 0; nb < NNB; ++nb) {
-        const int off = (((ND == 3) ? nb / 9 : 0) * IH + nb / 3 % 3) * IW + nb % 3;
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            union { uint4 u; bf16x8 v; } a, b0, b1;
-            a.u = *(const uint4*)(wfr + (((nb * 2 + kc) * 2 + h) * 8 + (r & 7)) * 8);
-            b0.u = halo[kc * 2 + h][pb[0] + off];
-            b1.u = halo[kc * 2 + h][pb[1] + off];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b0.v, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b1.v, acc[1], 0, 0, 0);
-        }
-    }
-    // ---- epilogue: D row (parity) = e + 4 h for e < 4: lane (r, h) holds (py, px) = (e >> 1, e & 1) on plane pz = h (2D: h == 0 only) ----
     const float bz = bias ? bias[0] : 0.f;
     const int ld = (ND == 3) ? 2 * sd : 1, lh = 2 * sh, lw = 2 * sw;
-    if (ND == 2 && h == 1) return;
+    store_lds();
+    __syncthreads();
+    // each wave: 4 column sets of 16 voxels (one x-row of the tile each): cs -> tile row (wave * 4 + cs) = (d, hh)
+    int pbv[4];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        const int m = (wave * 2 + ms) * 32 + r;
-        const int qz = o0d + m / (TW * TH), qy = o0h + m / TW % TH, qx = o0w + m % TW;
-        if (qz >= sd || qy >= sh || qx >= sw) continue;
-        const int lz = (ND == 3) ? 2 * qz + h : 0;
+    for (int cs = 0; cs < 4; ++cs) {
+        const int rowi = wave * 4 + cs;
+        pbv[cs] = ((rowi / TH) * IH + rowi % TH) * IW + col;
+    }
+    while (true) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) issue_loads(next);
+        int tt = tile;
+        const int tw_i = tt % tiles_w; tt /= tiles_w;
+        const int th_i = tt % tiles_h; tt /= tiles_h;
+        const int td_i = tt % tiles_d, b = tt / tiles_d;
+        const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
+        f32x4 acc[4];
 #pragma unroll
-        for (int py = 0; py < 2; ++py) {
-            const size_t idx = (((size_t)b * ld + lz) * lh + 2 * qy + py) * lw + 2 * qx;
-            float v0 = apply_act_t<EPI>(acc[ms][2 * py] + bz, act), v1 = apply_act_t<EPI>(acc[ms][2 * py + 1] + bz, act);
-            if (mask) {
-                union { uint32_t u; bf16 e[2]; } mk;
-                mk.u = *(const uint32_t*)(mask + idx);
-                if (!(to_f32(mk.e[0]) > 0.f)) v0 = 0.f;
-                if (!(to_f32(mk.e[1]) > 0.f)) v1 = 0.f;
-            }
-            union { uint32_t u; bf16 e[2]; } o;
-            o.e[0] = from_f32<bf16>(v0); o.e[1] = from_f32<bf16>(v1);
-            *(uint32_t*)(L + idx) = o.u;
+        for (int cs = 0; cs < 4; ++cs) acc[cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) {
+            const int off = (((ND == 3) ? nb / 9 : 0) * IH + nb / 3 % 3) * IW + nb % 3;
+            union { uint4 u; bf16x8 v; } a, bv[4];
+            a.u = *(const uint4*)(wfr + ((nb * 4 + kq) * 8 + (col & 7)) * 8);
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) bv[cs].u = halo[kq * PPITCH + pbv[cs] + off];
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) acc[cs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bv[cs].v, acc[cs], 0, 0, 0);
         }
+        // ---- epilogue: lanes 0..15 hold (py, px) = (r >> 1, r & 1) of plane pz = 0, lanes 16..31 of pz = 1 (2D: lanes 0..15 only) ----
+        if (kq < ((ND == 3) ? 2 : 1)) {
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) {
+                const int rowi = wave * 4 + cs;
+                const int qz = o0d + rowi / TH, qy = o0h + rowi % TH, qx = o0w + col;
+                if (qz >= sd || qy >= sh || qx >= sw) continue;
+                const int lz = (ND == 3) ? 2 * qz + kq : 0;
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const size_t idx = (((size_t)b * ld + lz) * lh + 2 * qy + py) * lw + 2 * qx;
+                    float v0 = apply_act_t<EPI>(acc[cs][2 * py] + bz, act), v1 = apply_act_t<EPI>(acc[cs][2 * py + 1] + bz, act);
+                    if constexpr (MASKED) {
+                        union { uint32_t u; bf16 e[2]; } mk;
+                        mk.u = *(const uint32_t*)(mask + idx);
+                        if (!(to_f32(mk.e[0]) > 0.f)) v0 = 0.f;
+                        if (!(to_f32(mk.e[1]) > 0.f)) v1 = 0.f;
+                    }
+                    *(uint32_t*)(L + idx) = pack2_bf16(v0, v1);
+                }
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();                                     // every wave is done with this tile's LDS image
+        store_lds();
+        __syncthreads();
+        tile = next;
     }
 }
 
@@ -817,15 +842,19 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
     const int64_t n = B * sd * sh * sw;                     // one thread per (source voxel, channel half)
     if (n >= ((int64_t)1 << 30) || (nd == 3 && ld != 2 * sd) || lh != 2 * sh || lw != 2 * sw) return CVAE_E_UNSUPPORTED;   // exact 2x only (depth counts in 3D)
     if (dtype == CVAE_BF16) {                               // MFMA form
-        const int td = (nd == 3) ? C1U_TD3 : 1, th = (nd == 3) ? C1U_TH3 : 16, tw = (nd == 3) ? C1U_TW3 : 16;
+        const int td = (nd == 3) ? 2 : 1, th = (nd == 3) ? 8 : 16, tw = 16;                 // TileC1U
         const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
-        if ((int64_t)tiles_d * tiles_h * tiles_w > 0x7fffffff || B > 65535) return CVAE_E_BADSHAPE;
-        dim3 mgrid((unsigned)(tiles_d * tiles_h * tiles_w), 1, (unsigned)B);
+        const long long ntiles_ll = (long long)B * tiles_d * tiles_h * tiles_w;
+        if (ntiles_ll > 0x7fffffff) return CVAE_E_BADSHAPE;
+        const int ntiles = (int)ntiles_ll;
+        dim3 mgrid((unsigned)(ntiles < CVAE_C1_MAX_WG ? ntiles : CVAE_C1_MAX_WG), 1, 1);      // a workgroup walks ntiles / grid tiles with one set of weight fragments
         const int epi = CVAE_EPI_OF(act);
-#define LAUNCH_UP_MFMA(ND, EPI) hipLaunchKernelGGL((up_c1_mfma_kernel<ND, EPI>), mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_h, tiles_w, act)
+#define LAUNCH_UP_MFMA_(ND, EPI, MASKED) hipLaunchKernelGGL((up_c1_mfma_kernel<ND, EPI, MASKED>), mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_d, tiles_h, tiles_w, ntiles, act)
+#define LAUNCH_UP_MFMA(ND, EPI) do { if (mask) LAUNCH_UP_MFMA_(ND, EPI, true); else LAUNCH_UP_MFMA_(ND, EPI, false); } while (0)
         if (nd == 3) { if (epi == 0) LAUNCH_UP_MFMA(3, 0); else if (epi == 1) LAUNCH_UP_MFMA(3, 1); else LAUNCH_UP_MFMA(3, 2); }
         else { if (epi == 0) LAUNCH_UP_MFMA(2, 0); else if (epi == 1) LAUNCH_UP_MFMA(2, 1); else LAUNCH_UP_MFMA(2, 2); }
 #undef LAUNCH_UP_MFMA
+#undef LAUNCH_UP_MFMA_
         CVAE_CHECK_LAUNCH();
         return CVAE_OK;
     }
