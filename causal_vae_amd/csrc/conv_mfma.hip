@@ -51,11 +51,14 @@ namespace {
 #define CVAE_APIPE 3
 #endif
 #ifndef CVAE_UPFULL
-#define CVAE_UPFULL 0
+#define CVAE_UPFULL 1
 #endif
 #ifndef CVAE_UPFULL_WIDE
 #define CVAE_UPFULL_WIDE 0
 #endif
+#ifndef CVAE_UPFULL_MIN_GRID
+#define CVAE_UPFULL_MIN_GRID 2048        // (tiles x channel blocks x batch) from which conv_up_full_kernel is used: many rounds of one workgroup per CU (the 240-row decode
+#endif                                   // sweep: -12 % on its 64 -> 32 channel layer); at the training step's 512 it measured +-0 against conv_data_kernel<UP>
 #ifndef CVAE_UPFULL_MIN_WG
 #define CVAE_UPFULL_MIN_WG 512
 #endif
@@ -932,6 +935,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_up_full_kernel(const T* __r
 #endif
 }
 
+static long long g_upfull_min_grid = CVAE_UPFULL_MIN_GRID;
 template <typename T, int ND, int WM, int WN, int MI, int NI, int KCH> constexpr size_t up_full_lds_bytes() {
     using TL = Tile<ND, WM * MI * 32>;
     constexpr int ID = (ND == 3) ? TL::TD + 2 : 1, IH = TL::TH + 2;
@@ -952,6 +956,7 @@ int launch_up_full(const void* in, const void* wp, const float* bias, const void
         g.tiles_d = (md + TL::TD - 1) / TL::TD; g.tiles_h = (mh + TL::TH - 1) / TL::TH; g.tiles_w = (mw + TL::TW - 1) / TL::TW;
         const long long tiles = (long long)g.tiles_d * g.tiles_h * g.tiles_w;
         const int npar = (ND == 3) ? 8 : 4, nblocks = g.Cl / BN;
+        if (tiles * nblocks * g.B < g_upfull_min_grid) return CVAE_E_UNSUPPORTED;
         // parity classes per workgroup: all of them (one halo stage per tile) once the grid has ~2 workgroups per CU without splitting them
         int psplit = 1;
         while (psplit < npar && tiles * nblocks * g.B * psplit < CVAE_UPFULL_MIN_WG) psplit *= 2;
@@ -981,10 +986,13 @@ int launch_up_full(const void* in, const void* wp, const float* bias, const void
 template <typename T, int ND, int WM, int WN, int MI, int NI, typename TO = T>
 int try_up_full(const void* in, const void* wp, const float* bias, const void* mask, void* out, const ConvGeom& g, int act, hipStream_t stream,
                 float acc_scale = 1.f, float out_scale = 1.f) {
-    if (!CVAE_UPFULL || (WN * NI > 1 && !CVAE_UPFULL_WIDE)) return CVAE_E_UNSUPPORTED;
-    if (g.Cs == 64) return launch_up_full<T, ND, WM, WN, MI, NI, 4, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
-    if (g.Cs == 128) return launch_up_full<T, ND, WM, WN, MI, NI, 8, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
-    if (g.Cs == 256) return launch_up_full<T, ND, WM, WN, MI, NI, 16, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+    if constexpr (!CVAE_UPFULL || (WN * NI > 1 && !CVAE_UPFULL_WIDE)) {      // the 64-channel-tile form measured slower than conv_data_kernel<UP> with BD: not instantiated
+        return CVAE_E_UNSUPPORTED;
+    } else {
+        if (g.Cs == 64) return launch_up_full<T, ND, WM, WN, MI, NI, 4, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+        if (g.Cs == 128) return launch_up_full<T, ND, WM, WN, MI, NI, 8, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+        if (g.Cs == 256) return launch_up_full<T, ND, WM, WN, MI, NI, 16, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+    }
     return CVAE_E_UNSUPPORTED;
 }
 
@@ -1497,6 +1505,12 @@ extern "C" int cvae_debug_stamps(unsigned long long* host, size_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), count * sizeof(unsigned long long)) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
 }
 #endif
+
+extern "C" int64_t cvae_tune_upfull_min_grid(int64_t min_grid) {      // < 0: query only.  Returns the previous threshold.  Tests set 0 to run every `up` case through both kernels.
+    const long long prev = g_upfull_min_grid;
+    if (min_grid >= 0) g_upfull_min_grid = min_grid;
+    return prev;
+}
 
 extern "C" size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, int dtype) {
     const int64_t taps = (nd == 3) ? 64 : 16;

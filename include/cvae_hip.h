@@ -343,6 +343,11 @@ int cvae_linear_bwd_data_bf16(const float* dy, const float* W, float* dx, int64_
 int cvae_linear_bwd_weight_bf16(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N, int64_t dy_stride,
                                 int64_t x_stride, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Tuning / test hook (process-wide, not thread-safe; call between launches): the grid size (tiles x channel blocks x batch) from which the bf16
+ * cvae_conv_up of a 32-channel output with 64 input channels switches to the whole-K kernel (default 2048).  min_grid < 0 only queries.
+ * Returns the previous value.  Both kernels compute the same product; the tests run every case through each. */
+int64_t cvae_tune_upfull_min_grid(int64_t min_grid);
+
 /* ---- optimiser ---------------------------------------------------------------------------------------------- */
 /* torch.optim.Adam (no weight decay / amsgrad) on flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t
  * computed by the caller.  grad_scale: optional device scalar multiplied into g first (gradient clipping). */

@@ -72,10 +72,14 @@ CONV_CASES = [
 
 @pytest.fixture(params=[True, False], ids=["splitk", "unsplit"])
 def split_k(request):
-    """Small test volumes would all take the split-K path (few workgroups); run every conv case both ways."""
+    """Small test volumes would all take the split-K path (few workgroups); run every conv case both ways.  The unsplit arm also lowers the grid
+    threshold of the whole-K `up` kernel to 0, so the narrow bf16 cases (64 -> 32 channels) run through conv_up_full_kernel there and through
+    conv_data_kernel<UP> in the other arm."""
     old, ops.SPLIT_K = ops.SPLIT_K, request.param
+    prev = L.lib.cvae_tune_upfull_min_grid(-1 if request.param else 0)
     yield request.param
     ops.SPLIT_K = old
+    L.lib.cvae_tune_upfull_min_grid(prev)
 
 
 # odd input extents (l = 2 s + 1: the conv floors, its data gradient must come back with the odd extent): the 7 -> 3 layer of ConditionalVAE
