@@ -202,7 +202,7 @@ def traffic_table():
     return json.load(open(p)), commit
 
 
-def roofline_from_timer(timer, n_steps, dtype, step_ms, step_flops, step_bytes, linear_dtype=None):
+def roofline_from_timer(timer, n_steps, dtype, step_ms, step_flops, step_bytes, linear_dtype=None, use_traffic=False):
     """Families by total time per step; the dominant one is the roofline kernel.  linear_dtype: arithmetic of the linear family when it
     differs from the convs' (fp32 MFMA linears next to bf16 convs price against the fp32 peak)."""
     summ = timer.summary()
@@ -217,7 +217,9 @@ def roofline_from_timer(timer, n_steps, dtype, step_ms, step_flops, step_bytes, 
     d = fams[dom]
     if dom.startswith("linear") and linear_dtype is not None:
         peak = PEAK_BF16_FLOPS if linear_dtype == "bf16" else PEAK_F32_FLOPS
-    traffic, commit = traffic_table()
+    # the committed counter passes describe ONE workload (128^3, B = 4, bf16 train step): other workloads report traffic = null
+    traffic, commit = traffic_table() if use_traffic else ({}, None)
+    commit = traffic.get("_commit", commit)
     tr = traffic.get(dom, {})
     ach = d["flops"] / (d["ms"] * 1e-3)
     roof = {"bound": "mfma", "kernel": dom, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
@@ -353,7 +355,8 @@ def run_volume(args, rank, world, dev):
     step_ms = res["ms_per_step"]
     fl, byt = step_algorithmic(args.batch, args.size, 2 if args.dtype == "bf16" else 4, n_params, conv_params)
     if timer is not None:
-        roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, step_ms, fl, byt)
+        roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, step_ms, fl, byt,
+                                                  use_traffic=(args.size == 128 and args.batch == 4 and args.dtype == "bf16"))
         res["roofline"] = roof
         res["conv_ms_per_step"] = sum(v["ms_per_step"] for v in fams.values())
         res["families"] = fams

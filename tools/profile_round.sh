@@ -21,3 +21,11 @@ python3 tools/pmc_sq.py gpurun_out/prof/pmc_sq > gpurun_out/prof/pmc_sq.txt 2>&1
 # keep only the summaries (the raw traces are tens of MB)
 find $P -name "*kernel_trace.csv" -delete; find $P -name "*agent_info.csv" -delete
 ls -la $P $P/stats | head -30
+# kernel-stat summaries of the other BASELINE.json workloads (configs[1], configs[2], configs[4])
+cd /tmp
+for w in mnist vol64-f32 decode; do
+  rocprofv3 --kernel-trace --stats -d $P/stats_$w -o run --output-format csv -- python3 $R/bench.py --workload $w --cpu-seconds 0 > $P/bench_${w}_under_rocprof.json 2> $P/stats_$w.err
+  find $P/stats_$w -name "*kernel_trace.csv" -delete; find $P/stats_$w -name "*agent_info.csv" -delete
+  echo "$w stats done"
+done
+cd $R
