@@ -1,9 +1,11 @@
 // conv_c1.hip — the single-channel ends of the network (image -> 32 features, 32 features -> image): Cl == 1.
-// These layers are HBM-bound (arithmetic intensity ~50 FLOP/B), so they are written as streaming
-// kernels: the 1-channel halo tile and the whole (<= 8 KB) weight live in LDS as fp32, outputs leave as
-// channel-contiguous rows.  The weight gradient is a [Cs x taps] = S^T · im2col(L) product with K = positions; it
-// runs on the fp32 32x32x2 MFMA (one element per lane per operand, so no transposes) and leaves with fp32 atomics
-// directly in the reference [Cs][1][taps] layout.
+// These layers are HBM-bound on paper (arithmetic intensity ~50 FLOP/B); what actually bounded them was access width — a tile
+// 8 positions wide reads 64-96 contiguous bytes per image row — so every kernel here tiles WIDE IN X (32 positions, 16 for the transposed conv)
+// and a workgroup walks several tiles with the next halo in flight.
+//   down   (image -> S)  : down_c1_vec_kernel (bf16 S; image read as stored, fp32 or bf16, in 16-byte vectors) / down_c1_kernel (element loads)
+//   up     (S -> image)  : up_c1_mfma_kernel (bf16: v_mfma_f32_16x16x32_bf16 over the 3^nd neighbourhood) / up_c1_kernel (scalar form, fp32)
+//   wgrad                : wgrad_c1_kernel, [Cs x taps] = S^T . im2col(L) with K = positions on the MFMA (bf16 32x32x16 with transposing LDS reads, fp32
+//                          32x32x2); persistent workgroups leave slabs of partial sums, wgrad_c1_finish_kernel adds them in index order (no atomics)
 #include "common.h"
 
 namespace {
@@ -536,7 +538,8 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
 //   bf16: A fragments (S^T) by the transposing LDS read; B fragments gathered from the 1-channel halo (8 stride-2
 //         elements per lane); v_mfma_f32_32x32x16_bf16.  A third accumulator S^T . ones yields the bias gradient.
 //   fp32: v_mfma_f32_32x32x2_f32, one element per lane per operand.
-// Each workgroup walks `total / n_split` tiles of 128 positions and leaves with fp32 atomics directly in [Cs][1][taps].
+// Each workgroup walks `total / n_split` tiles of 128 positions and leaves ONE slab of partial sums with plain stores; wgrad_c1_finish_kernel adds
+// the slabs in index order into [Cs][1][taps] (no atomics).
 // TL: the dtype the 1-channel image L is STORED in (fp32 for the network input: read directly, rounded to T on the way into LDS).
 // VEC (bf16 compute only): the halo rows of L are fetched as aligned 16-byte vectors ([2 o0w - EPV, 2 o0w + 2 TW + EPV), EPV = 4 fp32 / 8 bf16
 // elements: 3 loads per thread and tile instead of 8 element loads) and scattered into the four LDS planes element by element; needs

@@ -11,8 +11,10 @@
 //     materialised and each input byte crosses L2->LDS ~1.8x instead of 8x.
 //   * `up` is the transposed conv in its parity form: the 2x2x2 output parity classes are 8 independent k2/s1
 //     sub-convolutions (8 taps each), so no zero-insertion FLOPs are spent.
-//   * B (weights, pre-packed [tap][K/16][N][16] by cvae_conv_pack_weight) streams through a double-buffered LDS
-//     panel, 4 taps per barrier.
+//   * B (weights, pre-packed [tap][K/16][N][16] by cvae_conv_pack_weight): bf16 tiles of 2 x 2 waves fetch their fragments per wave straight
+//     from the packed global panels into a register ring ("BD"); the other forms stream them through a double-buffered LDS panel, 4 taps
+//     per barrier.  A second `up` kernel (conv_up_full_kernel) stages the halo of ALL input channels once and walks the output parities
+//     inside the workgroup; it serves the large grids of the decode sweep.
 //   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain).
 //   * epilogue fuses bias + ReLU/Sigmoid (forward use) or the ReLU mask of the saved activation (backward use).
 // wgrad — M = Cs, N = Cl, K = positions.  Both operands are [position][channel] in memory, i.e. K-strided: bf16 uses
