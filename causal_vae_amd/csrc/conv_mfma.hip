@@ -43,6 +43,12 @@ namespace {
 #ifndef CVAE_BDIRECT
 #define CVAE_BDIRECT 1                  // bf16 data kernels fetch their weight fragments per wave (BD, below): 0.867 -> 0.832 ms/step at 128^3 B=4
 #endif
+#ifndef CVAE_WG_TILES
+#define CVAE_WG_TILES 16
+#endif
+#ifndef CVAE_WG_MIN_WG
+#define CVAE_WG_MIN_WG 64
+#endif
 #ifndef CVAE_BD_GS
 #define CVAE_BD_GS 8
 #endif
@@ -1431,7 +1437,15 @@ int plan_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbias,
     if (const char* e = getenv("CVAE_TUNE_WGRAD_NSPLIT")) n_split = atoll(e);
     if (n_split * cb * tg > WGRAD_MAX_WG && n_split > 1) n_split = WGRAD_MAX_WG / ((long long)cb * tg) > 0 ? WGRAD_MAX_WG / ((long long)cb * tg) : 1;   // stay inside the validated workspace
 #endif
-    if (n_split_req > 0 && n_split_req < n_split) n_split = n_split_req;     // a grouped launch shares the chip: fewer, longer workgroups per layer
+    {   // ~CVAE_WG_TILES tiles of 128 positions per slab, at least CVAE_WG_MIN_WG workgroups: a function of THIS layer only, the same whether the layer
+        // is launched alone (cvae_conv_wgrad) or as one entry of a grouped launch (cvae_conv_wgrad_multi) — the summation order, and with it every bit
+        // of the gradient, does not depend on how the caller batches its launches
+        long long req = (total_tiles + CVAE_WG_TILES - 1) / CVAE_WG_TILES;
+        const long long groups = (long long)cb * tg;
+        if (req * groups < CVAE_WG_MIN_WG) req = (CVAE_WG_MIN_WG + groups - 1) / groups;
+        if (req < n_split) n_split = req;
+    }
+    if (n_split_req > 0 && n_split_req < n_split) n_split = n_split_req;
     if (n_split < 1) n_split = 1;
     if (n_split > total_tiles) n_split = total_tiles;
     if ((long long)cb * tg * n_split > (1 << 24)) return CVAE_E_BADSHAPE;
@@ -1752,12 +1766,6 @@ static int wgrad_multi_t(int count, const void* const* S, const void* const* L, 
     // workgroups — never on what else rides in the launch: the split-backward capture flushes decoder and encoder separately, and its
     // gradients must have the summation order (the bits) of the single-launch step.
     using TLm = Tile<ND, 128>;
-#ifndef CVAE_WG_TILES
-#define CVAE_WG_TILES 16
-#endif
-#ifndef CVAE_WG_MIN_WG
-#define CVAE_WG_MIN_WG 64
-#endif
     // longest workgroups first (tiles per slab, descending): the launch is ~2.5 rounds of workgroups, and a long one started last is the tail
     long long req[WG_MULTI_MAX], key[WG_MULTI_MAX];
     int order[WG_MULTI_MAX];
