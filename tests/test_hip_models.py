@@ -413,6 +413,33 @@ def test_two_runs_of_the_same_training_are_bit_identical(size, dtype, fused):
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
 
 
+@pytest.mark.parametrize("size", [64, 128])
+def test_grouped_and_per_layer_weight_gradients_are_bit_identical(size):
+    """ops.DEFER_WGRAD (conv weight gradients queued during the backward and run as ONE grouped launch) vs a launch per layer: a layer's slab
+    count depends on that layer only, so the fp32 summation order — and every bit of every gradient, loss and weight after 4 steps — is the
+    same whichever way the caller batches the launches (128^3: the bench workload's layer sizes, where the slab rule actually splits)."""
+    g = torch.Generator().manual_seed(23)
+    B = 2 if size == 128 else 3
+    x, m = torch.randn(B, 1, size, size, size, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (B,), generator=g).to(DEV)
+    runs, old = [], ops_mod.DEFER_WGRAD
+    try:
+        for defer in (True, False):
+            ops_mod.DEFER_WGRAD = defer
+            ops_mod.EpsSource._instances = 0
+            torch.manual_seed(42)
+            model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+            opt = FusedAdam(model.parameters(), lr=1e-4, device_step=True)
+            losses = [tuple(float(v) for v in train_step(model, opt, x, m, t)) for _ in range(4)]
+            runs.append((losses, {k: p.detach().clone() for k, p in model.named_parameters()}, {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    finally:
+        ops_mod.DEFER_WGRAD = old
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), ("grad", k)
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
 @pytest.mark.parametrize("graphed", [False, True], ids=["eager", "graph"])
 def test_training_state_checkpoint_resumes_the_same_run(graphed):
     """causal_vae_amd.checkpoint: model (reference keys only) + FusedAdam (moments and the DEVICE step count) + the Philox call count.  Three
