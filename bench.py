@@ -277,8 +277,8 @@ def run_volume(args, rank, world, dev):
             _ops.backward_from(loss)
             if reducer is not None:
                 reducer()
-            clip_grad_norm_(model.parameters(), 5.0)
-            opt.step()
+            _, coef = clip_grad_norm_(model.parameters(), 5.0, scale_grads=False)     # the clip coefficient rides into Adam (vessel/train.py:train_step)
+            opt.step(grad_scale=coef)
             return loss.detach(), recon.detach(), morph.detach()
         eager_step = vessel_step_fn
     else:

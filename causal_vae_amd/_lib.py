@@ -102,6 +102,8 @@ SIGNATURES = {
     "cvae_multi_copy": [_p, _p, _p, _i, _p],
     "cvae_counter_add": [_p, _i, _p],
     "cvae_sqnorm": [_p, _p, _i64, _p, _sz, _p],
+    "cvae_sqnorm_multi": [_p, _p, _i, _p, _p, _sz, _p],
+    "cvae_weighted_sum": [_p, _p, _i, _p, _p, _i, _p],
     "cvae_scale": [_p, _i64, _p, _p],
     "cvae_clip_coef": [_p, _p, _f, _p],
     "cvae_up2x_supported": [_i64] * 7,

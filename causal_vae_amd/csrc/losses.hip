@@ -88,6 +88,65 @@ struct BceF {   // -(x*max(log p, -100) + (1-x)*max(log(1-p), -100))  — aten b
 extern "C" int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(SseF, a, b, out, n, ws, wsb, stream); }
 extern "C" int cvae_sum_fwd(const float* x, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(SumF, x, x, out, n, ws, wsb, stream); }
 extern "C" int cvae_sqnorm(const float* g, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(SqF, g, g, out, n, ws, wsb, stream); }
+// *out += sum over a LIST of tensors of g^2 (the gradient norm of clip_grad_norm_) in ONE launch + one finish: every block sums one span of one
+// tensor into its scratch slot, red_finish_kernel adds the slots in index order.  Per tensor this was two launches (~50 tensors: ~100 launches
+// of < 5 us each in the vessel recipe's step).
+#define SQM_MAX_TENSORS 64
+struct SqTable {
+    const float* g[SQM_MAX_TENSORS];
+    long long n[SQM_MAX_TENSORS];
+    int blk_start[SQM_MAX_TENSORS + 1];
+    int count;
+    long long span;
+};
+__global__ __launch_bounds__(RED_BLOCK) void sqnorm_multi_kernel(SqTable tb, float* __restrict__ out, float* __restrict__ ws) {
+    __shared__ float red[RED_BLOCK / 64];
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    const float* __restrict__ g = tb.g[ti];
+    const long long base = (long long)((int)blockIdx.x - tb.blk_start[ti]) * tb.span, end = min(tb.n[ti], base + tb.span);
+    float acc = 0.f;
+    if ((((uintptr_t)g) & 15) == 0 && (base & 3) == 0) {
+        const long long v0 = base / 4, v1 = end / 4;
+        for (long long i = v0 + threadIdx.x; i < v1; i += RED_BLOCK) { const float4 v = ((const float4*)g)[i]; acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+        for (long long i = v1 * 4 + threadIdx.x; i < end; i += RED_BLOCK) acc += g[i] * g[i];
+    } else {
+        for (long long i = base + threadIdx.x; i < end; i += RED_BLOCK) acc += g[i] * g[i];
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) red_emit(s, out, ws, 0);
+}
+extern "C" int cvae_sqnorm_multi(const float* const* g, const int64_t* n, int count, float* out, void* ws, size_t wsb, void* stream) {
+    if (count < 0) return CVAE_E_BADSHAPE;
+    if (count == 0) return CVAE_OK;
+    if (!g || !n || !out) return CVAE_E_NULLPTR;
+    for (int c0 = 0; c0 < count; c0 += SQM_MAX_TENSORS) {
+        SqTable tb;
+        const int cnt = (count - c0 < SQM_MAX_TENSORS) ? count - c0 : SQM_MAX_TENSORS;
+        long long total = 0;
+        for (int i = 0; i < cnt; ++i) { if (n[c0 + i] < 0) return CVAE_E_BADSHAPE; total += n[c0 + i]; }
+        if (total == 0) continue;
+        // spans of a multiple of 1024 elements, few enough blocks for the caller's scratch (one float per block) and for the finish pass
+        long long cap = (ws && wsb >= sizeof(float)) ? (long long)(wsb / sizeof(float)) : 1;
+        if (cap > RED_MAX_BLOCKS) cap = RED_MAX_BLOCKS;
+        if (cap <= cnt) return CVAE_E_WORKSPACE;                  // at least one block per tensor
+        tb.span = ((total + (cap - cnt) - 1) / (cap - cnt) + 1023) / 1024 * 1024;
+        int blocks = 0, used = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t ni = n[c0 + i];
+            if (ni == 0) continue;
+            if (!g[c0 + i]) return CVAE_E_NULLPTR;
+            tb.g[used] = g[c0 + i]; tb.n[used] = ni; tb.blk_start[used] = blocks;
+            blocks += (int)((ni + tb.span - 1) / tb.span);
+            ++used;
+        }
+        tb.blk_start[used] = blocks; tb.count = used;
+        hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(blocks), dim3(RED_BLOCK), 0, (hipStream_t)stream, tb, out, (float*)ws);
+        CVAE_CHECK_LAUNCH();
+        RED_FINISH(1, blocks, ws, out, stream);
+    }
+    return CVAE_OK;
+}
 extern "C" int cvae_bce_fwd(const float* p, const float* x, float* out, int64_t n, void* ws, size_t wsb, void* stream) { LAUNCH_RED2(BceF, p, x, out, n, ws, wsb, stream); }
 
 // Elementwise two-input map with a device-scalar upstream gradient.
@@ -716,6 +775,34 @@ extern "C" int cvae_scale(float* g, int64_t n, const float* scale, void* stream)
 }
 __global__ void clip_coef_kernel(const float* __restrict__ sq, float* __restrict__ scale, float max_norm) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *scale = fminf(1.f, max_norm / (sqrtf(*sq) + 1e-6f));
+}
+// out[0] = sum_i w[i] * *t[i] (forward), or out[i] = w[i] * *g for every i (backward, g NULL = 1): the weighted sum of up to 8 scalar loss terms and
+// its gradients as ONE launch each (composed from torch scalar ops the vessel recipe's total was ~20 launches of < 5 us).
+struct Scalars8 { const float* t[8]; float w[8]; int n; };
+__global__ void weighted_sum_kernel(Scalars8 a, const float* __restrict__ g, float* __restrict__ out, int backward) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (backward) {
+        const float gv = g ? *g : 1.f;
+        for (int i = 0; i < a.n; ++i) out[i] = a.w[i] * gv;
+    } else {
+        float s = 0.f;
+        for (int i = 0; i < a.n; ++i) s += a.w[i] * *a.t[i];              // index order: reproducible
+        out[0] = s;
+    }
+}
+extern "C" int cvae_weighted_sum(const float* const* terms, const float* weights, int count, const float* g, float* out, int backward, void* stream) {
+    if (count < 1 || count > 8) return CVAE_E_BADSHAPE;
+    if (!weights || !out || (!backward && !terms)) return CVAE_E_NULLPTR;
+    Scalars8 a;
+    a.n = count;
+    for (int i = 0; i < count; ++i) {
+        a.t[i] = backward ? nullptr : terms[i];
+        if (!backward && !terms[i]) return CVAE_E_NULLPTR;
+        a.w[i] = weights[i];
+    }
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, g, out, backward);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
 }
 extern "C" int cvae_clip_coef(const float* sq, float* scale, float max_norm, void* stream) {
     if (!sq || !scale) return CVAE_E_NULLPTR;

@@ -1025,6 +1025,38 @@ class ElboUp2x(torch.autograd.Function):
         return dsrc, None, d_mhat, None, dmu, dlv, None
 
 
+class WeightedSum(torch.autograd.Function):
+    """sum_i w_i * t_i of 0-dim device tensors as one launch (and one for all the gradients): a loss composed of several terms."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        import ctypes as C
+        L.require_gpu(*terms)
+        n = len(terms)
+        if not 1 <= n <= 8 or len(weights) != n:
+            raise L.CvaeError("WeightedSum: 1..8 terms, one weight each")
+        ts = [t.float().contiguous() for t in terms]
+        if any(t.numel() != 1 for t in ts):
+            raise L.CvaeError("WeightedSum: scalar (0-dim) terms expected")
+        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        check(lib.cvae_weighted_sum((C.c_void_p * n)(*[t.data_ptr() for t in ts]), (C.c_float * n)(*[float(w) for w in weights]), n, None, ptr(out), 0, stream()), "weighted_sum")
+        ctx.weights = [float(w) for w in weights]
+        ctx.shapes = [t.shape for t in terms]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        n = len(ctx.weights)
+        out = torch.empty(n, dtype=torch.float32, device=g.device)
+        check(lib.cvae_weighted_sum(None, (C.c_float * n)(*ctx.weights), n, ptr(g.float().contiguous()), ptr(out), 1, stream()), "weighted_sum_bwd")
+        return (None,) + tuple(out[i].view(ctx.shapes[i]) for i in range(n))
+
+
+def weighted_sum(terms, weights):
+    return WeightedSum.apply(tuple(weights), *terms)
+
+
 def sse(a, b):
     """F.mse_loss(a, b, reduction='sum') (gradient flows to a)."""
     return _PairLoss.apply(a, b, "sse")

@@ -145,9 +145,12 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 @torch.no_grad()
-def clip_grad_norm_(parameters, max_norm):
+def clip_grad_norm_(parameters, max_norm, scale_grads=True):
     """torch.nn.utils.clip_grad_norm_ (vessel_analysis/01_train/train.py:85) without a host sync: returns
-    (total_norm ** 2, coef) as 0-dim device tensors; gradients are scaled in place by coef = min(1, max_norm/(norm+1e-6))."""
+    (total_norm ** 2, coef) as 0-dim device tensors, coef = min(1, max_norm/(norm+1e-6)).  scale_grads=True (the torch semantics): the
+    gradients are scaled in place by coef.  scale_grads=False: they are left as they are — hand coef to FusedAdam.step(grad_scale=coef),
+    which multiplies it into every gradient as it reads it (same update, one launch per tensor fewer).  The norm is one multi-tensor launch."""
+    import ctypes as C
     from . import ops
     ops.join_side_streams()
     params = [p for p in parameters if p.grad is not None]
@@ -158,12 +161,17 @@ def clip_grad_norm_(parameters, max_norm):
     coef = torch.empty((), dtype=torch.float32, device=dev)
     nws = int(lib.cvae_reduce_workspace_bytes())
     ws = torch.empty(nws // 4, dtype=torch.float32, device=dev)     # per-workgroup partial sums, added in a fixed order (no float atomics)
+    gs = []
     for p in params:
-        g = p.grad
-        if not g.is_contiguous():
-            g = p.grad = g.contiguous()
-        check(lib.cvae_sqnorm(ptr(g), ptr(sq), g.numel(), ptr(ws), nws, stream()), "sqnorm")
+        if not p.grad.is_contiguous():
+            p.grad = p.grad.contiguous()
+        if p.grad.dtype != torch.float32:
+            raise L.CvaeError("clip_grad_norm_: float32 gradients expected")
+        gs.append(p.grad)
+    n = len(gs)
+    check(lib.cvae_sqnorm_multi((C.c_void_p * n)(*[g.data_ptr() for g in gs]), (C.c_int64 * n)(*[g.numel() for g in gs]), n, ptr(sq), ptr(ws), nws, stream()), "sqnorm_multi")
     check(lib.cvae_clip_coef(ptr(sq), ptr(coef), float(max_norm), stream()), "clip_coef")
-    for p in params:
-        check(lib.cvae_scale(ptr(p.grad), p.grad.numel(), ptr(coef), stream()), "scale")
+    if scale_grads:
+        for g in gs:
+            check(lib.cvae_scale(ptr(g), g.numel(), ptr(coef), stream()), "scale")
     return sq, coef

@@ -482,9 +482,12 @@ def test_philox_normal_statistics_and_determinism():
     assert int(ctr) == 2 and torch.equal(d0, a[:64]) and not torch.equal(d0, d1)
 
 
-def test_fused_adam_and_clip_match_torch():
+@pytest.mark.parametrize("fold", [False, True], ids=["scale-in-place", "coef-into-adam"])
+def test_fused_adam_and_clip_match_torch(fold):
+    """clip_grad_norm_ (one multi-tensor norm launch) + FusedAdam vs torch's pair.  fold: the gradients are NOT scaled in place; the clip coefficient
+    goes to FusedAdam.step(grad_scale=coef) instead — the same update (what vessel/train.py:train_step does)."""
     g = torch.Generator().manual_seed(12)
-    shapes = [(512, 331), (64,), (32, 1, 4, 4, 4), (5,)]
+    shapes = [(512, 331), (64,), (32, 1, 4, 4, 4), (5,), (3, 100003)] + [(7, 11)] * 70          # > 64 tensors: two table launches; a misaligned-length tensor
     ps = [torch.randn(*s, generator=g) for s in shapes]
     ref = [p.clone().requires_grad_(True) for p in ps]
     mine = [p.clone().to(DEV).requires_grad_(True) for p in ps]
@@ -494,11 +497,16 @@ def test_fused_adam_and_clip_match_torch():
             gr = torch.randn(r.shape, generator=g) * (10.0 if step == 1 else 0.1)
             r.grad, m.grad = gr.clone(), gr.clone().to(DEV)
         n_ref = torch.nn.utils.clip_grad_norm_(ref, 5.0)
-        sq, coef = clip_grad_norm_(mine, 5.0)
+        sq, coef = clip_grad_norm_(mine, 5.0, scale_grads=not fold)
         torch.testing.assert_close(sq.sqrt().cpu(), n_ref, rtol=1e-5, atol=1e-6)
-        for r, m in zip(ref, mine):
-            torch.testing.assert_close(m.grad.cpu(), r.grad, rtol=1e-5, atol=1e-7)
-        o_ref.step(); o_mine.step()
+        if not fold:
+            for r, m in zip(ref, mine):
+                torch.testing.assert_close(m.grad.cpu(), r.grad, rtol=1e-5, atol=1e-7)
+        o_ref.step()
+        if fold:
+            o_mine.step(grad_scale=coef)
+        else:
+            o_mine.step()
     for r, m in zip(ref, mine):
         torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
 
