@@ -23,6 +23,7 @@
 //   plain stores; wgrad_reduce_kernel adds the slabs in index order and writes the reference [Cs][Cl][taps] layout (no atomics).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Development aid (make EXTRA=-DCVAE_STAMP, tools/stamp_probe.py): thread 0 of every workgroup of conv_data_kernel records the
 // shader clock at its phase boundaries into a device array that cvae_debug_stamps() copies out.  Not compiled by default.
@@ -48,6 +49,9 @@ namespace {
 #endif
 #ifndef CVAE_WG_MIN_WG
 #define CVAE_WG_MIN_WG 64
+#endif
+#ifndef CVAE_KSPLIT_WAVES
+#define CVAE_KSPLIT_WAVES 1             // bf16 64-channel tiles: 2 x 2 waves = (K split) x (N sub-tile) instead of (M half) x (N sub-tile): 0.793 -> 0.785 ms/step
 #endif
 #ifndef CVAE_BD_GS
 #define CVAE_BD_GS 8
@@ -186,11 +190,15 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // BD ("B direct"): every wave fetches its weight fragments straight from the packed global panels into a two-group register ring (the panels are
 // laid out so that one fragment of a wave is 1 KB contiguous) instead of all waves staging them through LDS: no weight traffic on the LDS
 // pipe, which the activation fragments already load to ~2/3 of the MFMA time, and no barrier inside a channel chunk's tap loop.
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = false>
-__global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
+// TS ("K split", BD only): TS = 2 wave groups of WM x WN waves each own every second k-step (odd / even taps for KH = 1, the two 16-channel halves
+// of a stage for KH = 2) of the WHOLE tile and add their accumulators through LDS once, before the epilogue.  With WM = 1 no two waves fetch the
+// same weight fragment, and a fetched fragment feeds MI = 4 MFMAs: half the bytes per MFMA on the vector-memory path the BD tap loop is bound by.
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = false, int TS = 1>
+__global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                   const TO* __restrict__ mask, TO* __restrict__ out, ConvGeom g, int act,
                                                                   float* __restrict__ ws, int ksplit, float acc_scale, float out_scale) {
-    constexpr int NT = WM * WN * 64;
+    static_assert(TS == 1 || (TS == 2 && BD && MI % 2 == 0), "the K split needs the per-wave weight fetch and an even number of M sub-tiles");
+    constexpr int NT = WM * WN * TS * 64;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     }
 #endif
     STAMP(0);
-    const int wm = wave / WN, wn = wave % WN;
+    const int ts = wave / (WM * WN), wv = wave % (WM * WN);      // K-split group (0 when TS == 1)
+    const int wm = wv / WN, wn = wv % WN;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z;
     const int Cin = UP ? g.Cs : g.Cl, Cout = UP ? g.Cl : g.Cs;
@@ -328,14 +337,22 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
 
     // ---- BD: k-steps of a chunk in the order the LDS form walks them (tap group, tap, k-step), cut into NGRP groups of GS steps; group g + 1
     // (or the next chunk's group 0) is in flight while group g feeds the MFMAs ----
-    constexpr int STEPS = NG * 4 * KH, GS = STEPS >= 64 ? CVAE_BD_GS : (STEPS >= 16 ? 8 : STEPS / 2), NGRP = STEPS / GS;
-    static_assert(!BD || (NGRP % 2 == 0 && GS * NGRP == STEPS && GS % KH == 0), "BD walks the groups in pairs");
-    const T* wl = wp + ((size_t)(n0 + wn * NI * 32 + r)) * 16 + 8 * h;
+    // With TS = 2 a wave walks its OWN steps u = 0 .. STEPS - 1 <-> stage step 2 u + ts.  The ts part never enters the loops: for KH = 1 it is the
+    // tap's low bit (down: the odd-x halo plane and the next weight tap; up: one slot to the right and weight tap kw - 2), for KH = 2 the second
+    // 16-channel half of the stage — a constant offset of this wave's LDS and weight base addresses.
+    constexpr int STEPS = NG * 4 * KH / TS, GS = STEPS >= 64 ? CVAE_BD_GS : (STEPS >= 16 ? (MI >= 4 ? 4 : 8) : STEPS / 2), NGRP = STEPS / GS;      // MI = 4: a step is 4 MFMAs, 4 steps are as long as 8
+    static_assert(!BD || (NGRP % 2 == 0 && GS * NGRP == STEPS && (GS * TS) % KH == 0), "BD walks the groups in pairs");
+    static_assert(TS == 1 || KH <= 2, "K split: one or two k-steps per stage");
+    const long long w_tap = (long long)nch16 * Cout * 16;     // elements between two taps of the packed panels
+    const long long w_ts = (TS == 1) ? 0 : (KH == 2 ? (long long)ts * Cout * 16 : (UP ? -2 * ts * w_tap : ts * w_tap));
+    const int a_ts = (TS == 1) ? 0 : (KH == 2 ? ts * 2 * PLANE : (UP ? ts : ts * NROWS * RS));
+    const T* wl = wp + ((size_t)(n0 + wn * NI * 32 + r)) * 16 + 8 * h + w_ts;
+    const char* halo_a = halo + (size_t)a_ts * FB;
     Frag<T> qa[BD ? GS : 1][NI], qb[BD ? GS : 1][NI];
     auto load_q = [&](Frag<T> (&q)[BD ? GS : 1][NI], int chunk, int gidx) {
 #pragma unroll
         for (int i = 0; i < GS; ++i) {
-            const int kk = i % KH, tj = gidx * (GS / KH) + i / KH;
+            const int kk = (i * TS) % KH, tj = gidx * (GS * TS / KH) + (i * TS) / KH;
             const int wt = tap_weight_idx(tj >> 2, tj & 3);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) lds_load(q[i][ni], (const char*)(wl + ((size_t)(wt * nch16 + chunk * KH + kk) * Cout + ni * 32) * 16));
@@ -344,11 +361,11 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     auto compute_q = [&](const Frag<T> (&q)[BD ? GS : 1][NI], int gidx) {
 #pragma unroll
         for (int i = 0; i < GS; ++i) {
-            const int kk = i % KH, tj = gidx * (GS / KH) + i / KH;
+            const int kk = (i * TS) % KH, tj = gidx * (GS * TS / KH) + (i * TS) / KH;
             const int toff = tap_halo_off(tj >> 2, tj & 3);
             Frag<T> a[MI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
+            for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo_a + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -359,8 +376,10 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     const int chunk_per = nchunks / ksplit;                 // host guarantees ksplit divides nchunks
     // what the epilogue needs from memory — this lane's bias values and ReLU-mask pieces — is requested now, not in the epilogue, where each was
     // an exposed global round trip at the end of every workgroup
+    constexpr int MO = MI / TS;                               // M sub-tiles this wave finishes (TS = 2: the other half goes to its partner wave)
+    const int mi0 = ts * MO;
     float bpre[NI][2][8];
-    Piece<TO> mpre[MI][NI][2];
+    Piece<TO> mpre[MO][NI][2];
     const int out_d = UP ? g.ld : g.sd, out_h = UP ? g.lh : g.sh, out_w = UP ? g.lw : g.sw;
     if (ksplit == 1) {
 #pragma unroll
@@ -373,8 +392,8 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
             }
         if (mask) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int ms = wm * MI + mi;
+            for (int mo = 0; mo < MO; ++mo) {
+                const int mi = mi0 + mo, ms = wm * MI + mi;
                 const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
                 int od, oh, ow;
                 if (UP) { od = (ND == 3) ? 2 * (o0d + d) + prd : 0; oh = 2 * (o0h + hh) + prh; ow = 2 * (o0w + w) + prw; }
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) piece_load_raw<TO>(mpre[mi][ni][j], mask + pidx + n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h);
+                    for (int j = 0; j < 2; ++j) piece_load_raw<TO>(mpre[mo][ni][j], mask + pidx + n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h);
             }
         }
     }
@@ -397,15 +416,15 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     // MFMA never waits for a read issued right before it — left to itself the compiler emits read / s_waitcnt / MFMA per step and the loop runs at
     // LDS latency (~35 % of the MFMA rate by the stamp probes, one wave per SIMD).
     auto bd_pair = [&](int chunk, int gp) {
-        constexpr int NS = 2 * GS, APD = CVAE_APIPE < NS ? CVAE_APIPE : NS - 1;
+        constexpr int NS = 2 * GS, APW = (MI >= 4) ? 2 : CVAE_APIPE, APD = APW < NS ? APW : NS - 1;      // MI = 4: 4 reads per step, 2 steps ahead is as many in flight
         load_q(qb, chunk, gp + 1);
         Frag<T> ar[APD + 1][MI];
         auto lda = [&](int slot, int i) {
             const int gidx = gp + i / GS, ii = i % GS;
-            const int kk = ii % KH, tj = gidx * (GS / KH) + ii / KH;
+            const int kk = (ii * TS) % KH, tj = gidx * (GS * TS / KH) + (ii * TS) / KH;
             const int toff = tap_halo_off(tj >> 2, tj & 3);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) lds_load(ar[slot][mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
+            for (int mi = 0; mi < MI; ++mi) lds_load(ar[slot][mi], halo_a + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
         };
 #pragma unroll
         for (int d = 0; d < APD; ++d) lda(d, d);
@@ -507,8 +526,39 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
     // positions: lane (r, h) holds, for position r of each M sub-tile, channels (e & 3) + 8 (e >> 2) + 4 h of each 32-channel N
     // sub-tile.  Two v_permlane32_swap per register pair regroup them so that the lane owns channels 8h..8h+7 and 16+8h..23+8h:
     // two 8-channel pieces, each ONE 16-byte (bf16) store and ONE 16-byte mask load instead of eight 2-byte ones.
+    // the exchange and the epilogue index the accumulators with ts: written once as a generic lambda and called with the wave's ts as a compile-time
+    // constant (a run-time index would put the accumulator array in scratch memory)
+    auto finish = [&](auto TSV) {
+        constexpr int tsc = decltype(TSV)::value, mi0c = tsc * MO;
+        if constexpr (TS == 2) {
+            // each wave hands the accumulators of the partner's M sub-tiles over through LDS (the halo is spent) and adds what the partner hands it
+            __syncthreads();
+            float4* xb = (float4*)smem;
+            const int pw = wave ^ (WM * WN);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+            for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const f32x16& a = acc[(1 - tsc) * MO + mo][ni];
+                        xb[(((size_t)wave * MO + mo) * NI + ni) * 4 * 64 + e4 * 64 + lane] = make_float4(a[4 * e4], a[4 * e4 + 1], a[4 * e4 + 2], a[4 * e4 + 3]);
+                    }
+            __syncthreads();
+#pragma unroll
+            for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const float4 v = xb[(((size_t)pw * MO + mo) * NI + ni) * 4 * 64 + e4 * 64 + lane];
+                        f32x16& a = acc[mi0c + mo][ni];
+                        a[4 * e4] += v.x; a[4 * e4 + 1] += v.y; a[4 * e4 + 2] += v.z; a[4 * e4 + 3] += v.w;
+                    }
+        }
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) {
+        const int mi = mi0c + mo;
         const int ms = wm * MI + mi;                                            // same lane -> position map as pbase
         const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
         int od, oh, ow;
@@ -552,7 +602,7 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
                 }
                 if (!ok) continue;
                 if (mask) {
-                    const TO* mv = (const TO*)&mpre[mi][ni][j];
+                    const TO* mv = (const TO*)&mpre[mo][ni][j];
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                         if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
@@ -568,6 +618,12 @@ __global__ __launch_bounds__(WM * WN * 64, BD ? 2 : 1) void conv_data_kernel(con
                 }
             }
         }
+    }
+    };
+    if constexpr (TS == 2) {
+        if (ts == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 1>{});
+    } else {
+        finish(std::integral_constant<int, 0>{});
     }
 #ifdef CVAE_STAMP
     __builtin_amdgcn_s_waitcnt(0);                         // vmcnt(0): the stores have left the wave
@@ -619,7 +675,7 @@ static int pick_ksplit(bool up, long long nwg, int nchunks) {
     return best;
 }
 
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = (CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2)>
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = (CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2), int TS = 1>
 int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
                     size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -628,9 +684,11 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     constexpr int IH = UP ? TL::TH + 1 : 2 * TL::TH + 2, IW = UP ? TL::TW + 1 : 2 * TL::TW + 2;
     constexpr int FB = 8 * sizeof(T);
     static_assert(IW >= 0, "");
-    constexpr size_t LDS = (size_t)2 * KH * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (BD ? 0 : (size_t)2 * 4 * KH * 2 * BN * FB);
+    constexpr size_t LDS_MAIN = (size_t)2 * KH * (UP ? 1 : 2) * ID * IH * HaloPitch<ND, UP>::RS * FB + (BD ? 0 : (size_t)2 * 4 * KH * 2 * BN * FB);
+    constexpr size_t LDS_X = TS == 2 ? (size_t)WM * WN * TS * (MI / 2) * NI * 16 * 64 * sizeof(float) : 0;      // the K split's accumulator exchange
+    constexpr size_t LDS = LDS_MAIN > LDS_X ? LDS_MAIN : LDS_X;
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
-    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD>;
+    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
@@ -649,7 +707,7 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     gy *= ksplit;
     if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
     dim3 grid((unsigned)tiles, (unsigned)gy, (unsigned)g.B);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const TO*)mask, (TO*)out, g, act, (float*)workspace, ksplit,
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * TS * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const TO*)mask, (TO*)out, g, act, (float*)workspace, ksplit,
                        acc_scale, out_scale);
     CVAE_CHECK_LAUNCH();
     if constexpr (sizeof(T) != 1) if (ksplit > 1) {
@@ -660,18 +718,19 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     return CVAE_OK;
 }
 
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI>
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int TS = 1>
 int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* ws, size_t wsb, hipStream_t stream) {
+    constexpr bool BDX = CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2;
     // 32-channel stages pay where the K loop is long and the grid small (measured: Cin 256: -12 %, 128: -5 %, 64: +2 %)
     if (UP && sizeof(T) == 2 && g.Cs >= 128 && (g.Cs % 32) == 0) {
         constexpr int KH2 = (UP && sizeof(T) == 2) ? 2 : 1;
-        if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, KH2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-        if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, KH2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-        return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, KH2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+        if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+        if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+        return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
     }
-    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
 }
 
 // Workspace the split-K path of launch_data would use for this geometry (0: the launch fills the chip without it).
@@ -1642,6 +1701,10 @@ extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, c
     if (Cl == 1) return cvae_conv_down_c1(L, dtype, (const float*)w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
     if (Cl % 16 || Cs % 64) return CVAE_E_UNSUPPORTED;
     GEOM_INIT();
+#if CVAE_KSPLIT_WAVES
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
+                                           : launch_data<bf16, 2, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
+#endif
     if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
                                            : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
     return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
@@ -1695,6 +1758,10 @@ extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, con
         if (nd == 3) rc = wide ? try_up_full<bf16, 3, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : try_up_full<bf16, 3, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
         else rc = wide ? try_up_full<bf16, 2, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : try_up_full<bf16, 2, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
         if (rc != CVAE_E_UNSUPPORTED) return rc;
+#if CVAE_KSPLIT_WAVES
+        if (wide) return nd == 3 ? launch_data<bf16, 3, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st)
+                                 : launch_data<bf16, 2, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
+#endif
         if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
         return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
     }
