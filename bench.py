@@ -205,7 +205,9 @@ def traffic_table():
 def roofline_from_timer(timer, n_steps, dtype, step_ms, step_flops, step_bytes, linear_dtype=None, use_traffic=False):
     """Families by total time per step; the dominant one is the roofline kernel.  linear_dtype: arithmetic of the linear family when it
     differs from the convs' (fp32 MFMA linears next to bf16 convs price against the fp32 peak)."""
-    summ = timer.summary()
+    summ = timer.summary() if (timer is not None and n_steps > 0) else {}
+    if not summ:                                             # --roofline-steps 0: A/B runs that only want the timing
+        return None, [], {}
     peak = PEAK_BF16_FLOPS if dtype == "bf16" else PEAK_F32_FLOPS
     fams = {}
     for k, (n, ms) in summ.items():
@@ -430,7 +432,8 @@ def run_mnist(args, rank, world, dev):
     step_by = 28 * n_params + 3 * 4 * n_params + B * 4 * (2 * 784 * 3 + 6 * (6272 + 3136 + 3136 + 6272))
     lin_dt = "bf16" if lin_bf16 else "f32"
     roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, res["ms_per_step"], step_fl, step_by, linear_dtype=lin_dt)
-    roof["linear_arithmetic"] = lin_dt
+    if roof is not None:
+        roof["linear_arithmetic"] = lin_dt
     res["roofline"], res["families"], res["kernels"] = roof, fams, kernels
     return res
 

@@ -164,6 +164,12 @@ __global__ __launch_bounds__(256) void down_c1_kernel(const T* __restrict__ L, c
 #ifndef CVAE_C1_MAX_WG
 #define CVAE_C1_MAX_WG 1024
 #endif
+#ifndef CVAE_C1U_WALK
+#define CVAE_C1U_WALK 1                 // up, Cl == 1, 3D: walk z columns when the launch has enough tiles
+#endif
+#ifndef CVAE_C1U_WALK_MIN_UNITS
+#define CVAE_C1U_WALK_MIN_UNITS 1024
+#endif
 template <int ND, int MS> struct TileC1V;
 template <int MS> struct TileC1V<3, MS> { static constexpr int TD = MS / 2, TH = 8, TW = 32; };   // wide in x: a halo row is 160-288 contiguous bytes, an output row 2 KB
 template <int MS> struct TileC1V<2, MS> { static constexpr int TD = 1, TH = 8 * MS, TW = 16; };
@@ -411,6 +417,27 @@ template <int ND> struct TileC1U;
 template <> struct TileC1U<3> { static constexpr int TD = 2, TH = 8, TW = 16; };
 template <> struct TileC1U<2> { static constexpr int TD = 1, TH = 16, TW = 16; };
 
+// Wm^T fragments of the Cl == 1 up convolution, once per workgroup: one 16-byte row = 8 channels of (neighbour, k group, parity)
+template <int ND>
+__device__ inline void up_c1_build_wfr(bf16* wfr, const float* __restrict__ w, int t) {
+    constexpr int NNB = (ND == 3) ? 27 : 9, TAPS = (ND == 3) ? 64 : 16, NPAR = (ND == 3) ? 8 : 4;
+    for (int row = t; row < NNB * 4 * 8; row += 256) {
+        const int p = row & 7, q = (row >> 3) & 3, nb = row >> 5;
+        const int c0 = 8 * q;
+        const int ox = nb % 3 - 1, oy = nb / 3 % 3 - 1, oz = (ND == 3) ? nb / 9 - 1 : 0;
+        const int px = p & 1, py = (p >> 1) & 1, pz = (ND == 3) ? (p >> 2) : 0;
+        const int ax = ox - px + 1, ay = oy - py + 1, az = oz - pz + 1;
+        const bool valid = (p < NPAR) & (ax >= 0) & (ax <= 1) & (ay >= 0) & (ay <= 1) & ((ND == 2) | ((az >= 0) & (az <= 1)));
+        const int kw = 3 - px - 2 * ax, kh = 3 - py - 2 * ay, kd = (ND == 3) ? 3 - pz - 2 * az : 0;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) {
+            const float* wp = w + c0 * TAPS + (kd * 4 + kh) * 4 + kw;
+            o = make_uint4(pack2_bf16(wp[0], wp[TAPS]), pack2_bf16(wp[2 * TAPS], wp[3 * TAPS]), pack2_bf16(wp[4 * TAPS], wp[5 * TAPS]), pack2_bf16(wp[6 * TAPS], wp[7 * TAPS]));
+        }
+        *(uint4*)(wfr + row * 8) = o;
+    }
+}
+
 template <int ND, int EPI, bool MASKED>
 __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
                                                          const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_d, int tiles_h,
@@ -455,21 +482,7 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
     };
     int tile = blockIdx.x;
     issue_loads(tile);
-    for (int row = t; row < NNB * 4 * 8; row += 256) {       // Wm^T, once per workgroup: one 16-byte row = 8 channels of (neighbour, k group, parity)
-        const int p = row & 7, q = (row >> 3) & 3, nb = row >> 5;
-        const int c0 = 8 * q;
-        const int ox = nb % 3 - 1, oy = nb / 3 % 3 - 1, oz = (ND == 3) ? nb / 9 - 1 : 0;
-        const int px = p & 1, py = (p >> 1) & 1, pz = (ND == 3) ? (p >> 2) : 0;
-        const int ax = ox - px + 1, ay = oy - py + 1, az = oz - pz + 1;
-        const bool valid = (p < NPAR) & (ax >= 0) & (ax <= 1) & (ay >= 0) & (ay <= 1) & ((ND == 2) | ((az >= 0) & (az <= 1)));
-        const int kw = 3 - px - 2 * ax, kh = 3 - py - 2 * ay, kd = (ND == 3) ? 3 - pz - 2 * az : 0;
-        uint4 o = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) {
-            const float* wp = w + c0 * TAPS + (kd * 4 + kh) * 4 + kw;
-            o = make_uint4(pack2_bf16(wp[0], wp[TAPS]), pack2_bf16(wp[2 * TAPS], wp[3 * TAPS]), pack2_bf16(wp[4 * TAPS], wp[5 * TAPS]), pack2_bf16(wp[6 * TAPS], wp[7 * TAPS]));
-        }
-        *(uint4*)(wfr + row * 8) = o;
-    }
+    up_c1_build_wfr<ND>(wfr, w, t);
     const float bz = bias ? bias[0] : 0.f;
     const int ld = (ND == 3) ? 2 * sd : 1, lh = 2 * sh, lw = 2 * sw;
     store_lds();
@@ -530,6 +543,132 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
         store_lds();
         __syncthreads();
         tile = next;
+    }
+}
+
+// The 3D form for long z columns: a workgroup walks `walk` consecutive tiles along z and keeps the two halo planes a tile shares with the next one
+// in LDS, so a step stages 2 planes instead of 4 (the halo is the kernel's L2 traffic: 2.8 source reads per voxel for a lone 2 x 8 x 16 tile, 1.4
+// when walking).  LDS holds two half-buffers of 2 planes; tile j of a walk reads logical planes {0,1} from buffer j % 2 and {2,3} from the other.
+// The host picks `walk` so that the launch still has >= ~1024 units (walk == 1 for the training batch: same traffic as up_c1_mfma_kernel).
+template <int EPI, bool MASKED>
+__global__ __launch_bounds__(256) void up_c1_mfma_walk_kernel(const bf16* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_d,
+                                                              int tiles_h, int tiles_w, int walk, int segs, int nunits, int act) {
+    using TLU = TileC1U<3>;
+    constexpr int TD = TLU::TD, TH = TLU::TH, TW = TLU::TW;
+    static_assert(TD == 2 && TW == 16 && TD * TH * TW == 256, "two z planes per tile, 16 consecutive-x voxels per column set");
+    constexpr int IH = TH + 2, IW = TW + 2, PLANE = IH * IW, HPOS = 2 * PLANE, PPITCH = (4 * PLANE + 15) / 16 * 16;
+    constexpr int NNB = 27, HN = (HPOS * 4 + 255) / 256;
+    __shared__ uint4 halo[4 * PPITCH];
+    __shared__ __attribute__((aligned(16))) bf16 wfr[NNB * 4 * 8 * 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, kq = lane >> 4;
+    uint4 hva[HN], hvb[HN];
+    // two planes gz0, gz0 + 1 of the halo of tile column (b, o0h, o0w): piece t % 4 of positions t / 4 + 64 i
+    auto issue_half = [&](uint4 (&hv)[HN], int b, int o0h, int o0w, int gz0) {
+        constexpr int DX = 64 % IW, DY = (64 / IW) % IH, DZ = 64 / PLANE;
+        const int piece = t & 3, pos0 = t >> 2;
+        int x = pos0 % IW, y = (pos0 / IW) % IH, z = pos0 / PLANE;
+        const bf16* Sb = S + (size_t)b * sd * sh * sw * 32 + piece * 8;
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int gz = gz0 + z, gy = o0h - 1 + y, gx = o0w - 1 + x;
+            const bool ok = (z < 2) & (gz >= 0) & (gz < sd) & (gy >= 0) & (gy < sh) & (gx >= 0) & (gx < sw);
+            const uint4 v = *(const uint4*)(Sb + (((size_t)min(max(gz, 0), sd - 1) * sh + min(max(gy, 0), sh - 1)) * sw + min(max(gx, 0), sw - 1)) * 32);
+            hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+            x += DX; if (x >= IW) { x -= IW; y += 1; }
+            y += DY; if (y >= IH) { y -= IH; z += 1; }
+            if (y >= IH) { y -= IH; z += 1; }
+            z += DZ;
+        }
+    };
+    auto store_half = [&](const uint4 (&hv)[HN], int buf) {
+#pragma unroll
+        for (int i = 0; i < HN; ++i) {
+            const int it = t + i * 256;
+            if (it < HPOS * 4) halo[(it & 3) * PPITCH + buf * HPOS + (it >> 2)] = hv[i];
+        }
+    };
+    auto decode = [&](int unit, int& b, int& td0, int& td1, int& o0h, int& o0w) {
+        const int tw_i = unit % tiles_w; unit /= tiles_w;
+        const int th_i = unit % tiles_h; unit /= tiles_h;
+        const int seg = unit % segs; b = unit / segs;
+        td0 = seg * walk; td1 = min(tiles_d, td0 + walk);
+        o0h = th_i * TH; o0w = tw_i * TW;
+    };
+    int unit = blockIdx.x, b, td, td_end, o0h, o0w;
+    decode(unit, b, td, td_end, o0h, o0w);
+    issue_half(hva, b, o0h, o0w, td * TD - 1);
+    issue_half(hvb, b, o0h, o0w, td * TD + 1);
+    up_c1_build_wfr<3>(wfr, w, t);
+    const float bz = bias ? bias[0] : 0.f;
+    const int ld = 2 * sd, lh = 2 * sh, lw = 2 * sw;
+    store_half(hva, 0);
+    store_half(hvb, 1);
+    __syncthreads();
+    // each wave: 4 column sets of 16 voxels (one x-row of the tile each): cs -> tile row (wave * 4 + cs) = (d, hh); d is the same for the wave
+    const int dz_own = (wave * 4) / TH;
+    int pb2[4];
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) pb2[cs] = kq * PPITCH + ((wave * 4 + cs) % TH) * IW + col;
+    int par = 0;                                             // buffer that holds logical planes 0, 1
+    while (true) {
+        const bool same = td + 1 < td_end;
+        const int next_unit = unit + (int)gridDim.x;
+        const bool has_next = next_unit < nunits;
+        int nb_ = 0, ntd = 0, ntd_end = 0, nh = 0, nw = 0;
+        if (same) issue_half(hva, b, o0h, o0w, (td + 1) * TD + 1);
+        else if (has_next) {
+            decode(next_unit, nb_, ntd, ntd_end, nh, nw);
+            issue_half(hva, nb_, nh, nw, ntd * TD - 1);
+            issue_half(hvb, nb_, nh, nw, ntd * TD + 1);
+        }
+        int zoff[3];
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) zoff[dz] = ((dz_own + dz + 2 * par) & 3) * PLANE;
+        f32x4 acc[4];
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs) acc[cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) {
+            const int off = (nb / 3 % 3) * IW + nb % 3;
+            union { uint4 u; bf16x8 v; } a, bv[4];
+            a.u = *(const uint4*)(wfr + ((nb * 4 + kq) * 8 + (col & 7)) * 8);
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) bv[cs].u = halo[zoff[nb / 9] + pb2[cs] + off];
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) acc[cs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bv[cs].v, acc[cs], 0, 0, 0);
+        }
+        // ---- epilogue: lanes 0..15 hold (py, px) = (r >> 1, r & 1) of plane pz = 0, lanes 16..31 of pz = 1 ----
+        if (kq < 2) {
+            const int o0d = td * TD;
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) {
+                const int rowi = wave * 4 + cs;
+                const int qz = o0d + rowi / TH, qy = o0h + rowi % TH, qx = o0w + col;
+                if (qz >= sd || qy >= sh || qx >= sw) continue;
+                const int lz = 2 * qz + kq;
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const size_t idx = (((size_t)b * ld + lz) * lh + 2 * qy + py) * lw + 2 * qx;
+                    float v0 = apply_act_t<EPI>(acc[cs][2 * py] + bz, act), v1 = apply_act_t<EPI>(acc[cs][2 * py + 1] + bz, act);
+                    if constexpr (MASKED) {
+                        union { uint32_t u; bf16 e[2]; } mk;
+                        mk.u = *(const uint32_t*)(mask + idx);
+                        if (!(to_f32(mk.e[0]) > 0.f)) v0 = 0.f;
+                        if (!(to_f32(mk.e[1]) > 0.f)) v1 = 0.f;
+                    }
+                    *(uint32_t*)(L + idx) = pack2_bf16(v0, v1);
+                }
+            }
+        }
+        if (!same && !has_next) break;
+        __syncthreads();                                     // every wave is done with this tile's LDS image
+        if (same) { store_half(hva, par); par ^= 1; td += 1; }   // the new planes replace logical {0,1}; old {2,3} become the next tile's {0,1}
+        else {
+            store_half(hva, 0); store_half(hvb, 1); par = 0;
+            unit = next_unit; b = nb_; td = ntd; td_end = ntd_end; o0h = nh; o0w = nw;
+        }
+        __syncthreads();
     }
 }
 
@@ -787,6 +926,8 @@ __global__ __launch_bounds__(256) void wgrad_c1_finish_kernel(const float* __res
     }
 }
 
+static int g_c1u_walk_min_units = CVAE_C1U_WALK_MIN_UNITS;
+
 }  // namespace
 
 // 1 when the vector-load form can read this image: whole 16-byte vectors per row and a 16-byte aligned base
@@ -839,6 +980,12 @@ int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* b
     return CVAE_OK;
 }
 
+int64_t cvae_tune_c1u_walk_min_units(int64_t min_units) {
+    const int64_t prev = g_c1u_walk_min_units;
+    if (min_units > 0 && min_units < ((int64_t)1 << 30)) g_c1u_walk_min_units = (int)min_units;
+    return prev;
+}
+
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream) {
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
@@ -852,6 +999,22 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
         const int ntiles = (int)ntiles_ll;
         dim3 mgrid((unsigned)(ntiles < CVAE_C1_MAX_WG ? ntiles : CVAE_C1_MAX_WG), 1, 1);      // a workgroup walks ntiles / grid tiles with one set of weight fragments
         const int epi = CVAE_EPI_OF(act);
+#if CVAE_C1U_WALK
+        if (nd == 3 && ntiles >= 2 * g_c1u_walk_min_units && tiles_d > 1) {   // long z columns: walk them, the shared halo planes stay in LDS
+            int walk = ntiles / g_c1u_walk_min_units;
+            if (walk > tiles_d) walk = tiles_d;
+            const int segs = (tiles_d + walk - 1) / walk;
+            const int nunits = (int)B * segs * tiles_h * tiles_w;
+            dim3 wgrid((unsigned)(nunits < CVAE_C1_MAX_WG ? nunits : CVAE_C1_MAX_WG), 1, 1);
+#define LAUNCH_UP_WALK_(EPI, MASKED) hipLaunchKernelGGL((up_c1_mfma_walk_kernel<EPI, MASKED>), wgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_d, tiles_h, tiles_w, walk, segs, nunits, act)
+#define LAUNCH_UP_WALK(EPI) do { if (mask) LAUNCH_UP_WALK_(EPI, true); else LAUNCH_UP_WALK_(EPI, false); } while (0)
+            if (epi == 0) LAUNCH_UP_WALK(0); else if (epi == 1) LAUNCH_UP_WALK(1); else LAUNCH_UP_WALK(2);
+#undef LAUNCH_UP_WALK
+#undef LAUNCH_UP_WALK_
+            CVAE_CHECK_LAUNCH();
+            return CVAE_OK;
+        }
+#endif
 #define LAUNCH_UP_MFMA_(ND, EPI, MASKED) hipLaunchKernelGGL((up_c1_mfma_kernel<ND, EPI, MASKED>), mgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_d, tiles_h, tiles_w, ntiles, act)
 #define LAUNCH_UP_MFMA(ND, EPI) do { if (mask) LAUNCH_UP_MFMA_(ND, EPI, true); else LAUNCH_UP_MFMA_(ND, EPI, false); } while (0)
         if (nd == 3) { if (epi == 0) LAUNCH_UP_MFMA(3, 0); else if (epi == 1) LAUNCH_UP_MFMA(3, 1); else LAUNCH_UP_MFMA(3, 2); }

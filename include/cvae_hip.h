@@ -347,6 +347,10 @@ int cvae_linear_bwd_weight_bf16(const float* dy, const float* x, float* dW, floa
  * cvae_conv_up of a 32-channel output with 64 input channels switches to the whole-K kernel (default 2048).  min_grid < 0 only queries.
  * Returns the previous value.  Both kernels compute the same product; the tests run every case through each. */
 int64_t cvae_tune_upfull_min_grid(int64_t min_grid);
+/* Same kind of hook for the bf16 3D cvae_conv_up_c1: a launch with at least 2 x min_units tiles (2 x 8 x 16 source voxels each) lets a workgroup
+ * walk ntiles / min_units consecutive tiles along z with the shared halo planes kept in LDS (default 1024).  min_units <= 0 only queries.
+ * Returns the previous value.  Same arithmetic per output voxel either way (bit-identical results). */
+int64_t cvae_tune_c1u_walk_min_units(int64_t min_units);
 
 /* ---- optimiser ---------------------------------------------------------------------------------------------- */
 /* torch.optim.Adam (no weight decay / amsgrad) on flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t

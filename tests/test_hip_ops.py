@@ -143,6 +143,35 @@ def test_conv_transpose_forward_backward(nd, B, Cl, Cs, size, dtype, split_k):
     close(bg.grad.cpu(), gb_ref, torch.float32, "db", scale=float(gb_ref.abs().max()) * 3)
 
 
+@pytest.mark.parametrize("B,ssize,act", [(3, (7, 9, 20), None), (2, (16, 8, 16), "sigmoid"), (1, (5, 3, 33), None)])
+def test_conv_up_c1_walking_z_columns_is_bit_identical(B, ssize, act):
+    """bf16 3D up convolution to one channel: large launches let a workgroup walk a z column of tiles and keep the shared halo planes in LDS
+    (up_c1_mfma_walk_kernel).  Every walk length — whole columns, ragged segments, none — must give the same bits, and those match the fp32
+    transposed convolution of the same bf16-rounded operands."""
+    g = torch.Generator().manual_seed(21)
+    x = rnd(torch.randn(B, 32, *ssize, generator=g), torch.bfloat16)
+    w = torch.randn(32, 1, 4, 4, 4, generator=g) / math.sqrt(32 * 8)
+    b = torch.randn(1, generator=g)
+    y_ref = F.conv_transpose3d(x, rnd(w, torch.bfloat16), b, stride=2, padding=1)
+    if act == "sigmoid":
+        y_ref = torch.sigmoid(y_ref)
+    xg, wg, bg = to_cl(x, torch.bfloat16), w.to(DEV), b.to(DEV)
+    tiles_d = (ssize[0] + 1) // 2
+    ntiles = B * tiles_d * ((ssize[1] + 7) // 8) * ((ssize[2] + 15) // 16)
+    outs = {}
+    prev = L.lib.cvae_tune_c1u_walk_min_units(-1)
+    try:
+        for name, units in [("none", 1 << 29), ("whole", 1), ("ragged", max(1, ntiles // 3)), ("pairs", max(1, ntiles // 2))]:
+            L.lib.cvae_tune_c1u_walk_min_units(units)
+            with torch.no_grad():
+                outs[name] = ops.ConvUp.apply(xg, wg, bg, 3, act, False, False).clone()
+    finally:
+        L.lib.cvae_tune_c1u_walk_min_units(prev)
+    close(from_cl(outs["none"], 3), y_ref, torch.bfloat16, "y")
+    for name in ("whole", "ragged", "pairs"):
+        assert torch.equal(outs[name], outs["none"]), name
+
+
 # --------------------------------------------------------------------------------------------- fp8 (e4m3) inference path
 def _e4m3_decode(codes):
     """uint8 OCP e4m3 codes -> fp32 (the CPU checker's own decode: torch.float8_e4m3fn is that format)."""
