@@ -5,7 +5,8 @@
 // The resized volume is 8x the decoder output (33.5 MB fp32 per batch of 4); written, re-read by the loss, re-read by the loss
 // backward, and its gradient written and re-read by the resize backward, it made ~240 MB of traffic around 2 MB of information.
 // Here the 2x resize is recomputed where it is needed from the small tensor:
-//   up2x_block_kernel<MODE 0>  recon = up(src)                     (model.forward: the volume a caller asked for)
+//   up2x_block_kernel<MODE 0>  recon = up(src)                     (model.forward: the volume a caller asked for; MODE 4: the same with nontemporal
+//                                                                   stores, for outputs of 256 MB and more — the counterfactual sweep writes 2 GB)
 //   up2x_block_kernel<MODE 1>  sum (up(src) - x)^2                 (ELBO forward without a backward to follow: reads x once, never writes the volume)
 //   up2x_block_kernel<MODE 3>  the same sum AND t1 = U_w^T (up(src) - x)   (ELBO forward of a training step: x is read ONCE per step; the
 //                              backward used to re-read it, 33.5 MB, in a launch of its own)
@@ -49,13 +50,23 @@ __device__ __forceinline__ Win4 win4(int i, int in, int out, float scale, bool s
     return r;
 }
 
+__device__ __forceinline__ void load4_f32(const float* p, float* o) { const float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void load4_f32(const bf16* p, float* o) {
+    const uint2 v = *(const uint2*)p;
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u); o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+#ifndef CVAE_UP2X_STREAM_BYTES
+#define CVAE_UP2X_STREAM_BYTES ((int64_t)256 << 20)          // cvae_up2x_fwd outputs from this size on use nontemporal stores (decode sweep: 707 -> 490 us with the vector loads)
+#endif
+
 // Exact 2x taps.  lin_tap() gives, for an even output o = 2 i: (i - 1, i) with weights (0.25, 0.75) — except o = 0: (0, 1) with
 // weights (1, 0) — and for an odd output o = 2 i + 1: (i, i + 1) with weights (0.75, 0.25), the upper index clamped to in - 1.
 // With source indices clamped on load the same values come out of a FIXED pattern: even -> (v[i-1], v[i]) x (0.25, 0.75), or x (0, 1)
 // at o = 0 (0*v0 + 1*v0 == 1*v0 + 0*v1); odd -> (v[i], v[i+1]) x (0.75, 0.25).  No per-output index arithmetic is left.
 __device__ __forceinline__ float2 even_w(int o) { return o == 0 ? make_float2(0.f, 1.f) : make_float2(0.25f, 0.75f); }
 
-// MODE 0: dst = up(src).  MODE 1: acc_out[block] = sum (up(src) - xin)^2.  MODE 3: MODE 1 and dst = t1[b][od][oh][x] = sum_ow Ww(ow -> x) (up(src) - xin).
+// MODE 0 / 4: dst = up(src).  MODE 1: acc_out[block] = sum (up(src) - xin)^2.  MODE 3: MODE 1 and dst = t1[b][od][oh][x] = sum_ow Ww(ow -> x) (up(src) - xin).
 // D == d (2D tensors) leaves the depth axis untouched.
 struct SmallBwd {                                            // the ELBO's small terms, ridden along the backward launch
     const float *m_hat, *m, *mu, *logvar;
@@ -71,9 +82,11 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
     const bool sdz = D != d;
     const float sw = (float)w / (float)W;
     const int wg = w >> 2, n = B * d * h * wg;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool live = i0 < n;
+    const int i = live ? i0 : n - 1;                         // idle lanes of the last block shadow the last item: the lane exchange below needs every lane
     float sse = 0.f;
-    if (i < n) {
+    {
         int r = i;
         const int xg = r % wg; r /= wg;
         const int y = r % h; r /= h;
@@ -90,9 +103,11 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
             for (int yr = 0; yr < 3; ++yr) {
                 const int yi = min(max(y - 1 + yr, 0), h - 1);
                 const T* row = src + ((size_t)(b * d + zi) * h + yi) * w;
-                float v[6];                                  // source x0 - 1 .. x0 + 4 (clamped)
-#pragma unroll
-                for (int c = 0; c < 6; ++c) v[c] = to_f32(row[min(max(x0 - 1 + c, 0), w - 1)]);
+                float v[6];                                  // source x0 - 1 .. x0 + 4 (clamped): one vector load, the two ends from the neighbouring lanes
+                load4_f32(row + x0, v + 1);
+                const float lft = __shfl_up(v[4], 1), rgt = __shfl_down(v[1], 1);
+                v[0] = (xg == 0) ? v[1] : (lane > 0 ? lft : to_f32(row[x0 - 1]));
+                v[5] = (xg == wg - 1) ? v[4] : (lane < 63 ? rgt : to_f32(row[x0 + 4]));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int jj = J0 + j;                   // ow = ow0 + jj, jj in [-1, 8]
@@ -114,7 +129,7 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            if (!sdz && a == 1) break;
+            if (!live || (!sdz && a == 1)) break;
             const int od = sdz ? 2 * z + a : z;
             // depth taps: rows (a, a + 1) with weights (dw.x, dw.y); on an unstrided depth axis all three rows hold plane z and dw = (1, 0)
             const int zr0 = a;
@@ -131,9 +146,15 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
                     o[j] = dw.x * lo + dw.y * hi;
                 }
                 const size_t rowoff = ((size_t)(b * D + od) * H + oh) * W;
-                if (MODE == 0) {
-                    *(float4*)(dst + rowoff + ow0) = make_float4(o[0], o[1], o[2], o[3]);
-                    *(float4*)(dst + rowoff + ow0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                if (MODE == 0 || MODE == 4) {
+                    const f32x4 oa = {o[0], o[1], o[2], o[3]}, ob = {o[4], o[5], o[6], o[7]};
+                    if (MODE == 4) {                         // a volume far beyond the L2 / MALL is written past them
+                        __builtin_nontemporal_store(oa, (f32x4*)(dst + rowoff + ow0));
+                        __builtin_nontemporal_store(ob, (f32x4*)(dst + rowoff + ow0 + 4));
+                    } else {
+                        *(f32x4*)(dst + rowoff + ow0) = oa;
+                        *(f32x4*)(dst + rowoff + ow0 + 4) = ob;
+                    }
                 } else {
                     const float4 xa = *(const float4*)(xin + rowoff + ow0), xb = *(const float4*)(xin + rowoff + ow0 + 4);
                     const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
@@ -243,8 +264,11 @@ extern "C" int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, 
     if (!up2x_ok(B, d, h, w, D, H, W)) return CVAE_E_UNSUPPORTED;
     if (!src || !dst) return CVAE_E_NULLPTR;
     const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
-    if (dtype == CVAE_BF16) hipLaunchKernelGGL((up2x_block_kernel<bf16, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
-    else if (dtype == CVAE_F32) hipLaunchKernelGGL((up2x_block_kernel<float, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{});
+    const bool stream_out = B * D * H * W * 4 >= CVAE_UP2X_STREAM_BYTES;
+#define UP2X_FWD(T, MODE) hipLaunchKernelGGL((up2x_block_kernel<T, MODE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{})
+    if (dtype == CVAE_BF16) { if (stream_out) UP2X_FWD(bf16, 4); else UP2X_FWD(bf16, 0); }
+    else if (dtype == CVAE_F32) { if (stream_out) UP2X_FWD(float, 4); else UP2X_FWD(float, 0); }
+#undef UP2X_FWD
     else return CVAE_E_DTYPE;
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
