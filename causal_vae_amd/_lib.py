@@ -69,6 +69,7 @@ SIGNATURES = {
     "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
     "cvae_tune_upfull_min_grid": [_i64],
     "cvae_tune_c1u_walk_min_units": [_i64],
+    "cvae_tune_xpair_min_wgs": [_i64],
     "cvae_linear_fwd_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
     "cvae_linear_bwd_data_bf16": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
     "cvae_linear_bwd_weight_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
@@ -124,7 +125,7 @@ SIGNATURES = {
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
-            "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64, "cvae_tune_upfull_min_grid": _i64, "cvae_tune_c1u_walk_min_units": _i64, "cvae_channel_sum_workspace_bytes": _sz,
+            "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64, "cvae_tune_upfull_min_grid": _i64, "cvae_tune_c1u_walk_min_units": _i64, "cvae_tune_xpair_min_wgs": _i64, "cvae_channel_sum_workspace_bytes": _sz,
             "cvae_linear_workspace_bytes": _sz, "cvae_reduce_workspace_bytes": _sz, "cvae_bn2d_workspace_bytes": _sz}
 
 for _name, _args in SIGNATURES.items():

@@ -74,6 +74,12 @@ __global__ __launch_bounds__(256) void pool_cat_fwd_kernel(const T* __restrict__
     }
 }
 
+#ifndef CVAE_BN_FWD_UNROLL
+#define CVAE_BN_FWD_UNROLL 2
+#endif
+#ifndef CVAE_BN_BWD_UNROLL
+#define CVAE_BN_BWD_UNROLL 8
+#endif
 // ------------------------------------------------------------------------------------------------ skinny_fwd_partial
 // partial[ks][m][n] = sum_{k in slice ks} x[m][k] W[n][k].  grid (N / 4, KS), 256 threads: 4 weight rows per workgroup share one
 // pass over the x slice; rows are read with coalesced 4-byte loads (K is odd in the model: rows are not 16-byte aligned).
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_partial_kernel(const float* __
     for (int r = 0; r < R; ++r) wr[r] = Wt + (size_t)min(n0 + r, N - 1) * K;
     // 16-byte loads at dword alignment (rows of odd length are not 16-byte aligned); the < 4-element tail of the slice goes scalar
     const int kvec = k0 + ((k1 - k0) & ~3);
-#pragma unroll 2
+#pragma unroll CVAE_BN_FWD_UNROLL
     for (int k = k0 + 4 * threadIdx.x; k < kvec; k += 1024) {
         F4U xv[MT], wv[R];
 #pragma unroll
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
         }
         __syncthreads();
         if (nk == 4) {
-#pragma unroll 8
+#pragma unroll CVAE_BN_BWD_UNROLL
             for (int j = 0; j < cnt; ++j) {
                 const F4U w = *(const F4U*)(Wt + (size_t)(nb + j) * K + k0);
                 F4U dw = {0.f, 0.f, 0.f, 0.f};

@@ -193,7 +193,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // TS ("K split", BD only): TS = 2 wave groups of WM x WN waves each own every second k-step (odd / even taps for KH = 1, the two 16-channel halves
 // of a stage for KH = 2) of the WHOLE tile and add their accumulators through LDS once, before the epilogue.  With WM = 1 no two waves fetch the
 // same weight fragment, and a fetched fragment feeds MI = 4 MFMAs: half the bytes per MFMA on the vector-memory path the BD tap loop is bound by.
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = false, int TS = 1>
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = false, int TS = 1, int XB = 1>
 __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                   const TO* __restrict__ mask, TO* __restrict__ out, ConvGeom g, int act,
                                                                   float* __restrict__ ws, int ksplit, float acc_scale, float out_scale) {
@@ -207,7 +207,11 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     // parity — 405 instead of the parity-independent 600 positions for 4 x 8 x 8 tiles (the halo loads are the largest single cost of
     // the `up` launches: 29 of 78 us on enc2's backward-data by ablation).
     constexpr int ID = (ND == 3) ? (UP ? TD + 1 : 2 * TD + 2) : 1;
-    constexpr int IH = UP ? TH + 1 : 2 * TH + 2, IW = UP ? TW + 1 : 2 * TW + 2;
+    // XB == 2: a layer at most TW / 2 wide puts two samples side by side in x (the 4^3 decoder input would leave half of every MFMA row tile
+    // empty): sample s owns tile columns [s TW / 2, (s + 1) TW / 2) and its own HWS halo columns, so a row of the halo is two sample rows with
+    // the zero padding of each in place; a tile column w reads slot w + s (+ tap), which is one more term in the per-lane base.
+    static_assert(XB == 1 || XB == 2, "one sample per tile, or two side by side in x");
+    constexpr int IH = UP ? TH + 1 : 2 * TH + 2, IW = (UP ? TW + 1 : 2 * TW + 2) + (XB - 1) * (UP ? 1 : 2), HWS = IW / XB;
     constexpr int NPOS = ID * IH * IW;
     constexpr int FB = 8 * sizeof(T);                    // bytes of one fragment piece (8 channels)
     constexpr int NG = UP ? (ND == 3 ? 2 : 1) : (ND == 3 ? 16 : 4);   // tap groups of 4
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     const int ts = wave / (WM * WN), wv = wave % (WM * WN);      // K-split group (0 when TS == 1)
     const int wm = wv / WN, wn = wv % WN;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z * XB;
     const int Cin = UP ? g.Cs : g.Cl, Cout = UP ? g.Cl : g.Cs;
     const int nblocks = Cout / BN;
     constexpr int NPAR = UP ? (ND == 3 ? 8 : 4) : 1;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     for (int mi = 0; mi < MI; ++mi) {
         const int ms = wm * MI + mi;
         const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
-        pbase[mi] = UP ? (d * IH + hh) * RS + w : ((2 * d) * IH + 2 * hh) * RS + w;
+        pbase[mi] = (UP ? (d * IH + hh) * RS + w : ((2 * d) * IH + 2 * hh) * RS + w) + ((XB == 2 && w >= TW / 2) ? 1 : 0);
     }
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -305,10 +309,11 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
         int x = pos0 % IW, y = (pos0 / IW) % IH, z = pos0 / (IW * IH);
 #pragma unroll
         for (int i = 0; i < HN; ++i) {
-            const int gz = g0d + z, gy = g0h + y, gx = g0w + x;
+            const int sx = (XB == 2 && x >= HWS) ? 1 : 0;   // sample of this halo column (its columns restart at the sample's own left padding)
+            const int gz = g0d + z, gy = g0h + y, gx = g0w + x - sx * HWS;
             const bool inbox = z < ID;
-            const bool ok = inbox & (gz >= 0) & (gz < in_d) & (gy >= 0) & (gy < in_h) & (gx >= 0) & (gx < in_w);
-            hoff[i] = ok ? (((gz * in_h + gy) * in_w + gx) * Cin + 8 * half) : -1;
+            const bool ok = inbox & (gz >= 0) & (gz < in_d) & (gy >= 0) & (gy < in_h) & (gx >= 0) & (gx < in_w) & (b + sx < g.B);
+            hoff[i] = ok ? ((((sx * in_d + gz) * in_h + gy) * in_w + gx) * Cin + 8 * half) : -1;
             hdst[i] = inbox ? (half * PLANE + hslot(z, y, x)) * FB : -1;
             x += DX; if (x >= IW) { x -= IW; y += 1; }
             y += DY; if (y >= IH) { y -= IH; z += 1; }
@@ -394,12 +399,13 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
 #pragma unroll
             for (int mo = 0; mo < MO; ++mo) {
                 const int mi = mi0 + mo, ms = wm * MI + mi;
-                const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
+                const int wt = ST::w_of(r), sx = (XB == 2 && wt >= TW / 2) ? 1 : 0, w = wt - sx * (TW / 2);
+                const int hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
                 int od, oh, ow;
                 if (UP) { od = (ND == 3) ? 2 * (o0d + d) + prd : 0; oh = 2 * (o0h + hh) + prh; ow = 2 * (o0w + w) + prw; }
                 else { od = o0d + d; oh = o0h + hh; ow = o0w + w; }
-                const bool ok = od < out_d && oh < out_h && ow < out_w;
-                const size_t pidx = ok ? ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout : 0;
+                const bool ok = od < out_d && oh < out_h && ow < out_w && b + sx < g.B;
+                const size_t pidx = ok ? ((((size_t)(b + sx) * out_d + od) * out_h + oh) * out_w + ow) * Cout : 0;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -560,12 +566,13 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     for (int mo = 0; mo < MO; ++mo) {
         const int mi = mi0c + mo;
         const int ms = wm * MI + mi;                                            // same lane -> position map as pbase
-        const int w = ST::w_of(r), hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
+        const int wt = ST::w_of(r), sx = (XB == 2 && wt >= TW / 2) ? 1 : 0, w = wt - sx * (TW / 2);
+        const int hh = (ms % HB) * ST::SH + ST::h_of(r), d = ms / HB;
         int od, oh, ow;
         if (UP) { od = (ND == 3) ? 2 * (o0d + d) + prd : 0; oh = 2 * (o0h + hh) + prh; ow = 2 * (o0w + w) + prw; }
         else { od = o0d + d; oh = o0h + hh; ow = o0w + w; }
-        const bool ok = od < out_d && oh < out_h && ow < out_w;
-        const size_t pidx = ((((size_t)b * out_d + od) * out_h + oh) * out_w + ow) * Cout;
+        const bool ok = od < out_d && oh < out_h && ow < out_w && b + sx < g.B;
+        const size_t pidx = ((((size_t)(b + sx) * out_d + od) * out_h + oh) * out_w + ow) * Cout;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             float v[2][8];
@@ -660,6 +667,15 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
     piece_store<T>(op, (char*)(out + i8));
 }
 
+#ifndef CVAE_XPAIR
+#define CVAE_XPAIR 1                    // two samples per tile (XB = 2) for layers at most half a tile wide
+#endif
+#ifndef CVAE_XPAIR_MIN_WGS
+#define CVAE_XPAIR_MIN_WGS 2048
+#endif
+static long long g_xpair_min_wgs = CVAE_XPAIR_MIN_WGS;
+static long long g_upfull_min_grid = CVAE_UPFULL_MIN_GRID;
+
 // Split-K factor for a launch of `nwg` workgroups over `nchunks` channel chunks: the layers with 8^3 / 4^3 grids fill a fraction
 // of the 256 CUs with one long serial K loop each; slicing K puts ~2 workgroups on every CU.  Largest divisor of nchunks <= target.
 // Only `down` splits: an `up` launch already has 8 (4) parity classes per tile and its output is 8x (4x) its input, so the fp32 slabs
@@ -675,7 +691,7 @@ static int pick_ksplit(bool up, long long nwg, int nchunks) {
     return best;
 }
 
-template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = (CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2), int TS = 1>
+template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = (CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2), int TS = 1, int XB = 1>
 int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
                     size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -688,13 +704,19 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     constexpr size_t LDS_X = TS == 2 ? (size_t)WM * WN * TS * (MI / 2) * NI * 16 * 64 * sizeof(float) : 0;      // the K split's accumulator exchange
     constexpr size_t LDS = LDS_MAIN > LDS_X ? LDS_MAIN : LDS_X;
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
-    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS>;
+    const int md = UP ? ((ND == 3) ? (g.ld + 1) / 2 : 1) : g.sd, mh = UP ? (g.lh + 1) / 2 : g.sh, mw = UP ? (g.lw + 1) / 2 : g.sw;
+    if constexpr (CVAE_XPAIR && XB == 1 && UP && ND == 3 && (TS == 2 || sizeof(T) == 1)) {
+        // a layer at most half a tile wide, on a launch that fills the chip several times over (the decode sweep's 4^3 -> 8^3 layer): two samples per tile
+        const long long wgs = (long long)((md + TL::TD - 1) / TL::TD) * ((mh + TL::TH - 1) / TL::TH) * ((UP ? g.Cl : g.Cs) / BN) * 8 * g.B;
+        if (mw <= TL::TW / 2 && g.B >= 2 && wgs >= g_xpair_min_wgs)
+            return launch_data_epi<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, 2>(in, wp, bias, mask, out, g, act, workspace, workspace_bytes, stream, acc_scale, out_scale);
+    }
+    auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, XB>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return CVAE_E_LAUNCH;
         attr_set = true;
     }
-    const int md = UP ? ((ND == 3) ? (g.ld + 1) / 2 : 1) : g.sd, mh = UP ? (g.lh + 1) / 2 : g.sh, mw = UP ? (g.lw + 1) / 2 : g.sw;
     g.tiles_d = (md + TL::TD - 1) / TL::TD; g.tiles_h = (mh + TL::TH - 1) / TL::TH; g.tiles_w = (mw + TL::TW - 1) / TL::TW;
     const int Cout = UP ? g.Cl : g.Cs, Cin = UP ? g.Cs : g.Cl;
     const int npar = UP ? ((ND == 3) ? 8 : 4) : 1;
@@ -706,7 +728,7 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     if (sizeof(T) == 1) ksplit = 1;                          // fp8: forward `up` only, never split
     gy *= ksplit;
     if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
-    dim3 grid((unsigned)tiles, (unsigned)gy, (unsigned)g.B);
+    dim3 grid((unsigned)tiles, (unsigned)gy, (unsigned)((g.B + XB - 1) / XB));
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * TS * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const TO*)mask, (TO*)out, g, act, (float*)workspace, ksplit,
                        acc_scale, out_scale);
     CVAE_CHECK_LAUNCH();
@@ -1002,7 +1024,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_up_full_kernel(const T* __r
 #endif
 }
 
-static long long g_upfull_min_grid = CVAE_UPFULL_MIN_GRID;
 template <typename T, int ND, int WM, int WN, int MI, int NI, int KCH> constexpr size_t up_full_lds_bytes() {
     using TL = Tile<ND, WM * MI * 32>;
     constexpr int ID = (ND == 3) ? TL::TD + 2 : 1, IH = TL::TH + 2;
@@ -1580,6 +1601,12 @@ extern "C" int cvae_debug_stamps(unsigned long long* host, size_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), count * sizeof(unsigned long long)) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
 }
 #endif
+
+extern "C" int64_t cvae_tune_xpair_min_wgs(int64_t min_wgs) {
+    const long long prev = g_xpair_min_wgs;
+    if (min_wgs >= 0) g_xpair_min_wgs = min_wgs;
+    return prev;
+}
 
 extern "C" int64_t cvae_tune_upfull_min_grid(int64_t min_grid) {      // < 0: query only.  Returns the previous threshold.  Tests set 0 to run every `up` case through both kernels.
     const long long prev = g_upfull_min_grid;

@@ -351,6 +351,10 @@ int64_t cvae_tune_upfull_min_grid(int64_t min_grid);
  * walk ntiles / min_units consecutive tiles along z with the shared halo planes kept in LDS (default 1024).  min_units <= 0 only queries.
  * Returns the previous value.  Same arithmetic per output voxel either way (bit-identical results). */
 int64_t cvae_tune_c1u_walk_min_units(int64_t min_units);
+/* And for the 3D cvae_conv_up / cvae_conv_up_fp8 of a layer at most 4 source voxels wide (the decoder's 4^3 input): from min_wgs workgroups on,
+ * a tile carries two samples side by side instead of one sample and an empty half (default 2048; 0 = always, < 0 only queries).  Returns the
+ * previous value.  Same products and the same summation order per output element (bit-identical results). */
+int64_t cvae_tune_xpair_min_wgs(int64_t min_wgs);
 
 /* ---- optimiser ---------------------------------------------------------------------------------------------- */
 /* torch.optim.Adam (no weight decay / amsgrad) on flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t

@@ -172,6 +172,37 @@ def test_conv_up_c1_walking_z_columns_is_bit_identical(B, ssize, act):
         assert torch.equal(outs[name], outs["none"]), name
 
 
+@pytest.mark.parametrize("B,Cs,Cl,ssize,act,masked", [(3, 256, 128, (4, 4, 4), "relu", False), (2, 128, 64, (4, 3, 4), None, True), (5, 128, 64, (2, 4, 3), "relu", True),
+                                                      (4, 64, 64, (8, 5, 2), None, False)])
+def test_conv_up_two_samples_per_tile_is_bit_identical(B, Cs, Cl, ssize, act, masked):
+    """bf16 3D up convolution of a layer at most 4 source voxels wide (the decoder's 4^3 input): large launches put two samples side by side in one
+    tile (conv_data_kernel<XB = 2>) instead of leaving half of it empty.  Same products in the same order: the bits must not move, with an odd
+    batch (a lone sample in the last tile), a ReLU mask on the output and narrower-than-4 rows; and they match the fp32 transposed convolution."""
+    g = torch.Generator().manual_seed(23)
+    x = rnd(torch.randn(B, Cs, *ssize, generator=g), torch.bfloat16)
+    w = torch.randn(Cs, Cl, 4, 4, 4, generator=g) / math.sqrt(Cs * 8)
+    b = torch.randn(Cl, generator=g)
+    y_ref = F.conv_transpose3d(x, rnd(w, torch.bfloat16), b, stride=2, padding=1)
+    if act == "relu":
+        y_ref = F.relu(y_ref)
+    mask = (torch.rand(y_ref.shape, generator=g) > 0.4).float() if masked else None
+    if masked:
+        y_ref = y_ref * mask
+    xg, bg = to_cl(x, torch.bfloat16), b.to(DEV)
+    wp = ops.pack_weight(w.to(DEV), 3, True, torch.bfloat16)
+    mg = to_cl(mask, torch.bfloat16) if masked else None
+    outs = {}
+    prev = L.lib.cvae_tune_xpair_min_wgs(-1)
+    try:
+        for name, wgs in [("single", 1 << 40), ("paired", 0)]:
+            L.lib.cvae_tune_xpair_min_wgs(wgs)
+            outs[name] = ops._conv_up(xg, wp, bg, mg, Cl, 3, act).clone()
+    finally:
+        L.lib.cvae_tune_xpair_min_wgs(prev)
+    close(from_cl(outs["single"], 3), y_ref, torch.bfloat16, "y")
+    assert torch.equal(outs["paired"], outs["single"])
+
+
 # --------------------------------------------------------------------------------------------- fp8 (e4m3) inference path
 def _e4m3_decode(codes):
     """uint8 OCP e4m3 codes -> fp32 (the CPU checker's own decode: torch.float8_e4m3fn is that format)."""
@@ -193,9 +224,17 @@ def test_quantize_fp8_codes_bit_exact(dtype):
     assert bool(same.all()), f"{int((~same).sum())} codes differ"
 
 
+@pytest.fixture(params=[False, True], ids=["single", "paired"])
+def xpair(request):
+    """Narrow 3D `up` layers (at most 4 source voxels wide) with one sample per tile, and with two side by side (the large-launch form)."""
+    prev = L.lib.cvae_tune_xpair_min_wgs(0 if request.param else 1 << 40)
+    yield request.param
+    L.lib.cvae_tune_xpair_min_wgs(prev)
+
+
 @pytest.mark.parametrize("nd,B,Cl,Cs,ssize,act,q_out", [(3, 2, 128, 256, (4, 4, 4), "relu", True), (3, 3, 64, 128, (8, 8, 8), "relu", False), (3, 1, 32, 64, (5, 6, 9), None, True),
-                                                        (2, 2, 32, 64, (12, 20), "relu", False)])
-def test_conv_up_fp8_matches_dequantised_reference(nd, B, Cl, Cs, ssize, act, q_out):
+                                                        (2, 2, 32, 64, (12, 20), "relu", False), (3, 3, 128, 256, (4, 4, 3), "relu", False)])
+def test_conv_up_fp8_matches_dequantised_reference(nd, B, Cl, Cs, ssize, act, q_out, xpair):
     """cvae_conv_up_fp8 on fp8 codes == conv_transpose (fp32, CPU) of the DEQUANTISED operands: the kernel adds no error beyond the quantisation it is
     given (fp32 accumulation; the result is rounded once to bf16, 2^-8, or to e4m3 codes, 2^-4 relative)."""
     g = torch.Generator().manual_seed(5)
