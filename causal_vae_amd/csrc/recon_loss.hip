@@ -56,6 +56,9 @@ __device__ __forceinline__ void load4_f32(const bf16* p, float* o) {
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u); o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
+#ifndef CVAE_UP2X_TILE
+#define CVAE_UP2X_TILE 1
+#endif
 #ifndef CVAE_UP2X_STREAM_BYTES
 #define CVAE_UP2X_STREAM_BYTES ((int64_t)256 << 20)          // cvae_up2x_fwd outputs from this size on use nontemporal stores (decode sweep: 707 -> 490 us with the vector loads)
 #endif
@@ -190,6 +193,89 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
     }
 }
 
+// The large-output form of MODE 0 for 3D volumes (the counterfactual sweep resizes 240 x 64^3 to 128^3: 2 GB of fp32): a workgroup stages the
+// 4 x 10 x 66 source values around a 2 x 8 x 64 source tile in LDS once (vector loads, edges clamped), every thread then produces the 2 x 2 output
+// rows of two (z, y) source rows for one group of 4 output columns — one 16-byte store per row, 64 lanes = two complete 512-byte row segments per
+// instruction.  Same taps and weights as up2x_block_kernel (even outputs (0.25, 0.75) of (i - 1, i), (0, 1) at o = 0; odd (0.75, 0.25) of (i, i + 1)).
+// Measured on the sweep (2 GB out): 503 -> ~350 us, the rate of a plain 2 GB fill on this GPU (345-360 us, tools/probes/hbm_probe.hip); outputs of
+// 256 MB and more are stored nontemporal (-20 us there).
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void up2x_tile_kernel(const T* __restrict__ src, float* __restrict__ dst, int d, int h, int w) {
+    constexpr int TZ = 2, TY = 8, TX = 64, PZ = TZ + 2, PY = TY + 2, PITCH = TX + 4;     // 66 used; 68 keeps rows 16-byte aligned
+    constexpr int VEC = 16 / sizeof(T), SEGS = TX / VEC;
+    __shared__ __attribute__((aligned(16))) float tile[PZ * PY * PITCH];
+    const int t = threadIdx.x;
+    int blk = blockIdx.x;
+    const int xt = blk % (w / TX); blk /= (w / TX);
+    const int yt = blk % (h / TY); blk /= (h / TY);
+    const int zt = blk % (d / TZ), b = blk / (d / TZ);
+    const int x0 = xt * TX, y0 = yt * TY, z0 = zt * TZ;
+    const T* sb = src + (size_t)b * d * h * w;
+    // interior: PZ * PY rows of TX values as 16-byte vectors; edges: the two clamped neighbours of every row
+    for (int i = t; i < PZ * PY * SEGS; i += 256) {
+        const int seg = i % SEGS, row = i / SEGS, py = row % PY, pz = row / PY;
+        const int zi = min(max(z0 - 1 + pz, 0), d - 1), yi = min(max(y0 - 1 + py, 0), h - 1);
+        float v[VEC];
+        if constexpr (sizeof(T) == 2) {
+            const uint4 q = *(const uint4*)(sb + ((size_t)zi * h + yi) * w + x0 + seg * VEC);
+            const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(u[e] << 16); v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+        } else {
+            const float4 q = *(const float4*)(sb + ((size_t)zi * h + yi) * w + x0 + seg * VEC);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        }
+        float* o = tile + row * PITCH + 1 + seg * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = v[e];
+    }
+    if (t < 2 * PZ * PY) {
+        const int side = t & 1, row = t >> 1, py = row % PY, pz = row / PY;
+        const int zi = min(max(z0 - 1 + pz, 0), d - 1), yi = min(max(y0 - 1 + py, 0), h - 1);
+        const int xi = side ? min(x0 + TX, w - 1) : max(x0 - 1, 0);
+        tile[row * PITCH + (side ? TX + 1 : 0)] = to_f32(sb[((size_t)zi * h + yi) * w + xi]);
+    }
+    __syncthreads();
+    const int xq = t & 31, yl = t >> 5;                       // output columns 4 (x0 / 2 .. ) : source x0 + 2 xq - 1 .. x0 + 2 xq + 2 = tile columns 2 xq .. 2 xq + 3
+    const int ow0 = 2 * x0 + 4 * xq;
+    const float2 ew0 = even_w(ow0);
+    float P[PZ][3][4];
+#pragma unroll
+    for (int pz = 0; pz < PZ; ++pz)
+#pragma unroll
+        for (int yr = 0; yr < 3; ++yr) {
+            const float* rp = tile + (pz * PY + yl + yr) * PITCH + 2 * xq;
+            const float2 va = *(const float2*)rp, vb = *(const float2*)(rp + 2);
+            const float v[4] = {va.x, va.y, vb.x, vb.y};
+            P[pz][yr][0] = ew0.x * v[0] + ew0.y * v[1];
+            P[pz][yr][1] = 0.75f * v[1] + 0.25f * v[2];
+            P[pz][yr][2] = 0.25f * v[1] + 0.75f * v[2];
+            P[pz][yr][3] = 0.75f * v[2] + 0.25f * v[3];
+        }
+    const int D = 2 * d, H = 2 * h, W = 2 * w;
+#pragma unroll
+    for (int zl = 0; zl < TZ; ++zl)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int od = 2 * (z0 + zl) + a;
+            const float2 dw = (a == 0) ? even_w(od) : make_float2(0.75f, 0.25f);
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+                const int oh = 2 * (y0 + yl) + bq;
+                const float2 hw = (bq == 0) ? even_w(oh) : make_float2(0.75f, 0.25f);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = hw.x * P[zl + a][bq][j] + hw.y * P[zl + a][bq + 1][j];
+                    const float hi = hw.x * P[zl + a + 1][bq][j] + hw.y * P[zl + a + 1][bq + 1][j];
+                    o[j] = dw.x * lo + dw.y * hi;
+                }
+                f32x4* op = (f32x4*)(dst + (((size_t)b * D + od) * H + oh) * W + ow0);
+                if (NT) __builtin_nontemporal_store(o, op); else *op = o;
+            }
+        }
+}
+
 // d src[b][z][y][x .. x + 3] = gs sum_{od, oh} Wd(od -> z) Wh(oh -> y) t1[b][od][oh][x ..], gs = 2 * (*gout) (1 when null).  One extra block
 // (blockIdx.x == sb.main_blocks) writes the gradients of the ELBO's small terms.
 template <typename T>
@@ -265,6 +351,18 @@ extern "C" int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, 
     if (!src || !dst) return CVAE_E_NULLPTR;
     const unsigned grid = (unsigned)((B * d * h * (w / 4) + 255) / 256);
     const bool stream_out = B * D * H * W * 4 >= CVAE_UP2X_STREAM_BYTES;
+#if CVAE_UP2X_TILE
+    if (D == 2 * d && d % 2 == 0 && h % 8 == 0 && w % 64 == 0 && (dtype == CVAE_BF16 || dtype == CVAE_F32)) {      // rows of 64: the LDS-tiled form
+        const dim3 tgrid((unsigned)(B * (d / 2) * (h / 8) * (w / 64)));
+        hipStream_t st = (hipStream_t)stream;
+#define UP2X_TILE(T, NT) hipLaunchKernelGGL((up2x_tile_kernel<T, NT>), tgrid, dim3(256), 0, st, (const T*)src, dst, (int)d, (int)h, (int)w)
+        if (dtype == CVAE_BF16) { if (stream_out) UP2X_TILE(bf16, true); else UP2X_TILE(bf16, false); }
+        else { if (stream_out) UP2X_TILE(float, true); else UP2X_TILE(float, false); }
+#undef UP2X_TILE
+        CVAE_CHECK_LAUNCH();
+        return CVAE_OK;
+    }
+#endif
 #define UP2X_FWD(T, MODE) hipLaunchKernelGGL((up2x_block_kernel<T, MODE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{})
     if (dtype == CVAE_BF16) { if (stream_out) UP2X_FWD(bf16, 4); else UP2X_FWD(bf16, 0); }
     else if (dtype == CVAE_F32) { if (stream_out) UP2X_FWD(float, 4); else UP2X_FWD(float, 0); }

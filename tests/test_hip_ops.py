@@ -325,7 +325,8 @@ def test_adaptive_avgpool_flatten(nd, size, out, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("nd,src,dst", [(2, (64, 64), (64, 96)), (2, (64, 64), (128, 160)), (2, (16, 16), (9, 11)), (3, (16, 16, 16), (32, 32, 32)),
-                                        (3, (8, 8, 8), (12, 20, 9)), (3, (8, 8, 8), (8, 8, 8))])
+                                        (3, (8, 8, 8), (12, 20, 9)), (3, (8, 8, 8), (8, 8, 8)),
+                                        (3, (4, 8, 64), (8, 16, 128)), (3, (2, 16, 128), (4, 32, 256))])     # rows of 64: the LDS-tiled exact-2x kernel (one and two x tiles)
 def test_upsample_linear(nd, src, dst, dtype):
     g = torch.Generator().manual_seed(5)
     x = rnd(torch.randn(2, 1, *src, generator=g), dtype).requires_grad_(True)
