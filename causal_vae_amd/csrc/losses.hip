@@ -776,8 +776,9 @@ extern "C" int cvae_scale(float* g, int64_t n, const float* scale, void* stream)
 __global__ void clip_coef_kernel(const float* __restrict__ sq, float* __restrict__ scale, float max_norm) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *scale = fminf(1.f, max_norm / (sqrtf(*sq) + 1e-6f));
 }
-// out[0] = sum_i w[i] * *t[i] (forward), or out[i] = w[i] * *g for every i (backward, g NULL = 1): the weighted sum of up to 8 scalar loss terms and
-// its gradients as ONE launch each (composed from torch scalar ops the vessel recipe's total was ~20 launches of < 5 us).
+// out[0] = sum_i w[i] * *t[i] and out[1 + i] = w[i] * *t[i] (forward: the total and the weighted terms a training loop logs), or out[i] = w[i] * *g for
+// every i (backward, g NULL = 1): the weighted sum of up to 8 scalar loss terms and its gradients as ONE launch each (composed from torch scalar ops
+// the vessel recipe's total was ~20 launches of < 5 us).
 struct Scalars8 { const float* t[8]; float w[8]; int n; };
 __global__ void weighted_sum_kernel(Scalars8 a, const float* __restrict__ g, float* __restrict__ out, int backward) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -786,7 +787,7 @@ __global__ void weighted_sum_kernel(Scalars8 a, const float* __restrict__ g, flo
         for (int i = 0; i < a.n; ++i) out[i] = a.w[i] * gv;
     } else {
         float s = 0.f;
-        for (int i = 0; i < a.n; ++i) s += a.w[i] * *a.t[i];              // index order: reproducible
+        for (int i = 0; i < a.n; ++i) { const float v = a.w[i] * *a.t[i]; out[1 + i] = v; s += v; }     // index order: reproducible
         out[0] = s;
     }
 }

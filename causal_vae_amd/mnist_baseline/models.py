@@ -37,9 +37,12 @@ class CausalMorphVAE12(nn.Module):
         """Decoder half: cat[m_hat, z] -> dec_fc -> dec_conv (check_mnist_counterfactual.py:72-74, any number of rows at once)."""
         return self.dec_conv(self.dec_fc(ops.cat([m_hat, z])).view(-1, 64, 7, 7))
 
+    def encode(self, x, m, t):
+        """Encoder half: enc_conv -> cat[x_feat, m, t] -> enc_fc; returns the [B, 2 z] head (mu | logvar) (models.py:55-60 of the reference)."""
+        return self.enc_fc(ops.cat([self.enc_conv(x), m, t]))
+
     def forward(self, x, m, t, eps=None):
-        x_feat = self.enc_conv(x)
-        mu, logvar = self.enc_fc(ops.cat([x_feat, m, t])).chunk(2, dim=1)
+        mu, logvar = self.encode(x, m, t).chunk(2, dim=1)
         z = self.reparameterize(mu, logvar, eps)
         m_hat = self.morph_predictor(t)
         h = self.dec_fc(ops.cat([m_hat, z])).view(-1, 64, 7, 7)

@@ -21,26 +21,35 @@ def train_step(vae, discriminator, opt_vae, opt_d, x, m, t, eps=None, beta=None,
     eps_d, eps_vae, eps_adv = eps if eps is not None else (None, None, None)
     t_indices = torch.argmax(t, dim=1)
     # ---- 1. discriminator ----
+    # the reference runs the whole VAE here (:47) and keeps mu, logvar: the decoder half of that no-grad forward reaches no result, so only
+    # the encoder half runs (same mu, logvar, bit for bit)
     opt_d.zero_grad(set_to_none=True)
     with torch.no_grad():
-        _, _, mu, logvar = vae(x, m, t, eps=eps_d)
+        mu, logvar = vae.encode(x, m, t).chunk(2, dim=1)
         z = vae.reparameterize(mu, logvar, eps_d)
     loss_d = ops.SoftmaxCE.apply(discriminator(z), t_indices)
-    loss_d.backward()
+    ops.backward_from(loss_d)
     opt_d.step()
     # ---- 2. VAE ----
+    # the adversarial term back-propagates THROUGH the discriminator; its own parameter gradients from this pass are dead in the reference too
+    # (opt_d.zero_grad() drops them before the next D step reads anything), so they are not computed
     opt_vae.zero_grad(set_to_none=True)
-    recon_x, m_hat, mu, logvar = vae(x, m, t, eps=eps_vae)
-    loss_recon = ops.bce_sum(recon_x.view(-1, 784), x.view(-1, 784))
-    loss_kld = ops.KLD.apply(mu, logvar) * beta
-    loss_morph = ops.sse(m_hat, m) * 100
-    z_sample = vae.reparameterize(mu, logvar, eps_adv)
-    loss_adv = ops.UniformKL.apply(discriminator(z_sample)) * lambda_adv * 100
-    loss = loss_recon + loss_kld + loss_morph + loss_adv
-    loss.backward()
+    d_params = [p for p in discriminator.parameters() if p.requires_grad]
+    for p in d_params:
+        p.requires_grad_(False)
+    try:
+        recon_x, m_hat, mu, logvar = vae(x, m, t, eps=eps_vae)
+        loss_recon = ops.bce_sum(recon_x.view(-1, 784), x.view(-1, 784))
+        z_sample = vae.reparameterize(mu, logvar, eps_adv)
+        # loss = recon + BETA * kld + 100 * morph + LAMBDA_ADV * 100 * adv: one launch for the sum and the four logged terms, one for their gradients
+        loss, parts = ops.weighted_sum([loss_recon, ops.KLD.apply(mu, logvar), ops.sse(m_hat, m), ops.UniformKL.apply(discriminator(z_sample))],
+                                       [1.0, beta, 100.0, lambda_adv * 100.0], return_terms=True)
+        ops.backward_from(loss)
+    finally:
+        for p in d_params:
+            p.requires_grad_(True)
     opt_vae.step()
-    return dict(loss=loss.detach(), loss_d=loss_d.detach(), recon=loss_recon.detach(), kld=loss_kld.detach(),
-                morph=loss_morph.detach(), adv=loss_adv.detach())
+    return dict(loss=loss.detach(), loss_d=loss_d.detach(), recon=parts[0], kld=parts[1], morph=parts[2], adv=parts[3])
 
 
 def train_model(train_loader, epochs=None, device=None, verbose=True):

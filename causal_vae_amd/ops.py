@@ -1026,7 +1026,8 @@ class ElboUp2x(torch.autograd.Function):
 
 
 class WeightedSum(torch.autograd.Function):
-    """sum_i w_i * t_i of 0-dim device tensors as one launch (and one for all the gradients): a loss composed of several terms."""
+    """sum_i w_i * t_i of 0-dim device tensors as one launch (and one for all the gradients): a loss composed of several terms.
+    Returns (total, weighted terms [n]); only the total carries a gradient (the weighted terms are what a training loop logs)."""
 
     @staticmethod
     def forward(ctx, weights, *terms):
@@ -1038,14 +1039,16 @@ class WeightedSum(torch.autograd.Function):
         ts = [t.float().contiguous() for t in terms]
         if any(t.numel() != 1 for t in ts):
             raise L.CvaeError("WeightedSum: scalar (0-dim) terms expected")
-        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        out = torch.empty(n + 1, dtype=torch.float32, device=ts[0].device)
         check(lib.cvae_weighted_sum((C.c_void_p * n)(*[t.data_ptr() for t in ts]), (C.c_float * n)(*[float(w) for w in weights]), n, None, ptr(out), 0, stream()), "weighted_sum")
         ctx.weights = [float(w) for w in weights]
         ctx.shapes = [t.shape for t in terms]
-        return out
+        total, parts = out[0], out[1:]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gparts):
         import ctypes as C
         n = len(ctx.weights)
         out = torch.empty(n, dtype=torch.float32, device=g.device)
@@ -1053,8 +1056,10 @@ class WeightedSum(torch.autograd.Function):
         return (None,) + tuple(out[i].view(ctx.shapes[i]) for i in range(n))
 
 
-def weighted_sum(terms, weights):
-    return WeightedSum.apply(tuple(weights), *terms)
+def weighted_sum(terms, weights, return_terms=False):
+    """sum_i weights[i] * terms[i]; with return_terms also the n weighted terms (a [n] tensor, no gradient)."""
+    total, parts = WeightedSum.apply(tuple(weights), *terms)
+    return (total, parts) if return_terms else total
 
 
 def sse(a, b):

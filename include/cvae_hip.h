@@ -372,8 +372,9 @@ int cvae_multi_copy(const float* const* src, float* const* dst, const int64_t* n
 int cvae_counter_add(int* counter, int delta, void* stream);
 /* *out += sum g^2 */
 int cvae_sqnorm(const float* g, float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
-/* Weighted sum of up to 8 scalar (0-dim, device) loss terms: backward == 0: out[0] = sum_i weights[i] * *terms[i] (host arrays of device pointers /
- * host floats); backward != 0: out[i] = weights[i] * *g (g NULL = 1) for i < count — the gradient of every term. */
+/* Weighted sum of up to 8 scalar (0-dim, device) loss terms: backward == 0: out[0] = sum_i weights[i] * *terms[i] and out[1 + i] = weights[i] * *terms[i]
+ * (host arrays of device pointers / host floats; `out` holds count + 1 floats); backward != 0: out[i] = weights[i] * *g (g NULL = 1) for i < count —
+ * the gradient of every term. */
 int cvae_weighted_sum(const float* const* terms, const float* weights, int count, const float* g, float* out, int backward, void* stream);
 /* The same sum over a LIST of tensors (host arrays of `count` device pointers / sizes) in one launch + one finish; workspace: cvae_reduce_workspace_bytes()
  * (CVAE_E_WORKSPACE below count + 1 floats). */
