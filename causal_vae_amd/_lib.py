@@ -38,6 +38,7 @@ SIGNATURES = {
     "cvae_nsc_to_ncs": [_p, _p, _i64, _i64, _i64, _i, _i, _p],
     "cvae_cast": [_p, _p, _i64, _i, _i, _p],
     "cvae_copy_panel": [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "cvae_copy_panels": [_p, _p, _p, _i, _p, _i64, _i64, _i64, _i, _p],
     "cvae_onehot_panel": [_p, _p, _i64, _i64, _i64, _i64, _p],
     "cvae_conv_packed_weight_bytes": [_i64, _i64, _i, _i],
     "cvae_conv_pack_weight": [_p, _p, _i64, _i64, _i, _i, _i, _p],

@@ -52,8 +52,7 @@ class CausalBioVAE(nn.Module):
 
     # ---- reference surface -----------------------------------------------------------------------------------
     def encode(self, x, m, t_onehot):
-        x_feat = self.enc_conv(x)
-        h = self.enc_fc(ops.cat([x_feat, m, t_onehot]))
+        h = self.enc_fc(self.enc_conv.forward_cat(x, [m, t_onehot]))
         return self.fc_mu(h), self.fc_logvar(h)
 
     def reparameterize(self, mu, logvar, eps=None):

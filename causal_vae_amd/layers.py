@@ -195,7 +195,7 @@ class ConvStack(nn.Sequential):
             i += 2 if act else 1
         return h, mods[i:], prev_act
 
-    def forward(self, x):
+    def _pooled(self, x):
         require_gpu(x)
         h, rest, last_act = self.features_cl(x)
         nd = x.dim() - 2
@@ -206,7 +206,14 @@ class ConvStack(nn.Sequential):
                 out_size = ((1,) + tuple(o)) if nd == 2 else tuple(o)
             elif not isinstance(m, nn.Flatten):
                 raise CvaeError(f"ConvStack: unsupported trailing layer {type(m).__name__}")
-        return ops.AdaptiveAvgPoolFlatten.apply(h, out_size, last_act == "relu")
+        return h, out_size, last_act == "relu"
+
+    def forward(self, x):
+        return ops.AdaptiveAvgPoolFlatten.apply(*self._pooled(x))
+
+    def forward_cat(self, x, extras):
+        """torch.cat([self(x), *extras], dim=1) without the intermediate: the features are written into the wide matrix directly (ops.FlattenCat)."""
+        return ops.FlattenCat.apply(*self._pooled(x), *extras)
 
 
 class DeconvStack(nn.Sequential):

@@ -39,7 +39,7 @@ class CausalMorphVAE12(nn.Module):
 
     def encode(self, x, m, t):
         """Encoder half: enc_conv -> cat[x_feat, m, t] -> enc_fc; returns the [B, 2 z] head (mu | logvar) (models.py:55-60 of the reference)."""
-        return self.enc_fc(ops.cat([self.enc_conv(x), m, t]))
+        return self.enc_fc(self.enc_conv.forward_cat(x, [m, t]))
 
     def forward(self, x, m, t, eps=None):
         mu, logvar = self.encode(x, m, t).chunk(2, dim=1)

@@ -39,8 +39,7 @@ class CausalMorphVAE12(nn.Module):
         return ops.Reparameterize.apply(mu, logvar, eps)
 
     def forward(self, x, m, t, eps=None):
-        x_feat = self.enc_conv(x)
-        mu, logvar = self.enc_fc(ops.cat([x_feat, m, t])).chunk(2, dim=1)
+        mu, logvar = self.enc_fc(self.enc_conv.forward_cat(x, [m, t])).chunk(2, dim=1)
         z = self.reparameterize(mu, logvar, eps)
         h = self.morph_predictor_shared(t)
         m_mu, m_logvar = self.morph_predictor_mu(h), self.morph_predictor_logvar(h)

@@ -178,37 +178,59 @@ class FromChannelsLast(torch.autograd.Function):
         return out, None
 
 
+def _copy_panels(panels, wide, col0, gather):
+    """cvae_copy_panels on fp32 [B, w_i] matrices (row strides taken from the tensors) and the wide matrix they sit side by side in."""
+    import ctypes as C
+    k = len(panels)
+    check(lib.cvae_copy_panels((C.c_void_p * k)(*[t.data_ptr() for t in panels]), (C.c_int64 * k)(*[t.shape[1] for t in panels]), (C.c_int64 * k)(*[t.stride(0) for t in panels]),
+                               k, ptr(wide), wide.shape[0], wide.stride(0), col0, int(gather), stream()), "copy_panels")
+
+
+def _as_panel(t):
+    """A [B, w] fp32 matrix whose rows are contiguous (a column slice of a wider matrix qualifies: its row stride travels with it)."""
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise L.CvaeError("cat: fp32 [B, n] matrices expected")
+    return t if (t.stride(1) == 1 and t.stride(0) >= t.shape[1]) or t.shape[1] == 0 else t.contiguous()
+
+
 class Cat(torch.autograd.Function):
-    """torch.cat(tensors, dim=1) for fp32 [B, n_i] matrices (cvae_copy_panel)."""
+    """torch.cat(tensors, dim=1) for fp32 [B, n_i] matrices: one launch (cvae_copy_panels), one more for all the gradients."""
 
     @staticmethod
     def forward(ctx, *ts):
         L.require_gpu(*ts)
+        if len(ts) > 8:
+            raise L.CvaeError("cat: at most 8 tensors")
+        ts = [_as_panel(t) for t in ts]
         B = ts[0].shape[0]
         widths = [t.shape[1] for t in ts]
         out = _empty((B, sum(widths)), torch.float32, ts[0])
-        col = 0
-        for t, w in zip(ts, widths):
-            t = t.contiguous()
-            check(lib.cvae_copy_panel(ptr(t), ptr(out), B, w, w, out.shape[1], col, stream()), "copy_panel")
-            col += w
+        _copy_panels(ts, out, 0, False)
         ctx.widths = widths
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        B, tot = g.shape
-        outs, col = [], 0
-        for i, w in enumerate(ctx.widths):
-            if ctx.needs_input_grad[i]:
-                o = _empty((B, w), torch.float32, g)
-                # a panel copy with the roles of the strides swapped: src row stride = tot, start at column `col`
-                check(lib.cvae_copy_panel(g.data_ptr() + 4 * col, ptr(o), B, w, tot, w, 0, stream()), "copy_panel")
-                outs.append(o)
-            else:
-                outs.append(None)
-            col += w
+        B = g.shape[0]
+        need = [i for i in range(len(ctx.widths)) if ctx.needs_input_grad[i]]
+        outs = [None] * len(ctx.widths)
+        if need:
+            # the needed pieces are gathered in one launch: consecutive runs of needed columns would be simplest, but any subset works by
+            # giving the skipped pieces a width-0 panel... they still shift the offsets, so gather run by run
+            col, runs, cur = 0, [], None
+            for i, w in enumerate(ctx.widths):
+                if ctx.needs_input_grad[i]:
+                    outs[i] = _empty((B, w), torch.float32, g)
+                    if cur is None:
+                        cur = (col, [])
+                        runs.append(cur)
+                    cur[1].append(outs[i])
+                else:
+                    cur = None
+                col += w
+            for col0, panels in runs:
+                _copy_panels(panels, g, col0, True)
         return tuple(outs)
 
 
@@ -604,6 +626,51 @@ class AdaptiveAvgPoolFlatten(torch.autograd.Function):
         check(lib.cvae_adaptive_avgpool_bwd(ptr(g), ptr(x) if relu_input else None, ptr(dx), B, D, H, W, Cc, OD, OH, OW, g.shape[1],
                                             L.dtype_code(x.dtype), stream()), "avgpool_bwd")
         return dx, None, None
+
+
+class FlattenCat(torch.autograd.Function):
+    """cat([Flatten(AdaptiveAvgPool(x)), *extras], dim=1) written in place: the pooled / flattened features go straight into the wide matrix (row stride
+    = its width) and the extras follow in one panel launch; the backward reads the feature columns of the incoming gradient where they lie."""
+
+    @staticmethod
+    def forward(ctx, x, out_size, relu_input, *extras):
+        L.require_gpu(x, *extras)
+        B, D, H, W, Cc = _cl_dims(x)
+        OD, OH, OW = out_size
+        F = Cc * OD * OH * OW
+        extras = [_as_panel(e) for e in extras]
+        if len(extras) > 8 or any(e.shape[0] != B for e in extras):
+            raise L.CvaeError("FlattenCat: up to 8 extras with the batch of x")
+        K = F + sum(e.shape[1] for e in extras)
+        out = _empty((B, K), torch.float32, x)
+        check(lib.cvae_adaptive_avgpool_fwd(ptr(x), ptr(out), B, D, H, W, Cc, OD, OH, OW, K, L.dtype_code(x.dtype), stream()), "avgpool_fwd")
+        if extras:
+            _copy_panels(extras, out, F, False)
+        ctx.save_for_backward(x)
+        ctx.cfg = (out_size, relu_input, F, [e.shape[1] for e in extras])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        (OD, OH, OW), relu_input, F, widths = ctx.cfg
+        B, D, H, W, Cc = x.shape
+        g = g.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.cvae_adaptive_avgpool_bwd(ptr(g), ptr(x) if relu_input else None, ptr(dx), B, D, H, W, Cc, OD, OH, OW, g.shape[1],
+                                                L.dtype_code(x.dtype), stream()), "avgpool_bwd")
+        outs, col = [], F
+        for i, w in enumerate(widths):
+            if ctx.needs_input_grad[3 + i]:
+                o = _empty((B, w), torch.float32, g)
+                _copy_panels([o], g, col, True)
+                outs.append(o)
+            else:
+                outs.append(None)
+            col += w
+        return (dx, None, None) + tuple(outs)
 
 
 class UpsampleLinear(torch.autograd.Function):

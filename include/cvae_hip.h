@@ -68,6 +68,10 @@ int cvae_nsc_to_ncs(const void* src, void* dst, int64_t B, int64_t C, int64_t S,
 int cvae_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 /* dst[b, col0 + j] = src[b, j] for j < cols (fp32): writes one panel of a concatenated [B, dst_stride] matrix. */
 int cvae_copy_panel(const float* src, float* dst, int64_t B, int64_t cols, int64_t src_stride, int64_t dst_stride, int64_t col0, void* stream);
+/* Up to 8 panels in one launch (host arrays of device pointers / widths / row strides): gather == 0: wide[b][col0 + off_i + j] = panels[i][b * strides[i] + j]
+ * with off_i = widths[0] + .. + widths[i-1] (torch.cat(dim=1)); gather != 0: the reverse copy (the column ranges of `wide` out into the panels: cat's backward). */
+int cvae_copy_panels(float* const* panels, const int64_t* widths, const int64_t* strides, int count, float* wide, int64_t B, int64_t wide_stride, int64_t col0,
+                     int gather, void* stream);
 /* dst[b, col0 + t[b]] = 1, other columns of the panel 0 (F.one_hot(t, n).float() into a concat panel). */
 int cvae_onehot_panel(const int64_t* t, float* dst, int64_t B, int64_t n_classes, int64_t dst_stride, int64_t col0, void* stream);
 

@@ -306,7 +306,7 @@ def test_conv_unsupported_and_bad_shapes_fail_loudly():
 # --------------------------------------------------------------------------------------------- pool / resize / layout
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("nd,size,out", [(2, (4, 6), (4, 4)), (2, (8, 10), (4, 4)), (2, (7, 7), (7, 7)), (3, (8, 8, 8), (4, 4, 4)),
-                                         (3, (4, 4, 4), (4, 4, 4)), (3, (5, 6, 9), (4, 4, 4))])
+                                         (3, (4, 4, 4), (4, 4, 4)), (3, (5, 6, 9), (4, 4, 4)), (2, (9, 9), (9, 9))])     # equal sizes: the bare-Flatten transpose kernels
 def test_adaptive_avgpool_flatten(nd, size, out, dtype):
     g = torch.Generator().manual_seed(4)
     x = rnd(torch.randn(3, 40, *size, generator=g).relu(), dtype).requires_grad_(True)
@@ -357,6 +357,43 @@ def test_layout_roundtrip_cat_onehot(dtype):
     assert torch.equal(ag.grad.cpu(), torch.arange(5 * 64, dtype=torch.float32).view(5, 64)[:, :33])
     t = torch.tensor([0, 18, 3, 7], dtype=torch.int64)
     assert torch.equal(ops.one_hot(t.to(DEV), 19).cpu(), F.one_hot(t, 19).float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("size,out,C", [((7, 7), (7, 7), 64), ((9, 10), (9, 10), 70), ((8, 12), (4, 4), 32)])
+def test_flatten_cat_writes_features_and_extras_in_place(size, out, C, dtype):
+    """ops.FlattenCat == torch.cat([flatten(pool(x)), m, t], 1), forward and every gradient (the features' with the ReLU mask folded), one of the
+    extras being a column slice of a wider matrix."""
+    g = torch.Generator().manual_seed(14)
+    B = 5
+    x = rnd(torch.randn(B, C, *size, generator=g).relu(), dtype).requires_grad_(True)
+    wide = torch.randn(B, 30, generator=g)
+    m, t = wide[:, 4:16].clone().requires_grad_(True), torch.randn(B, 10, generator=g)
+    y_ref = torch.cat([F.adaptive_avg_pool2d(x, out).flatten(1), m, t], 1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    gx_ref, gm_ref = torch.autograd.grad(y_ref, [x, m], gy)
+    gx_ref = gx_ref * (x.detach() > 0)
+    xg = to_cl(x.detach(), dtype).requires_grad_(True)
+    mg = wide.to(DEV)[:, 4:16].requires_grad_(True)          # a strided view: rows 30 floats apart
+    y = ops.FlattenCat.apply(xg, (1,) + out, True, mg, t.to(DEV))
+    close(y.cpu(), y_ref.detach(), torch.float32, "flatten_cat")
+    dx, dm = torch.autograd.grad(y, [xg, mg], gy.to(DEV))
+    close(from_cl(dx, 2), gx_ref, dtype, "dx")
+    assert torch.equal(dm.cpu(), gm_ref)
+
+
+def test_cat_many_pieces_one_launch_partial_gradients():
+    g = torch.Generator().manual_seed(15)
+    ps = [torch.randn(6, w, generator=g) for w in (3, 17, 1, 40, 8)]
+    need = [True, False, True, True, False]
+    gs = [p.to(DEV).requires_grad_(n) for p, n in zip(ps, need)]
+    out = ops.cat(gs)
+    assert torch.equal(out.cpu(), torch.cat(ps, 1))
+    gy = torch.randn(6, 69, generator=g)
+    grads = torch.autograd.grad(out, [t for t, n in zip(gs, need) if n], gy.to(DEV))
+    cols = [0, 3, 20, 21, 61, 69]
+    for gr, i in zip(grads, [i for i, n in enumerate(need) if n]):
+        assert torch.equal(gr.cpu(), gy[:, cols[i]:cols[i + 1]])
 
 
 # --------------------------------------------------------------------------------------------- linear / BN
