@@ -86,6 +86,8 @@ SIGNATURES = {
     "cvae_reduce_workspace_bytes": [],
     "cvae_reparam_kld_fwd": [_p, _p, _p, _p, _p, _i64, _p, _sz, _p],
     "cvae_reparam_kld_bwd": [_p, _p, _f] + [_p] * 5 + [_i64, _p],
+    "cvae_latent_head_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "cvae_latent_head_bwd": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "cvae_sse_fwd": [_p, _p, _p, _i64, _p, _sz, _p],
     "cvae_sse_bwd": [_p, _p, _p, _f, _p, _i64, _p],
     "cvae_combine3": [_p, _f, _f, _p],

@@ -268,6 +268,66 @@ extern "C" int cvae_reparam_kld_bwd(const float* dz, const float* gkld, float gk
     return CVAE_OK;
 }
 
+// The latent head of a VAE step in one launch each way: h = [B][2 Z] rows (mu | logvar) exactly as the encoder's last Linear leaves them (no chunk copies),
+// z1 = mu + eps1 exp(logvar / 2), optionally a second sample z2 from eps2 (the adversarial branch of mnist_test/01_baseline_causal_vae/train.py:78-81), and
+// kld = -0.5 sum(1 + logvar - mu^2 - exp(logvar)) ASSIGNED (not accumulated) to *kld.  One workgroup: the reduction is a fixed tree, and a latent head is
+// B x Z <= a few 10^4 elements.  The backward writes d h from d z1, d z2 and the KLD's incoming gradient: what autograd did with 3 kernels, 4 adds and a cat.
+__global__ __launch_bounds__(1024) void latent_head_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps1, const float* __restrict__ eps2,
+                                                               float* __restrict__ z1, float* __restrict__ z2, float* __restrict__ kld, int64_t B, int64_t Z) {
+    __shared__ float red[16];
+    const int64_t n = B * Z;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t b = i / Z, j = i - b * Z;
+        const float m = h[b * 2 * Z + j], lv = h[b * 2 * Z + Z + j], sd = expf(0.5f * lv);
+        if (z1) z1[i] = m + eps1[i] * sd;
+        if (z2) z2[i] = m + eps2[i] * sd;
+        acc += 1.f + lv - m * m - expf(lv);
+    }
+    if (kld) {
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int w = 0; w < 16; ++w) s += red[w];
+            *kld = -0.5f * s;
+        }
+    }
+}
+__global__ void latent_head_bwd_kernel(const float* __restrict__ dz1, const float* __restrict__ dz2, const float* __restrict__ gkld, const float* __restrict__ h,
+                                       const float* __restrict__ eps1, const float* __restrict__ eps2, float* __restrict__ dh, int64_t B, int64_t Z) {
+    const float gk = gkld ? *gkld : 0.f;
+    const int64_t n = B * Z;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / Z, j = i - b * Z;
+        const float m = h[b * 2 * Z + j], lv = h[b * 2 * Z + Z + j];
+        float gm = gk * m, gl = gk * 0.5f * (expf(lv) - 1.f), ge = 0.f;
+        if (dz1) { const float g = dz1[i]; gm += g; ge += g * eps1[i]; }
+        if (dz2) { const float g = dz2[i]; gm += g; ge += g * eps2[i]; }
+        gl += ge * 0.5f * expf(0.5f * lv);
+        dh[b * 2 * Z + j] = gm;
+        dh[b * 2 * Z + Z + j] = gl;
+    }
+}
+extern "C" int cvae_latent_head_fwd(const float* h, const float* eps1, const float* eps2, float* z1, float* z2, float* kld, int64_t B, int64_t Z, void* stream) {
+    if (B < 0 || Z <= 0 || B * Z > ((int64_t)1 << 24)) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!h || (z1 && !eps1) || (z2 && !eps2) || (!z1 && !z2 && !kld)) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(latent_head_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, h, eps1, eps2, z1, z2, kld, B, Z);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+extern "C" int cvae_latent_head_bwd(const float* dz1, const float* dz2, const float* gkld, const float* h, const float* eps1, const float* eps2, float* dh,
+                                    int64_t B, int64_t Z, void* stream) {
+    if (B < 0 || Z <= 0) return CVAE_E_BADSHAPE;
+    if (B == 0) return CVAE_OK;
+    if (!h || !dh || (dz1 && !eps1) || (dz2 && !eps2)) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(latent_head_bwd_kernel, dim3(cvae_grid_1d(B * Z, 256, 256)), dim3(256), 0, (hipStream_t)stream, dz1, dz2, gkld, h, eps1, eps2, dh, B, Z);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
 // out4 = {total, a, b, c} with total = a + wb * b + wc * c  (the ELBO of causal_cascade/train.py:16 from its three terms)
 __global__ void combine3_kernel(float* __restrict__ out4, float wb, float wc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out4[0] = out4[1] + wb * out4[2] + wc * out4[3];

@@ -41,6 +41,21 @@ class CausalMorphVAE12(nn.Module):
         """Encoder half: enc_conv -> cat[x_feat, m, t] -> enc_fc; returns the [B, 2 z] head (mu | logvar) (models.py:55-60 of the reference)."""
         return self.enc_fc(self.enc_conv.forward_cat(x, [m, t]))
 
+    def forward_train(self, x, m, t, eps_vae=None, eps_adv=None):
+        """forward() plus what the adversarial step takes from the same latent head (train.py:65-81 of the reference): the KLD sum and the second
+        sample z' = reparameterize(mu, logvar) that feeds the discriminator — mu | logvar are consumed where the encoder leaves them (ops.LatentHead),
+        both noise draws are one Philox launch.  Returns (recon_x, m_hat, mu, logvar, kld, z_adv)."""
+        h = self.encode(x, m, t)
+        B, Z = h.shape[0], self.z_dim
+        if eps_vae is None or eps_adv is None:
+            e = self._eps.draw(h.new_empty(2 * B, Z))
+            eps_vae, eps_adv = (e[:B] if eps_vae is None else eps_vae), (e[B:] if eps_adv is None else eps_adv)
+        z, z_adv, kld = ops.LatentHead.apply(h, eps_vae, eps_adv, True)
+        m_hat = self.morph_predictor(t)
+        recon_x = self.dec_conv(self.dec_fc(ops.cat([m_hat, z])).view(-1, 64, 7, 7))
+        mu, logvar = h.chunk(2, dim=1)
+        return recon_x, m_hat, mu, logvar, kld, z_adv
+
     def forward(self, x, m, t, eps=None):
         mu, logvar = self.encode(x, m, t).chunk(2, dim=1)
         z = self.reparameterize(mu, logvar, eps)

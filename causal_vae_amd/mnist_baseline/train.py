@@ -25,8 +25,8 @@ def train_step(vae, discriminator, opt_vae, opt_d, x, m, t, eps=None, beta=None,
     # the encoder half runs (same mu, logvar, bit for bit)
     opt_d.zero_grad(set_to_none=True)
     with torch.no_grad():
-        mu, logvar = vae.encode(x, m, t).chunk(2, dim=1)
-        z = vae.reparameterize(mu, logvar, eps_d)
+        h = vae.encode(x, m, t)
+        z, _, _ = ops.LatentHead.apply(h, eps_d if eps_d is not None else vae._eps.draw(h.new_empty(h.shape[0], vae.z_dim)), None, False)
     loss_d = ops.SoftmaxCE.apply(discriminator(z), t_indices)
     ops.backward_from(loss_d)
     opt_d.step()
@@ -38,11 +38,10 @@ def train_step(vae, discriminator, opt_vae, opt_d, x, m, t, eps=None, beta=None,
     for p in d_params:
         p.requires_grad_(False)
     try:
-        recon_x, m_hat, mu, logvar = vae(x, m, t, eps=eps_vae)
+        recon_x, m_hat, mu, logvar, kld, z_sample = vae.forward_train(x, m, t, eps_vae, eps_adv)
         loss_recon = ops.bce_sum(recon_x.view(-1, 784), x.view(-1, 784))
-        z_sample = vae.reparameterize(mu, logvar, eps_adv)
         # loss = recon + BETA * kld + 100 * morph + LAMBDA_ADV * 100 * adv: one launch for the sum and the four logged terms, one for their gradients
-        loss, parts = ops.weighted_sum([loss_recon, ops.KLD.apply(mu, logvar), ops.sse(m_hat, m), ops.UniformKL.apply(discriminator(z_sample))],
+        loss, parts = ops.weighted_sum([loss_recon, kld, ops.sse(m_hat, m), ops.UniformKL.apply(discriminator(z_sample))],
                                        [1.0, beta, 100.0, lambda_adv * 100.0], return_terms=True)
         ops.backward_from(loss)
     finally:

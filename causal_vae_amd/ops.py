@@ -935,6 +935,39 @@ class Reparameterize(torch.autograd.Function):
         return dmu, dlv, None
 
 
+class LatentHead(torch.autograd.Function):
+    """(z1, z2, kld) from the encoder's [B, 2 Z] head h = (mu | logvar): z_k = mu + eps_k exp(logvar / 2) (eps2 / z2 optional), kld as ops.KLD — one launch,
+    and one for d h in the backward (cvae_latent_head_fwd / _bwd) instead of chunk copies, three kernels, their gradient adds and a cat."""
+
+    @staticmethod
+    def forward(ctx, h, eps1, eps2, want_kld):
+        L.require_gpu(h, eps1)
+        if h.dtype != torch.float32 or h.dim() != 2 or h.shape[1] % 2:
+            raise L.CvaeError("LatentHead: fp32 [B, 2 Z] head expected")
+        h, eps1 = h.contiguous(), eps1.contiguous()
+        B, Z = h.shape[0], h.shape[1] // 2
+        if tuple(eps1.shape) != (B, Z) or (eps2 is not None and tuple(eps2.shape) != (B, Z)):
+            raise L.CvaeError("LatentHead: eps must be [B, Z]")
+        eps2 = None if eps2 is None else eps2.contiguous()
+        z1 = _empty((B, Z), torch.float32, h)
+        z2 = None if eps2 is None else _empty((B, Z), torch.float32, h)
+        kld = torch.empty((), dtype=torch.float32, device=h.device) if want_kld else None
+        check(lib.cvae_latent_head_fwd(ptr(h), ptr(eps1), ptr(eps2), ptr(z1), ptr(z2), ptr(kld), B, Z, stream()), "latent_head_fwd")
+        ctx.save_for_backward(h, eps1, eps2)
+        return z1, z2, kld
+
+    @staticmethod
+    def backward(ctx, g1, g2, gk):
+        h, eps1, eps2 = ctx.saved_tensors
+        B, Z = h.shape[0], h.shape[1] // 2
+        dh = torch.empty_like(h)
+        g1 = None if g1 is None else g1.contiguous()
+        g2 = None if g2 is None else g2.contiguous()
+        gk = None if gk is None else gk.float().contiguous()
+        check(lib.cvae_latent_head_bwd(ptr(g1), ptr(g2), ptr(gk), ptr(h), ptr(eps1), ptr(eps2), ptr(dh), B, Z, stream()), "latent_head_bwd")
+        return dh, None, None, None
+
+
 class KLD(torch.autograd.Function):
     """-0.5 * sum(1 + logvar - mu^2 - exp(logvar))   (causal_cascade/train.py:13)."""
 

@@ -310,6 +310,12 @@ int cvae_reparam_kld_fwd(const float* mu, const float* logvar, const float* eps,
  * dz / gkld (device scalar) may be NULL. */
 int cvae_reparam_kld_bwd(const float* dz, const float* gkld, float gk_scale, const float* mu, const float* logvar, const float* eps,
                          float* dmu, float* dlogvar, int64_t n, void* stream);
+/* The same head on the encoder's [B][2 Z] output rows (mu | logvar) without splitting them: z1 = mu + eps1 exp(logvar / 2), an optional second sample z2
+ * from eps2, and *kld = the KLD sum (assigned; any of z1 / z2 / kld may be NULL).  One launch; B * Z <= 2^24.  The backward writes d h [B][2 Z] from
+ * d z1, d z2 (either may be NULL) and the KLD's incoming gradient *gkld (NULL: 0). */
+int cvae_latent_head_fwd(const float* h, const float* eps1, const float* eps2, float* z1, float* z2, float* kld, int64_t B, int64_t Z, void* stream);
+int cvae_latent_head_bwd(const float* dz1, const float* dz2, const float* gkld, const float* h, const float* eps1, const float* eps2, float* dh,
+                         int64_t B, int64_t Z, void* stream);
 /* *out += sum (a - b)^2 */
 int cvae_sse_fwd(const float* a, const float* b, float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
 /* da = 2*(a - b) * (*gout) * scale   (db = -da is formed by the caller when needed) */

@@ -557,6 +557,31 @@ def test_reparam_kld_gauss_nll_vessel(golden):
             gold.check(tag, "g_" + k, a[k].grad, rtol=2e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("two", [True, False], ids=["two-samples", "one-sample"])
+def test_latent_head_matches_chunk_reparam_kld(two):
+    """ops.LatentHead on the [B, 2 Z] head == chunk -> reparameterize (twice) + KLD, values and d h."""
+    g = torch.Generator().manual_seed(31)
+    B, Z = 37, 10
+    h = (torch.randn(B, 2 * Z, generator=g) * 0.7).requires_grad_(True)
+    e1, e2 = torch.randn(B, Z, generator=g), torch.randn(B, Z, generator=g)
+    mu, lv = h.chunk(2, dim=1)
+    z1_ref, z2_ref = mu + e1 * torch.exp(0.5 * lv), mu + e2 * torch.exp(0.5 * lv)
+    kld_ref = -0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp())
+    g1, g2, gk = torch.randn(B, Z, generator=g), torch.randn(B, Z, generator=g), torch.tensor(0.37)
+    obj = (z1_ref * g1).sum() + kld_ref * gk + ((z2_ref * g2).sum() if two else 0)
+    (dh_ref,) = torch.autograd.grad(obj, h)
+    hg = h.detach().to(DEV).requires_grad_(True)
+    z1, z2, kld = ops.LatentHead.apply(hg, e1.to(DEV), e2.to(DEV) if two else None, True)
+    close(z1.cpu(), z1_ref.detach(), torch.float32, "z1")
+    assert abs(float(kld) - float(kld_ref)) <= 1e-6 * abs(float(kld_ref))
+    assert (z2 is None) == (not two)
+    if two:
+        close(z2.cpu(), z2_ref.detach(), torch.float32, "z2")
+    obj_g = (z1 * g1.to(DEV)).sum() + kld * gk.to(DEV) + ((z2 * g2.to(DEV)).sum() if two else 0)
+    (dh,) = torch.autograd.grad(obj_g, hg)
+    close(dh.cpu(), dh_ref, torch.float32, "dh")
+
+
 def test_softmax_ce_and_uniform_kl():
     g = torch.Generator().manual_seed(11)
     logits = (torch.randn(37, 10, generator=g) * 3).requires_grad_(True)
