@@ -181,11 +181,14 @@ __global__ void slab_sum_bias_act_kernel(const float* __restrict__ slabs, int sp
 // split-K factor of gemm_f32 for an [M][N] result over K: until ~2 workgroups per CU exist, keeping >= 4 K-steps (64 k) per split.  A small result
 // over a long reduction (the weight gradients of the MLP heads over a 1024-row batch: 1 - 8 tiles, K = 1024) is otherwise ONE workgroup walking
 // the whole reduction.
+#ifndef CVAE_GEMM_SPLIT_MIN_KSTEPS
+#define CVAE_GEMM_SPLIT_MIN_KSTEPS 8
+#endif
 static int64_t gemm_splits(int64_t M, int64_t N, int64_t K, int64_t* k_per_split_out) {
     const int64_t tm = (M + LT - 1) / LT, tn = (N + LT - 1) / LT;
     int64_t splits = 1;
     const int64_t ksteps = (K + LK - 1) / LK;
-    if (tm * tn < 512 && ksteps >= 8) {
+    if (tm * tn < 512 && ksteps >= CVAE_GEMM_SPLIT_MIN_KSTEPS) {
         splits = 512 / (tm * tn);
         if (splits > ksteps / 4) splits = ksteps / 4;
         if (splits < 1) splits = 1;

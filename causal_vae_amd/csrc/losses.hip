@@ -275,14 +275,25 @@ extern "C" int cvae_reparam_kld_bwd(const float* dz, const float* gkld, float gk
 __global__ __launch_bounds__(1024) void latent_head_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps1, const float* __restrict__ eps2,
                                                                float* __restrict__ z1, float* __restrict__ z2, float* __restrict__ kld, int64_t B, int64_t Z) {
     __shared__ float red[16];
-    const int64_t n = B * Z;
+    const int n = (int)(B * Z), Zi = (int)Z;
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const int64_t b = i / Z, j = i - b * Z;
-        const float m = h[b * 2 * Z + j], lv = h[b * 2 * Z + Z + j], sd = expf(0.5f * lv);
-        if (z1) z1[i] = m + eps1[i] * sd;
-        if (z2) z2[i] = m + eps2[i] * sd;
-        acc += 1.f + lv - m * m - expf(lv);
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 1024) {     // four elements per pass: their loads are issued together, not one round trip each
+        float m[4], lv[4], e1[4], e2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024, ic = i < n ? i : n - 1, b = ic / Zi, j = ic - b * Zi;
+            m[u] = h[(size_t)b * 2 * Zi + j]; lv[u] = h[(size_t)b * 2 * Zi + Zi + j];
+            e1[u] = z1 ? eps1[ic] : 0.f; e2[u] = z2 ? eps2[ic] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            if (i >= n) break;
+            const float sd = expf(0.5f * lv[u]);
+            if (z1) z1[i] = m[u] + e1[u] * sd;
+            if (z2) z2[i] = m[u] + e2[u] * sd;
+            acc += 1.f + lv[u] - m[u] * m[u] - expf(lv[u]);
+        }
     }
     if (kld) {
         acc = wave_sum(acc);

@@ -20,6 +20,11 @@ def train_step(vae, discriminator, opt_vae, opt_d, x, m, t, eps=None, beta=None,
     lambda_adv = CONFIG["LAMBDA_ADV"] if lambda_adv is None else lambda_adv
     eps_d, eps_vae, eps_adv = eps if eps is not None else (None, None, None)
     t_indices = torch.argmax(t, dim=1)
+    with ops.zero_pool(8, x):                                # the step's five scalar loss sums share one zeroed block
+        return _train_step(vae, discriminator, opt_vae, opt_d, x, m, t, t_indices, eps_d, eps_vae, eps_adv, beta, lambda_adv)
+
+
+def _train_step(vae, discriminator, opt_vae, opt_d, x, m, t, t_indices, eps_d, eps_vae, eps_adv, beta, lambda_adv):
     # ---- 1. discriminator ----
     # the reference runs the whole VAE here (:47) and keeps mu, logvar: the decoder half of that no-grad forward reaches no result, so only
     # the encoder half runs (same mu, logvar, bit for bit)

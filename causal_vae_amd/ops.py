@@ -83,7 +83,32 @@ def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+_ZERO_POOL = [None, 0]
+
+
+class zero_pool:
+    """`with ops.zero_pool(n):` — the accumulating scalar reductions inside the block (loss sums: `*out += ...` kernels) take their zeroed 0-dim outputs
+    from ONE torch.zeros(n) made on entry instead of one fill launch each.  The fill belongs to the step that uses it, so a captured step stays
+    replayable; more than n requests fall back to their own zeros."""
+
+    def __init__(self, n, like):
+        self.n, self.like = int(n), like
+
+    def __enter__(self):
+        self.prev = list(_ZERO_POOL)
+        _ZERO_POOL[0], _ZERO_POOL[1] = torch.zeros(self.n, dtype=torch.float32, device=self.like.device), 0
+        return self
+
+    def __exit__(self, *exc):
+        _ZERO_POOL[0], _ZERO_POOL[1] = self.prev
+        return False
+
+
 def _scalar(like):
+    pool, used = _ZERO_POOL
+    if pool is not None and used < pool.numel() and pool.device == like.device:
+        _ZERO_POOL[1] = used + 1
+        return pool[used]
     return torch.zeros((), dtype=torch.float32, device=like.device)
 
 
@@ -1145,10 +1170,13 @@ class WeightedSum(torch.autograd.Function):
         ctx.shapes = [t.shape for t in terms]
         total, parts = out[0], out[1:]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)                     # no zeros launch for the gradient slot of `parts`
         return total, parts
 
     @staticmethod
     def backward(ctx, g, _gparts):
+        if g is None:
+            return (None,) * (1 + len(ctx.weights))
         import ctypes as C
         n = len(ctx.weights)
         out = torch.empty(n, dtype=torch.float32, device=g.device)
