@@ -12,6 +12,7 @@
 // ([split][M][N], plain stores) and one finish launch adds the slabs in index order, then bias and activation — no float
 // atomics, so results are bit-reproducible.  Without (enough) workspace the same kernels run unsplit.
 #include "common.h"
+#include <type_traits>
 
 #define LT 64
 #define LK 16
@@ -166,6 +167,184 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     }
 }
 
+#ifndef CVAE_GEMM_T128
+#define CVAE_GEMM_T128 1
+#endif
+#ifndef CVAE_GEMM_T128_DEPTH
+#define CVAE_GEMM_T128_DEPTH 2
+#endif
+#ifndef CVAE_GEMM_T128_BK
+#define CVAE_GEMM_T128_BK 32
+#endif
+#ifndef CVAE_GEMM_T128_WGS
+#define CVAE_GEMM_T128_WGS 256
+#endif
+// The large-product form of the bf16-operand GEMM (M, N >= 128): 128 x 128 tiles, 4 waves of 64 x 64 (2 x 2 MFMA tiles: every fragment read feeds two
+// MFMAs), fp32 operands fetched as 16-byte vectors along whichever dimension is contiguous and written to LDS as 8-byte bf16 quads:
+//   * an operand that is k-contiguous in memory (x, W in the forward) gets a [row][k] image (pitch BK + 8) read with ds_read_b128;
+//   * an operand that is row-contiguous (g^T and x in the weight gradient, W in the data gradient) keeps its memory order in a [k][row] image
+//     (pitch 160: the four k-rows of a transposed read fall in four different 64-byte bank groups) and is read with ds_read_b64_tr_b16 — no
+//     scalar transposing stores.
+// gemm_bf16_kernel above moved 4-byte loads and 2-byte LDS stores, 64 x 64 tiles: 80 TFLOP/s on 1024 x 3158 x 512 (38-42 us per product).
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };       // float4 at dword alignment (rows of odd length)
+// out[e] = e < nvalid ? L[e + sh] : 0 (sh in 0..3; e + sh <= 3 wherever e < nvalid): the fix-up of a vector that was loaded from a start clamped into the row
+__device__ __forceinline__ F4U shift_sel(F4U L, int sh, int nvalid) {
+    F4U o;
+    o.x = sh == 0 ? L.x : (sh == 1 ? L.y : (sh == 2 ? L.z : L.w));
+    o.y = sh == 0 ? L.y : (sh == 1 ? L.z : (sh == 2 ? L.w : 0.f));
+    o.z = sh == 0 ? L.z : (sh == 1 ? L.w : 0.f);
+    o.w = sh == 0 ? L.w : 0.f;
+    if (nvalid < 1) o.x = 0.f;
+    if (nvalid < 2) o.y = 0.f;
+    if (nvalid < 3) o.z = 0.f;
+    if (nvalid < 4) o.w = 0.f;
+    return o;
+}
+template <bool A_KC, bool B_KC, int BK>
+__global__ __launch_bounds__(256) void gemm_bf16_t128_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                             const float* __restrict__ bias, int64_t M, int64_t N, int64_t K,
+                                                             int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
+                                                             int64_t k_per_split, int act, float* __restrict__ slabs, int tn, int tm, int n_slow) {
+    constexpr int BT = 128, PR = BK + 8, PT = 160, NL = BK / 8;      // NL: 16-byte loads per thread per operand per stage
+    constexpr int IMG = (BT * PR > BK * PT) ? BT * PR : BK * PT;
+    __shared__ __attribute__((aligned(16))) bf16 As[IMG];
+    __shared__ __attribute__((aligned(16))) bf16 Bs[IMG];
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3, colblk = gq & 1;     // transposed-read roles (T10): h == gq >> 1
+    const int wm = wave >> 1, wn = wave & 1;
+    // 1-D grid, XCD-aware (blocks b and b + 8 share an XCD and its L2): every XCD gets a contiguous run of the order (split, slow tile index, fast tile
+    // index), i.e. the workgroups of one K slice — which re-read the same A rows and B rows — sit behind one L2.  In grid order the 4 n-tiles sharing an
+    // A tile landed on 4 different XCDs and the forward moved 106 MB through the fabric for 19 MB of operands.  The larger operand's tile index is the
+    // slow one (its tiles are fetched once per XCD).
+    int lid;
+    { const int nb = (int)gridDim.x, qq = nb >> 3, rr = nb & 7, xx = blockIdx.x & 7; lid = (xx < rr ? xx * (qq + 1) : rr * (qq + 1) + (xx - rr) * qq) + ((int)blockIdx.x >> 3); }
+    const int tiles = tn * tm, split = lid / tiles, tl = lid - split * tiles;
+    const int bx = n_slow ? tl / tm : tl % tn, by = n_slow ? tl % tm : tl / tn;
+    const int64_t m0 = (int64_t)by * BT, n0 = (int64_t)bx * BT;
+    const int64_t kbeg = (int64_t)split * k_per_split;
+    const int64_t kend = min(K, kbeg + k_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // DEPTH stages of both operands in flight in registers: a workgroup has ~10 stages of 32 k and one workgroup sits on a CU, so with a single
+    // stage in flight every stage cost a full global round trip (2 us per stage measured: 26 us for the 1024 x 3158 x 512 forward)
+    constexpr int DEPTH = CVAE_GEMM_T128_DEPTH;
+    F4U ra[DEPTH][NL], rb[DEPTH][NL];
+    // one operand's stage: P[row * s_row + k * s_k], rows row0 .. row0 + 127 (< R), k in [k0, k0 + BK) (< kend)
+    // Every load is an unconditional 16-byte vector from an address clamped into the operand (rows to R - 1 / R - 4, k to K - 4 / kend - 1); what the
+    // clamp moved or what lies past the range is fixed up in registers when the stage is written to LDS (stash).  No branch surrounds a load, and the
+    // stage loop below is straight-line code: with guarded loads or conditional fetches the compiler's s_waitcnt insertion fell back to vmcnt(0) before
+    // every LDS write — one global round trip per stage, whatever the prefetch depth (26 us for the 1024 x 3158 x 512 forward).
+    auto fetch = [&](auto kc, const float* __restrict__ P, int64_t row0, int64_t R, int64_t s_row, int64_t s_k, int64_t k0, F4U (&rg)[NL]) {
+        if constexpr (decltype(kc)::value) {                 // k contiguous: thread -> rows t / (BK / 4) + (1024 / BK) i, k = 4 (t % (BK / 4))
+            constexpr int QR = BK / 4, RS = 256 / QR;
+            const int64_t gkc = min(k0 + 4 * (t % QR), K - 4);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) rg[i] = *(const F4U*)(P + min(row0 + t / QR + RS * i, R - 1) * s_row + gkc);
+        } else {                                             // row contiguous: thread -> rows 4 (t % 32) .. + 3, k = NL (t / 32) + j
+            const int64_t gc = min(row0 + 4 * (t & 31), R - 4);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) rg[j] = *(const F4U*)(P + min(k0 + NL * (t >> 5) + j, kend - 1) * s_k + gc);
+        }
+    };
+    auto stash = [&](auto kc, bf16* img, const F4U (&rg)[NL], int64_t row0, int64_t R, int64_t k0) {
+        const bool interior = row0 + BT <= R && k0 + BK <= kend;
+        if constexpr (decltype(kc)::value) {
+            constexpr int QR = BK / 4, RS = 256 / QR;
+            const int64_t gk = k0 + 4 * (t % QR);
+            const int sh = (int)(gk - min(gk, K - 4)), nv = (int)max((int64_t)0, min((int64_t)4, kend - gk));
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const F4U v = interior ? rg[i] : shift_sel(rg[i], sh, (row0 + t / QR + RS * i) < R ? nv : 0);
+                *(uint2*)(img + (t / QR + RS * i) * PR + 4 * (t % QR)) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+            }
+        } else {
+            const int64_t g = row0 + 4 * (t & 31);
+            const int sh = (int)(g - min(g, R - 4)), nv = (int)max((int64_t)0, min((int64_t)4, R - g));
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const F4U v = interior ? rg[j] : shift_sel(rg[j], sh, (k0 + NL * (t >> 5) + j) < kend ? nv : 0);
+                *(uint2*)(img + (NL * (t >> 5) + j) * PT + 4 * (t & 31)) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+            }
+        }
+    };
+    // fragment of rows rb0 .. rb0 + 31, k-step kk (16 k): lane (r, h) gets row r, k = 16 kk + 8 h .. + 7
+    auto frag = [&](auto kc, const bf16* img, int rb0, int kk) -> bf16x8 {
+        if constexpr (decltype(kc)::value) return *(const bf16x8*)(img + (rb0 + r) * PR + kk * 16 + 8 * h);
+        else {
+            bf16x8 o;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + (kk * 16 + 8 * h + 4 * jj + q) * PT + rb0 + 16 * colblk + 4 * p));
+                o[4 * jj + 0] = v[0]; o[4 * jj + 1] = v[1]; o[4 * jj + 2] = v[2]; o[4 * jj + 3] = v[3];
+            }
+            return o;
+        }
+    };
+    const std::integral_constant<bool, A_KC> akc;
+    const std::integral_constant<bool, B_KC> bkc;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { fetch(akc, A, m0, M, sam, sak, kbeg + d * BK, ra[d]); fetch(bkc, Bm, n0, N, sbn, sbk, kbeg + d * BK, rb[d]); }
+    // DEPTH stages per trip, no exits inside: a stage past kend stashes zeros (its loads were clamped) and multiplies them
+    for (int64_t k0 = kbeg; k0 < kend; k0 += DEPTH * BK) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t ks = k0 + d * BK;
+            stash(akc, As, ra[d], m0, M, ks);
+            stash(bkc, Bs, rb[d], n0, N, ks);
+            __syncthreads();
+            fetch(akc, A, m0, M, sam, sak, ks + DEPTH * BK, ra[d]);
+            fetch(bkc, Bm, n0, N, sbn, sbk, ks + DEPTH * BK, rb[d]);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a[i] = frag(akc, As, wm * 64 + i * 32, kk); b[i] = frag(bkc, Bs, wn * 64 + i * 32, kk); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    // D: lane (r, h) holds column r, rows (e & 3) + 8 (e >> 2) + 4 h of each 32 x 32 tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t gn = n0 + wn * 64 + j * 32 + r;
+        if (gn >= N) continue;
+        const float bv = (bias && !slabs) ? bias[gn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gm = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (gm < M) {
+                    if (slabs) slabs[((size_t)split * M + gm) * N + gn] = acc[i][j][e];
+                    else C[gm * ldc + gn] = apply_act(acc[i][j][e] + bv, act);
+                }
+            }
+    }
+}
+// split-K of the 128-tile form: until ~CVAE_GEMM_T128_WGS workgroups exist, >= 4 stages per split
+static int64_t gemm_t128_splits(int64_t M, int64_t N, int64_t K, int64_t* k_per_split_out) {
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), stages = (K + CVAE_GEMM_T128_BK - 1) / CVAE_GEMM_T128_BK;
+    int64_t splits = CVAE_GEMM_T128_WGS / tiles;
+    if (splits > stages / 4) splits = stages / 4;
+    if (splits < 1) splits = 1;
+    const int64_t kps = ((stages + splits - 1) / splits) * CVAE_GEMM_T128_BK;
+    if (k_per_split_out) *k_per_split_out = kps;
+    return (K + kps - 1) / kps;
+}
+static bool gemm_t128_ok(int64_t M, int64_t N, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn) {
+    return CVAE_GEMM_T128 && M >= 128 && N >= 128 && (sak == 1 || sam == 1) && (sbk == 1 || sbn == 1);     // (the caller adds K >= 128: a one-stage product is all output)
+}
+
 // C[m][c] = act(sum_s slabs[s][m][c] + bias[c]), s in index order
 __global__ void slab_sum_bias_act_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C, const float* __restrict__ bias, int64_t M, int64_t N,
                                          int64_t ldc, int act) {
@@ -203,6 +382,26 @@ static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias
     if (M < 0 || N <= 0 || K <= 0 || ldc < N) return CVAE_E_BADSHAPE;
     if (M == 0) return CVAE_OK;
     if (!A || !Bm || !C) return CVAE_E_NULLPTR;
+    if (bf16_math && K >= 128 && gemm_t128_ok(M, N, sam, sak, sbk, sbn)) {
+        int64_t kps;
+        int64_t sp = gemm_t128_splits(M, N, K, &kps);
+        if (sp > 1 && (!ws || ws_bytes < (size_t)sp * M * N * sizeof(float))) { sp = 1; kps = ((K + CVAE_GEMM_T128_BK - 1) / CVAE_GEMM_T128_BK) * CVAE_GEMM_T128_BK; }
+        float* sl = sp > 1 ? ws : nullptr;
+        const int64_t tn128 = (N + 127) / 128, tm128 = (M + 127) / 128;
+        if (tn128 * tm128 * sp > 0x7fffffff) return CVAE_E_BADSHAPE;
+        const dim3 grid((unsigned)(tn128 * tm128 * sp));
+        const bool akc = sak == 1, bkc = sbk == 1;
+        const int n_slow = N > M;
+#define T128(AK, BKC) hipLaunchKernelGGL((gemm_bf16_t128_kernel<AK, BKC, CVAE_GEMM_T128_BK>), grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, kps, act, sl, (int)tn128, (int)tm128, n_slow)
+        if (akc) { if (bkc) T128(true, true); else T128(true, false); } else { if (bkc) T128(false, true); else T128(false, false); }
+#undef T128
+        CVAE_CHECK_LAUNCH();
+        if (sl) {
+            hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, (const float*)sl, (int)sp, C, bias, M, N, ldc, act);
+            CVAE_CHECK_LAUNCH();
+        }
+        return CVAE_OK;
+    }
     const int64_t tm = (M + LT - 1) / LT, tn = (N + LT - 1) / LT;
     if (tm > 65535) return CVAE_E_BADSHAPE;
     int64_t k_per_split;
@@ -369,15 +568,17 @@ static int64_t skinny_bwd_chunks(int64_t K, int64_t N, bool wide, int64_t* nchun
 extern "C" size_t cvae_linear_workspace_bytes(int64_t M, int64_t K, int64_t N, int op) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
     int64_t splits = 1, elems = 0;
+    // (the bf16-operand products may take the 128-tile kernel, whose split count differs: the larger of the two needs is reported)
+    auto both = [](int64_t m, int64_t n, int64_t k) { const int64_t a = gemm_splits(m, n, k, nullptr), b = (m >= 128 && n >= 128 && k >= 128) ? gemm_t128_splits(m, n, k, nullptr) : 1; return a > b ? a : b; };
     if (op == 0) {                                           // forward: y [M][N] over K
-        if (M <= SK_M && K >= 64) splits = skinny_fwd_chunks(K, N, nullptr); else splits = gemm_splits(M, N, K, nullptr);
+        if (M <= SK_M && K >= 64) splits = skinny_fwd_chunks(K, N, nullptr); else splits = both(M, N, K);
         elems = M * N;
     } else if (op == 1) {                                    // backward-data: dx [M][K] over N
-        if (M <= SK_M) splits = skinny_bwd_chunks(K, N, K >= 1024, nullptr); else splits = gemm_splits(M, K, N, nullptr);
+        if (M <= SK_M) splits = skinny_bwd_chunks(K, N, K >= 1024, nullptr); else splits = both(M, K, N);
         elems = M * K;
     } else if (op == 2) {                                    // backward-weight: dW [N][K] over M (+ the bias column sums)
         if (M > SK_M) {
-            splits = gemm_splits(N, K, M, nullptr);
+            splits = both(N, K, M);
             const size_t cs = cvae_channel_sum_workspace_bytes(M, N, CVAE_F32);
             const size_t sl = splits > 1 ? (size_t)splits * N * K * sizeof(float) : 0;
             return sl > cs ? sl : cs;
