@@ -237,39 +237,50 @@ __global__ __launch_bounds__(256) void gemm_bf16_t128_kernel(const float* __rest
     F4U ra[DEPTH][NL], rb[DEPTH][NL];
     // one operand's stage: P[row * s_row + k * s_k], rows row0 .. row0 + 127 (< R), k in [k0, k0 + BK) (< kend)
     // Every load is an unconditional 16-byte vector from an address clamped into the operand (rows to R - 1 / R - 4, k to K - 4 / kend - 1); what the
-    // clamp moved or what lies past the range is fixed up in registers when the stage is written to LDS (stash).  No branch surrounds a load, and the
-    // stage loop below is straight-line code: with guarded loads or conditional fetches the compiler's s_waitcnt insertion fell back to vmcnt(0) before
-    // every LDS write — one global round trip per stage, whatever the prefetch depth (26 us for the 1024 x 3158 x 512 forward).
-    auto fetch = [&](auto kc, const float* __restrict__ P, int64_t row0, int64_t R, int64_t s_row, int64_t s_k, int64_t k0, F4U (&rg)[NL]) {
-        if constexpr (decltype(kc)::value) {                 // k contiguous: thread -> rows t / (BK / 4) + (1024 / BK) i, k = 4 (t % (BK / 4))
-            constexpr int QR = BK / 4, RS = 256 / QR;
-            const int64_t gkc = min(k0 + 4 * (t % QR), K - 4);
+    // clamp moved or what lies past kend is fixed up in registers when the stage is written to LDS (stash) — and only there, behind block-uniform
+    // branches that contain no load.  No branch surrounds a load and the stage loop is straight-line code: with guarded loads or conditional fetches
+    // the compiler's s_waitcnt insertion fell back to vmcnt(0) before every LDS write (one global round trip per stage whatever the prefetch depth).
+    // Rows past R need no zeroing: they only reach outputs that are never stored.  Offsets are 32-bit (the host checks the operands' extents) and
+    // the row part is hoisted: a wave64 VALU instruction costs 4 cycles, and 64-bit address arithmetic plus unconditional fix-up selects for 8
+    // vectors per stage had the loop VALU-bound (1.2 us per stage for 256 cycles of MFMA).
+    constexpr int QR = BK / 4, RS = 256 / QR;                // k-contiguous image: thread -> rows t / QR + RS i, k = 4 (t % QR)
+    const int kq = 4 * (t % QR), kl = NL * (t >> 5);         // row-contiguous image: thread -> rows 4 (t % 32) .. + 3, k = kl + j
+    const int Ki = (int)K, kendi = (int)kend;
+    int rowA[NL], rowB[NL];                                  // hoisted row parts (k-contiguous: one per vector; row-contiguous: [0] only)
 #pragma unroll
-            for (int i = 0; i < NL; ++i) rg[i] = *(const F4U*)(P + min(row0 + t / QR + RS * i, R - 1) * s_row + gkc);
-        } else {                                             // row contiguous: thread -> rows 4 (t % 32) .. + 3, k = NL (t / 32) + j
-            const int64_t gc = min(row0 + 4 * (t & 31), R - 4);
+    for (int i = 0; i < NL; ++i) {
+        rowA[i] = A_KC ? (int)(min(m0 + t / QR + RS * i, M - 1) * sam) : (int)min(m0 + 4 * (t & 31), M - 4);
+        rowB[i] = B_KC ? (int)(min(n0 + t / QR + RS * i, N - 1) * sbn) : (int)min(n0 + 4 * (t & 31), N - 4);
+    }
+    auto fetch = [&](auto kc, const float* __restrict__ P, const int (&rowo)[NL], int s_k, int k0, F4U (&rg)[NL]) {
+        if constexpr (decltype(kc)::value) {
+            const int d = min(k0 + kq, Ki - 4);
 #pragma unroll
-            for (int j = 0; j < NL; ++j) rg[j] = *(const F4U*)(P + min(k0 + NL * (t >> 5) + j, kend - 1) * s_k + gc);
+            for (int i = 0; i < NL; ++i) rg[i] = *(const F4U*)(P + (rowo[i] + d));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) rg[j] = *(const F4U*)(P + (min(k0 + kl + j, kendi - 1) * s_k + rowo[0]));
         }
     };
-    auto stash = [&](auto kc, bf16* img, const F4U (&rg)[NL], int64_t row0, int64_t R, int64_t k0) {
-        const bool interior = row0 + BT <= R && k0 + BK <= kend;
+    auto stash = [&](auto kc, bf16* img, const F4U (&rg)[NL], int row0, int R, int k0) {
+        const bool kpart = k0 + BK > kendi;                  // block-uniform: only the last stage of the last split, or a padding stage
         if constexpr (decltype(kc)::value) {
-            constexpr int QR = BK / 4, RS = 256 / QR;
-            const int64_t gk = k0 + 4 * (t % QR);
-            const int sh = (int)(gk - min(gk, K - 4)), nv = (int)max((int64_t)0, min((int64_t)4, kend - gk));
+            const int gk = k0 + kq, sh = gk - min(gk, Ki - 4), nv = max(0, min(4, kendi - gk));
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                const F4U v = interior ? rg[i] : shift_sel(rg[i], sh, (row0 + t / QR + RS * i) < R ? nv : 0);
-                *(uint2*)(img + (t / QR + RS * i) * PR + 4 * (t % QR)) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+                F4U v = rg[i];
+                if (kpart) v = shift_sel(v, sh, nv);
+                *(uint2*)(img + (t / QR + RS * i) * PR + kq) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
             }
         } else {
-            const int64_t g = row0 + 4 * (t & 31);
-            const int sh = (int)(g - min(g, R - 4)), nv = (int)max((int64_t)0, min((int64_t)4, R - g));
+            const bool redge = row0 + BT > R;                // block-uniform: the last row tile of an extent that is not a multiple of 128
+            const int g = row0 + 4 * (t & 31), sh = g - min(g, R - 4);
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                const F4U v = interior ? rg[j] : shift_sel(rg[j], sh, (k0 + NL * (t >> 5) + j) < kend ? nv : 0);
-                *(uint2*)(img + (NL * (t >> 5) + j) * PT + 4 * (t & 31)) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+                F4U v = rg[j];
+                if (redge) v = shift_sel(v, sh, 4);
+                if (kpart && k0 + kl + j >= kendi) v = F4U{0.f, 0.f, 0.f, 0.f};
+                *(uint2*)(img + (kl + j) * PT + 4 * (t & 31)) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
             }
         }
     };
@@ -288,18 +299,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_t128_kernel(const float* __rest
     };
     const std::integral_constant<bool, A_KC> akc;
     const std::integral_constant<bool, B_KC> bkc;
+    const int sak_i = (int)sak, sbk_i = (int)sbk, m0i = (int)m0, n0i = (int)n0, Mi = (int)M, Ni = (int)N;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { fetch(akc, A, m0, M, sam, sak, kbeg + d * BK, ra[d]); fetch(bkc, Bm, n0, N, sbn, sbk, kbeg + d * BK, rb[d]); }
+    for (int d = 0; d < DEPTH; ++d) { fetch(akc, A, rowA, sak_i, (int)kbeg + d * BK, ra[d]); fetch(bkc, Bm, rowB, sbk_i, (int)kbeg + d * BK, rb[d]); }
     // DEPTH stages per trip, no exits inside: a stage past kend stashes zeros (its loads were clamped) and multiplies them
-    for (int64_t k0 = kbeg; k0 < kend; k0 += DEPTH * BK) {
+    for (int k0 = (int)kbeg; k0 < kendi; k0 += DEPTH * BK) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            const int64_t ks = k0 + d * BK;
-            stash(akc, As, ra[d], m0, M, ks);
-            stash(bkc, Bs, rb[d], n0, N, ks);
+            const int ks = k0 + d * BK;
+            stash(akc, As, ra[d], m0i, Mi, ks);
+            stash(bkc, Bs, rb[d], n0i, Ni, ks);
             __syncthreads();
-            fetch(akc, A, m0, M, sam, sak, ks + DEPTH * BK, ra[d]);
-            fetch(bkc, Bm, n0, N, sbn, sbk, ks + DEPTH * BK, rb[d]);
+            fetch(akc, A, rowA, sak_i, ks + DEPTH * BK, ra[d]);
+            fetch(bkc, Bm, rowB, sbk_i, ks + DEPTH * BK, rb[d]);
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
                 bf16x8 a[2], b[2];
@@ -313,22 +325,49 @@ __global__ __launch_bounds__(256) void gemm_bf16_t128_kernel(const float* __rest
             __syncthreads();
         }
     }
-    // D: lane (r, h) holds column r, rows (e & 3) + 8 (e >> 2) + 4 h of each 32 x 32 tile
+    // Epilogue through LDS, 16 tile rows at a time: the MFMA leaves a lane one column of 16 rows, so direct stores are 4-byte pieces in 128-byte runs
+    // (6-11 us of a 28 us product by ablation: 13-17 MB of output per product); staged, every lane stores 16 bytes and a wave two 512-byte rows.
+    // D: lane (r, h) holds column r, rows (e & 3) + 8 (e >> 2) + 4 h of each 32 x 32 tile.
+    constexpr int SPITCH = 132;                              // floats: 528 B rows keep the 16-byte reads aligned and spread the 4-row step over the banks
+    static_assert(16 * SPITCH * 4 <= IMG * 2, "the staging rows fit the A image");
+    float* stage = (float*)As;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t gn = n0 + wn * 64 + j * 32 + r;
-        if (gn >= N) continue;
-        const float bv = (bias && !slabs) ? bias[gn] : 0.f;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int pwm = pass >> 2, pi = (pass >> 1) & 1, half = pass & 1;
+        if (wm == pwm) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t gm = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (gm < M) {
-                    if (slabs) slabs[((size_t)split * M + gm) * N + gn] = acc[i][j][e];
-                    else C[gm * ldc + gn] = apply_act(acc[i][j][e] + bv, act);
+                for (int eh = 0; eh < 2; ++eh)
+#pragma unroll
+                    for (int el = 0; el < 4; ++el)
+                        stage[(el + 4 * h + 8 * eh) * SPITCH + wn * 64 + j * 32 + r] = acc[pi][j][4 * (2 * half + eh) + el];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int lr = (t >> 5) + 8 * u, c4 = t & 31;
+            const int64_t gm = m0 + pwm * 64 + pi * 32 + 16 * half + lr, gn = n0 + 4 * c4;
+            const float4 v4 = *(const float4*)(stage + lr * SPITCH + 4 * c4);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (gm < M && gn < N) {
+#ifndef CVAE_GEMM_T128_NOSTORE
+                float* dst = slabs ? slabs + ((size_t)split * M + gm) * N + gn : C + gm * ldc + gn;
+                if (!slabs) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + ((bias && gn + e < N) ? bias[gn + e] : 0.f), act);
                 }
+                if (gn + 3 < N) *(F4U*)dst = F4U{v[0], v[1], v[2], v[3]};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) if (gn + e < N) dst[e] = v[e];
+                }
+#else
+                if (v[0] == 123.456f) C[0] = 1.f;            // probe build: the epilogue's stores removed
+#endif
             }
+        }
+        __syncthreads();
     }
 }
 // split-K of the 128-tile form: until ~CVAE_GEMM_T128_WGS workgroups exist, >= 4 stages per split
@@ -382,7 +421,7 @@ static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias
     if (M < 0 || N <= 0 || K <= 0 || ldc < N) return CVAE_E_BADSHAPE;
     if (M == 0) return CVAE_OK;
     if (!A || !Bm || !C) return CVAE_E_NULLPTR;
-    if (bf16_math && K >= 128 && gemm_t128_ok(M, N, sam, sak, sbk, sbn)) {
+    if (bf16_math && K >= 128 && gemm_t128_ok(M, N, sam, sak, sbk, sbn) && (M * sam + K * sak) < ((int64_t)1 << 31) && (N * sbn + K * sbk) < ((int64_t)1 << 31)) {      // (32-bit element offsets inside the kernel)
         int64_t kps;
         int64_t sp = gemm_t128_splits(M, N, K, &kps);
         if (sp > 1 && (!ws || ws_bytes < (size_t)sp * M * N * sizeof(float))) { sp = 1; kps = ((K + CVAE_GEMM_T128_BK - 1) / CVAE_GEMM_T128_BK) * CVAE_GEMM_T128_BK; }
