@@ -3,7 +3,8 @@
 // 8 positions wide reads 64-96 contiguous bytes per image row — so every kernel here tiles WIDE IN X (32 positions, 16 for the transposed conv)
 // and a workgroup walks several tiles with the next halo in flight.
 //   down   (image -> S)  : down_c1_vec_kernel (bf16 S; image read as stored, fp32 or bf16, in 16-byte vectors) / down_c1_kernel (element loads)
-//   up     (S -> image)  : up_c1_mfma_kernel (bf16: v_mfma_f32_16x16x32_bf16 over the 3^nd neighbourhood) / up_c1_kernel (scalar form, fp32)
+//   up     (S -> image)  : up_c1_mfma_kernel (bf16: v_mfma_f32_16x16x32_bf16 over the 3^nd neighbourhood; up_c1_mfma_walk_kernel walks z columns of tiles
+//                          on large 3D launches and keeps the shared halo planes in LDS) / up_c1_kernel (scalar form, fp32)
 //   wgrad                : wgrad_c1_kernel, [Cs x taps] = S^T . im2col(L) with K = positions on the MFMA (bf16 32x32x16 with transposing LDS reads, fp32
 //                          32x32x2); persistent workgroups leave slabs of partial sums, wgrad_c1_finish_kernel adds them in index order (no atomics)
 #include "common.h"

@@ -11,6 +11,8 @@
 // workgroups until the grid covers the chip: every split leaves its partial tile in a slab of the caller's workspace
 // ([split][M][N], plain stores) and one finish launch adds the slabs in index order, then bias and activation — no float
 // atomics, so results are bit-reproducible.  Without (enough) workspace the same kernels run unsplit.
+// Opt-in bf16-operand forms (Linear.math = bfloat16: fp32 in memory, rounded on the way into LDS, fp32 accumulate and output): gemm_bf16_kernel (the same
+// 64 x 64 tiling) and, for products with M, N, K >= 128, gemm_bf16_t128_kernel (128 x 128 tiles, vector operand fetch, transposed LDS reads).
 #include "common.h"
 #include <type_traits>
 
