@@ -417,7 +417,8 @@ def test_linear_forward_backward(M, K, N, act):
     close(bg.grad.cpu(), gb_ref, torch.float32, "db")
 
 
-@pytest.mark.parametrize("M,K,N,act", [(1024, 3158, 512, "relu"), (1024, 22, 3136, "relu"), (200, 700, 130, None), (64, 4096, 96, "leaky02")])
+@pytest.mark.parametrize("M,K,N,act", [(1024, 3158, 512, "relu"), (1024, 22, 3136, "relu"), (200, 700, 130, None), (64, 4096, 96, "leaky02"),
+                                       (300, 515, 257, None), (129, 1031, 641, "relu")])     # odd extents everywhere: the 128-tile kernel's clamped vector fetches and edge fix-ups
 def test_linear_bf16_math_forward_backward(M, K, N, act):
     """ops.Linear(math=bfloat16): the GEMMs round their operands to bf16 on the way into LDS and accumulate in fp32.  Reference: fp32 CPU products of
     the ROUNDED operands (x, W for the forward; dy, W for dx; dy, x for dW), so only summation order differs: the fp32 tolerances of `close`.
