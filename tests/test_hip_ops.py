@@ -341,6 +341,22 @@ def test_upsample_linear(nd, src, dst, dtype):
     close(from_cl(xg.grad, nd), gx_ref, dtype, "dupsample")
 
 
+@pytest.mark.parametrize("B,src", [(32, (64, 64, 64)), (64, (64, 64, 32))], ids=["tile-kernel", "block-kernel"])
+def test_up2x_streaming_outputs_equal_the_small_launches(B, src):
+    """Exact-2x resizes of 256 MB and more leave through nontemporal stores (rows of 64: up2x_tile_kernel<NT>; other widths: up2x_block_kernel MODE 4).
+    Same arithmetic as the launches below that size, which test_upsample_linear ties to F.interpolate: the bits must agree chunk by chunk."""
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, *src, 1, generator=g).to(DEV).to(torch.bfloat16)
+    dst = tuple(2 * v for v in src)
+    assert B * dst[0] * dst[1] * dst[2] * 4 >= 256 << 20
+    with torch.no_grad():
+        big = ops.UpsampleLinear.apply(x, dst)
+        for b0 in range(0, B, 8):
+            small = ops.UpsampleLinear.apply(x[b0:b0 + 8].contiguous(), dst)
+            assert torch.equal(big[b0:b0 + 8], small), b0
+            del small
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_layout_roundtrip_cat_onehot(dtype):
     g = torch.Generator().manual_seed(6)
