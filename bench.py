@@ -116,6 +116,8 @@ def make_batch(B, size, seed, device, binary=False):
 
 
 def cpu_info():
+    """Host description for the cpu_baseline leg: logical CPUs, the affinity mask, the PHYSICAL cores inside it (distinct
+    thread-sibling sets: SURVEY.md §8(d) asks for "all physical cores of the node"), the cgroup CPU quota if one is set, the model."""
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -124,8 +126,20 @@ def cpu_info():
                 break
     except OSError:
         pass
-    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return dict(os_cpu_count=os.cpu_count(), affinity=aff, cpu_model=model)
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            cores.add(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip())
+        except OSError:
+            cores.add(str(c))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return dict(os_cpu_count=os.cpu_count(), affinity=len(cpus), physical_cores=len(cores), cgroup_cpu_quota=quota, cpu_model=model)
 
 
 def cpu_baseline(B, size, budget_s, x, m, t, eps, lr, threads, min_steps):
@@ -149,10 +163,9 @@ def cpu_baseline(B, size, budget_s, x, m, t, eps, lr, threads, min_steps):
             break
     times.sort()
     med = times[len(times) // 2]
-    info = cpu_info()
     return dict(value=B / med, unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{len(times)} timed oracle train steps (fp32, B={B}, {size}^3) after 1 warm-up; median {med * 1e3:.0f} ms/step",
-                losses=[v if v == v and abs(v) != float("inf") else None for v in losses[:8]], **info), losses
+                losses=[v if v == v and abs(v) != float("inf") else None for v in losses[:8]]), losses
 
 
 def timed_region(step, steps, warmup, world, dev, min_total_s):
@@ -313,6 +326,7 @@ def run_volume(args, rank, world, dev):
             if not want_split:
                 raise
             capture_fallback = repr(e)
+            _ops.reset_pending_wgrads()                              # a backward that raised never ran its end-of-backward flush: drop its queue
             print(f"[bench] split-backward capture failed ({e!r}); falling back to one exchange after the backward", file=sys.stderr)
             want_split = False
             gstep = GraphedTrainStep(model, opt, (x, m, t), None, reducer=reducer, warmup=3)
@@ -365,9 +379,20 @@ def run_volume(args, rank, world, dev):
         res["kernels"] = kernels
     if world == 1 and args.cpu_seconds > 0 and not vessel:
         info = cpu_info()
-        threads = args.cpu_threads if args.cpu_threads > 0 else min(info["affinity"], 16)
+        # torch.set_num_threads(all physical cores of the node) — the cores inside this process's affinity mask — plus an
+        # 8-thread figure for comparability with the survey's ballparks; the 16-thread figure (the box's per-GPU CPU share, what rounds 1-2
+        # reported) stays as a third field.  The main leg also yields the K + 1 losses of the ELBO trajectory check below.
+        threads = args.cpu_threads if args.cpu_threads > 0 else max(1, info["physical_cores"])
         K = 5
-        cb, ref_losses = cpu_baseline(args.batch, args.size, args.cpu_seconds, x.cpu(), m.cpu(), t.cpu(), eps.cpu(), args.lr, threads, K + 1)
+        xc, mc, tc, ec = x.cpu(), m.cpu(), t.cpu(), eps.cpu()
+        cb, ref_losses = cpu_baseline(args.batch, args.size, args.cpu_seconds * 0.5, xc, mc, tc, ec, args.lr, threads, K + 1)
+        cb.update(info)
+        cb["threads_rule"] = "all physical cores in the affinity mask (thread-sibling sets), torch.set_num_threads"
+        for name, nthr in (("cpu_baseline_8t", 8), ("cpu_baseline_16t", 16)):
+            if nthr < threads:
+                sub, _ = cpu_baseline(args.batch, args.size, args.cpu_seconds * 0.25, xc, mc, tc, ec, args.lr, nthr, 3)
+                sub.pop("losses", None)
+                cb[name] = sub
         res["cpu_baseline"] = cb
         res["elbo_rel_err"] = abs(elbo0 - ref_losses[0]) / abs(ref_losses[0])
         res["gpu_over_cpu"] = res["value"] / cb["value"]
@@ -495,6 +520,43 @@ def run_decode(args, rank, world, dev):
     return res
 
 
+SECONDARY = (("mnist", "mnist", None, {}), ("vol64-f32", "vol64-f32", None, {}), ("decode-bf16", "decode", "bf16", {}), ("decode-fp8", "decode", "fp8", {}))
+
+
+def secondary_lines(args, dev):
+    """The other BASELINE.json configurations, measured in the SAME default run (so the driver's record carries them): configs[1] MNIST bf16
+    batch 1024, configs[2] 64^3 fp32 batch 16, configs[4] the 240-row counterfactual decode in bf16 and fp8 (and, with the fp8 train step,
+    its train leg).  Same timed-region protocol as the headline (barrier + synchronize brackets, median repetition); compact fields only —
+    the full line of each is `python bench.py --workload ...`."""
+    import copy
+    import gc
+    out = {}
+    for name, workload, dtype, extra in SECONDARY:
+        a = copy.copy(args)
+        dsz, dB, ddt = WORKLOAD_DEFAULTS[workload]
+        a.workload, a.size, a.batch, a.dtype = workload, dsz, dB, dtype or ddt
+        a.cpu_seconds, a.roofline_steps, a.min_timed_s, a.steps, a.warmup = 0.0, 2, 0.2, 20, 5
+        for k, v in extra.items():
+            setattr(a, k, v)
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            fn = run_mnist if workload == "mnist" else (run_decode if workload == "decode" else run_volume)
+            r = fn(a, 0, 1, dev)
+            roof = r.get("roofline") or {}
+            out[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "ms_per_step_min": r["ms_per_step_min"],
+                         "dtype": r["dtype"], "workload": r["config"]["workload"], "final_loss": r.get("final_loss"),
+                         "roofline_step": roof.get("step"), "roofline_kernel": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_ms")} if roof else None}
+            if "fp8" in r:
+                out[name]["fp8"] = r["fp8"]
+        except Exception as e:                                      # noqa: BLE001 - a secondary line must never take the headline down
+            out[name] = {"error": repr(e)}
+    return out
+
+
+WORKLOAD_DEFAULTS = {"vol128": (128, 4, "bf16"), "vol128-vessel": (128, 4, "bf16"), "vol64-f32": (64, 16, "f32"), "mnist": (28, 1024, "bf16"), "decode": (128, 4, "bf16")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -505,8 +567,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8"], help="fp8: decode workload only (e4m3 conv operands)")
     ap.add_argument("--min-timed-s", type=float, default=0.2, help="repeat the K-step timed region until this much has been timed; the median repetition is reported")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = the box's CPU share: min(affinity, 16 per GPU))")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg: half for the all-cores figure, a quarter each for the 8- and 16-thread ones (0 disables)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the main cpu_baseline leg (0 = every physical core in the affinity mask)")
     ap.add_argument("--lr", type=float, default=1e-4, help="Adam learning rate (the reference uses 1e-3, causal_cascade/main.py:50, at which the 3D lift diverges on step 3 in the oracle too: DESIGN.md)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--overlap-adam", action="store_true", help="run the non-encoder part of the Adam update on a side stream under the encoder backward")
@@ -520,10 +582,10 @@ def main():
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")
     ap.add_argument("--force-overlap-exchange", action="store_true", help="take the split-backward capture also at N = 1 (no exchange happens)")
     ap.add_argument("--roofline-steps", type=int, default=5, help="eager steps with per-launch HIP events after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="default vol128 run at N = 1: skip the compact lines of the other BASELINE.json configurations")
     ap.add_argument("--decode-native", action="store_true", help="decode workload: stop at the decoder's native 64^3 (no resize)")
     args = ap.parse_args()
-    defaults = {"vol128": (128, 4, "bf16"), "vol128-vessel": (128, 4, "bf16"), "vol64-f32": (64, 16, "f32"), "mnist": (28, 1024, "bf16"), "decode": (128, 4, "bf16")}
-    dsz, dB, ddt = defaults[args.workload]
+    dsz, dB, ddt = WORKLOAD_DEFAULTS[args.workload]
     args.size = args.size or dsz
     args.batch = args.batch or dB
     args.dtype = args.dtype or ddt
@@ -554,6 +616,8 @@ def main():
         res = run_decode(args, rank, world, dev)
     else:
         res = run_volume(args, rank, world, dev)
+    if args.workload == "vol128" and world == 1 and not args.no_secondary and args.cpu_seconds > 0 and res is not None:      # the full-report run (A/B runs pass --cpu-seconds 0)
+        res["secondary"] = secondary_lines(args, dev)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

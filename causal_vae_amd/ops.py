@@ -338,13 +338,21 @@ SPLIT_K = True      # hand the conv data kernels their split-K scratch (tests sw
 
 def _can_defer(weight, bias):
     """A weight gradient may be computed at the END of the backward pass only if nothing looks at it earlier: no accumulation onto an
-    existing .grad (AccumulateGrad would add the still-empty tensor), no tensor hooks, no double backward."""
+    existing .grad (AccumulateGrad would add the still-empty tensor), no tensor hooks (pre- or post-accumulate), no double backward, and
+    no second use of the same weight in this pass (the engine would add two still-empty tensors before the flush)."""
     if torch.is_grad_enabled():
         return False
     for p in (weight, bias):
         if p is None:
             continue
-        if not p.is_leaf or p.grad is not None or p._backward_hooks:      # a derived weight (ops.Conv3ToK4) hands its gradient on at once
+        if not p.is_leaf or p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False                                     # a derived weight (ops.Conv3ToK4) hands its gradient on at once
+    if _wg_task_is_current():
+        if id(weight) in _WG_SHARED:
+            return False
+        if any(e["wid"] == id(weight) for e in _WG_PENDING):
+            _wgrad_flush()                                   # the first use's gradient must exist before the engine sums the two
+            _WG_SHARED.add(id(weight))
             return False
     return True
 
@@ -395,12 +403,35 @@ DEFER_WGRAD = True     # weight gradients of the MFMA conv layers are queued dur
                        # reduce launch) at its end (cvae_conv_wgrad_multi): the small layers run in the shadow of the large ones
 _WG_PENDING = []
 _WG_QUEUED = [False]
+_WG_TASK = [-1]            # id of the autograd graph task the queue (and its end-of-backward callback) belongs to
+_WG_SHARED = set()         # weights met twice in this pass (shared by two layers): their gradients are computed at once
+
+
+def _graph_task_id():
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
+def _wg_task_is_current():
+    return _WG_QUEUED[0] and _WG_TASK[0] == _graph_task_id()
+
+
+def reset_pending_wgrads():
+    """Forget queued weight gradients without computing them.  A backward pass that raised never runs its end-of-backward callback (the
+    engine drops it), so its entries — and the "callback queued" flag — would otherwise outlive it; every deferral checks for that
+    itself (a queue that belongs to another graph task is stale), and callers that catch a failed step / capture may call this too."""
+    _WG_PENDING.clear()
+    _WG_SHARED.clear()
+    _WG_QUEUED[0] = False
+    _WG_TASK[0] = -1
 
 
 def _wgrad_flush():
     """Run every queued weight gradient (grouped by device / nd / dtype, <= 8 layers per launch).  Installed as the autograd engine's
-    end-of-backward callback, so `.grad` is complete when loss.backward() / torch.autograd.grad() returns — any optimizer works."""
-    _WG_QUEUED[0] = False
+    end-of-backward callback, so `.grad` is complete when loss.backward() / torch.autograd.grad() returns — any optimizer works.
+    Every entry owns a reference to the STORAGE of its outputs (not to the tensors: a second tensor reference would make AccumulateGrad
+    clone the still-empty gradient instead of adopting it), so the launch never writes to memory the allocator has handed on — also when
+    nobody kept the gradient (torch.autograd.grad(loss, [x]) with trainable weights)."""
     if not _WG_PENDING:
         return
     todo = list(_WG_PENDING)
@@ -410,6 +441,7 @@ def _wgrad_flush():
         groups.setdefault((e["S"].device, e["nd"], e["S"].dtype), []).append(e)
     for (dev, nd, dt), es in groups.items():
         with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
             for c0 in range(0, len(es), 8):
                 ch = es[c0:c0 + 8]
                 k = len(ch)
@@ -418,6 +450,16 @@ def _wgrad_flush():
                 label = f"conv_wgrad_multi nd{nd} B{ch[0]['dims'][0]} " + ";".join("S{1}x{2}x{3}x{4}L{8}".format(*e["dims"]) for e in ch)
                 check(L.timed(label, lib.cvae_conv_wgrad_multi, k, vp("S"), vp("L"), vp("dW"), vp("db"), (C_.c_int * k)(*[e["side"] for e in ch]), vp("ws"),
                               (C_.c_size_t * k)(*[e["nbytes"] for e in ch]), dims, nd, L.dtype_code(dt), stream()), "conv_wgrad_multi")
+                for e in ch:                                 # scratch allocated on a forked side stream (FORK_BACKWARD), used here on the caller's:
+                    if e["alloc_stream"] != cur.cuda_stream:  # tell the caching allocator, or the side stream's pool may hand it on too early
+                        e["ws"].record_stream(cur)
+
+
+def _wgrad_callback():
+    _WG_QUEUED[0] = False
+    _WG_TASK[0] = -1
+    _WG_SHARED.clear()
+    _wgrad_flush()
 
 
 def flush_pending_wgrads():
@@ -425,7 +467,7 @@ def flush_pending_wgrads():
     _wgrad_flush()
 
 
-def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False, may_defer=False):
+def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False, may_defer=False, wid=None):
     """dW and, in the same pass, the bias gradient: want_sbias = per-channel sum of S (Conv layer), want_lbias = of L (ConvTranspose).
     may_defer: the caller has checked that nothing reads the returned tensors before the backward pass ends (see _can_defer)."""
     B, sd, sh, sw, Cs = _cl_dims(St)
@@ -443,12 +485,18 @@ def _conv_wgrad(St, Lt, nd, wshape, want_sbias=False, want_lbias=False, may_defe
     exact2x = lh == 2 * sh and lw == 2 * sw and (nd == 2 or ld == 2 * sd)
     if (DEFER_WGRAD and may_defer and Cl != 1 and Cs % 64 == 0 and Cl % 32 == 0 and B > 0 and (exact2x or not want_lbias)):
         try:
+            tid = _graph_task_id()
+            if _WG_QUEUED[0] and _WG_TASK[0] != tid:         # left behind by a backward pass that raised: its callback never ran
+                reset_pending_wgrads()
             if not _WG_QUEUED[0]:
-                torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush)     # only legal inside a backward pass
+                torch.autograd.Variable._execution_engine.queue_callback(_wgrad_callback)     # only legal inside a backward pass
                 _WG_QUEUED[0] = True
-            # the outputs are queued by ADDRESS: a second reference to dW / db would make AccumulateGrad clone them (still empty) instead of
-            # adopting them as .grad; their storage is kept alive by whoever receives the gradient (.grad or torch.autograd.grad's result)
+                _WG_TASK[0] = tid
+            # the outputs are queued by ADDRESS plus a reference to their STORAGE: a second reference to the tensors dW / db would make
+            # AccumulateGrad clone them (still empty) instead of adopting them as .grad
             _WG_PENDING.append(dict(S=St, L=Lt, dW=dW.data_ptr(), db=(db.data_ptr() if db is not None else None), side=1 if want_lbias else 0, ws=ws,
+                                    keep=(dW.untyped_storage(), db.untyped_storage() if db is not None else None), wid=wid,
+                                    alloc_stream=torch.cuda.current_stream(St.device).cuda_stream,
                                     nbytes=nbytes, nd=nd, dims=(B, sd, sh, sw, Cs, ld, lh, lw, Cl)))
             return (dW, db) if (want_sbias or want_lbias) else dW
         except RuntimeError:
@@ -512,9 +560,9 @@ class ConvDown(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 defer = _can_defer(weight, ctx.bias_ref if want_db else None)
                 if want_db:
-                    dw, db = _conv_wgrad(g, x, nd, weight.shape, want_sbias=True, may_defer=defer)
+                    dw, db = _conv_wgrad(g, x, nd, weight.shape, want_sbias=True, may_defer=defer, wid=id(weight))
                 else:
-                    dw = _conv_wgrad(g, x, nd, weight.shape, may_defer=defer)
+                    dw = _conv_wgrad(g, x, nd, weight.shape, may_defer=defer, wid=id(weight))
             elif want_db:
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
@@ -555,9 +603,9 @@ class ConvUp(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 defer = _can_defer(weight, ctx.bias_ref if want_db else None)
                 if want_db:
-                    dw, db = _conv_wgrad(x, g, nd, weight.shape, want_lbias=True, may_defer=defer)
+                    dw, db = _conv_wgrad(x, g, nd, weight.shape, want_lbias=True, may_defer=defer, wid=id(weight))
                 else:
-                    dw = _conv_wgrad(x, g, nd, weight.shape, may_defer=defer)
+                    dw = _conv_wgrad(x, g, nd, weight.shape, may_defer=defer, wid=id(weight))
             elif want_db:
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
@@ -928,11 +976,13 @@ class EpsSource:
         return philox_normal(like.shape, torch.initial_seed(), 0, like.device, self.counter, self.subsequence())
 
     def state(self):
-        """{'calls': number of draws so far} (one host sync)."""
-        return {"calls": int(self.counter.item()) if self.counter is not None else int(self._pending or 0)}
+        """{'calls': number of draws so far (one host sync), 'instance': which of the process's streams this model draws from}."""
+        return {"calls": int(self.counter.item()) if self.counter is not None else int(self._pending or 0), "instance": int(self.instance)}
 
     def load_state(self, st):
         calls = int(st["calls"])
+        if "instance" in st:                                 # the stream id travels with the checkpoint: construction order in the resuming process
+            self.instance = int(st["instance"])              # (a second model, a helper built first) must not change the noise
         if self.counter is not None:
             self.counter.fill_(calls)
         else:

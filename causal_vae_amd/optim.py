@@ -112,13 +112,26 @@ class FusedAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        """Restores IN PLACE where the moment buffers and the device step counter already exist: a HIP graph captured with this optimizer
+        (graph.GraphedTrainStep) replays against those very tensors, and fresh ones would be silently ignored by the replayed update."""
+        old = {p: (st.get("exp_avg"), st.get("exp_avg_sq")) for p, st in self.state.items()}
         super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            for key, prev in zip(("exp_avg", "exp_avg_sq"), old.get(p, (None, None))):
+                new = st.get(key)
+                if prev is not None and new is not None and new is not prev and prev.shape == new.shape and prev.device == new.device:
+                    prev.copy_(new)
+                    st[key] = prev
         steps = {int(st["step"]) for st in self.state.values() if "step" in st}
         if len(steps) > 1:
             raise L.CvaeError("FusedAdam.load_state_dict: parameters carry different step counts")
         if self.device_step and steps:
             dev = next(iter(self.state)).device
-            self._step_dev = torch.full((), steps.pop(), dtype=torch.int32, device=dev)
+            t = steps.pop()
+            if self._step_dev is not None and self._step_dev.device == dev:
+                self._step_dev.fill_(t)
+            else:
+                self._step_dev = torch.full((), t, dtype=torch.int32, device=dev)
         self._counted = False
 
     @torch.no_grad()

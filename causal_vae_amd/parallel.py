@@ -158,13 +158,13 @@ def convert_sync_batchnorm(module, group=None):
 def sync_buffers(module, group=None, mode="average"):
     """BatchNorm running statistics are updated from rank-local batches and drift apart; call this before saving a checkpoint (or once
     per epoch) so that every rank — and the file rank 0 writes — holds the same buffers.  mode 'average': mean over ranks of the floating
-    buffers (integer ones, num_batches_tracked, take the maximum); 'broadcast': rank 0's values."""
+    buffers (integer ones, num_batches_tracked, take the maximum); 'broadcast': the values of the group's first rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
     for b in module.buffers():
         if mode == "broadcast":
-            dist.broadcast(b.data, src=0, group=group)
+            dist.broadcast(b.data, src=(dist.get_global_rank(group, 0) if group is not None else 0), group=group)
         elif b.is_floating_point():
             dist.all_reduce(b.data, op=dist.ReduceOp.SUM, group=group)
             b.data.div_(world)

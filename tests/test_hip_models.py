@@ -478,6 +478,96 @@ def test_training_state_checkpoint_resumes_the_same_run(graphed):
     assert o_b.state_dict()["state"][0]["step"] == 6
 
 
+def test_deferred_wgrad_survives_partial_and_failed_backwards():
+    """The deferred conv weight gradients (ops.DEFER_WGRAD) must not depend on how the backward pass was asked for or how the previous one ended:
+    (a) torch.autograd.grad(loss, [x]) with trainable conv weights — the engine drops their gradients, the end-of-backward launch must still write
+    into memory it owns (the queue holds the storages) and the NEXT full backward must be exact; (b) a backward that raises never runs its flush
+    callback — the following step must notice the stale queue and produce the same gradients as a fresh process; (c) a conv weight shared by two
+    layers (the engine sums two gradients before any flush) gets both computed at once."""
+    g = torch.Generator().manual_seed(77)
+    x, m = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t, eps = torch.randint(0, 19, (2,), generator=g).to(DEV), torch.randn(2, 64, generator=g).to(DEV)
+
+    def grads(model):
+        for p in model.parameters():
+            p.grad = None
+        loss = model.forward_elbo(x, m, t, eps=eps)[0]
+        ops_mod.backward_from(loss)
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+    ref = grads(model)
+    # (a) input gradient only
+    h = torch.randn(2, 8, 8, 8, 64, generator=g).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    w = model.enc_conv[4].weight
+    y = ops_mod.ConvDown.apply(h, w, model.enc_conv[4].bias, 3, "relu", False, False)
+    gx, = torch.autograd.grad(y.float().sum(), [h])
+    assert bool(torch.isfinite(gx.float()).all()) and not ops_mod._WG_PENDING and not ops_mod._WG_QUEUED[0]
+    again = grads(model)
+    for k in ref:
+        assert torch.equal(ref[k], again[k]), k
+    # (b) a backward that raises after a conv layer has queued its gradient
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, v):
+            return v.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError("boom")
+    h2 = torch.randn(2, 8, 8, 8, 64, generator=g).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    y2 = ops_mod.ConvDown.apply(Boom.apply(h2), w, model.enc_conv[4].bias, 3, "relu", False, False)
+    w.grad = None
+    model.enc_conv[4].bias.grad = None
+    with pytest.raises(RuntimeError, match="boom"):
+        y2.float().sum().backward()
+    assert ops_mod._WG_QUEUED[0] and ops_mod._WG_PENDING          # the engine dropped the callback: this is the stale state
+    after = grads(model)
+    assert not ops_mod._WG_PENDING and not ops_mod._WG_QUEUED[0]
+    for k in ref:
+        assert torch.equal(ref[k], after[k]), k
+    # (c) one weight, two uses in one graph
+    w.grad = None
+    model.enc_conv[4].bias.grad = None
+    ha, hb = (torch.randn(2, 8, 8, 8, 64, generator=g).to(DEV).to(torch.bfloat16) for _ in range(2))
+    singles = []
+    for hh in (ha, hb):
+        w.grad = None
+        ops_mod.ConvDown.apply(hh.clone().requires_grad_(True), w, None, 3, "relu", False, False).float().sum().backward()
+        singles.append(w.grad.clone())
+    w.grad = None
+    ya = ops_mod.ConvDown.apply(ha.clone().requires_grad_(True), w, None, 3, "relu", False, False)
+    yb = ops_mod.ConvDown.apply(hb.clone().requires_grad_(True), w, None, 3, "relu", False, False)
+    (ya.float().sum() + yb.float().sum()).backward()
+    assert torch.allclose(w.grad, singles[0] + singles[1], rtol=1e-5, atol=1e-4), float((w.grad - singles[0] - singles[1]).abs().max())
+
+
+def test_fused_adam_load_state_dict_after_capture_reaches_the_replayed_update():
+    """FusedAdam.load_state_dict restores the moments and the device step counter IN PLACE: a graph captured before the load keeps replaying
+    against the same tensors, so a checkpoint loaded after capture is what the replayed update continues from."""
+    from causal_vae_amd.graph import GraphedTrainStep
+    g = torch.Generator().manual_seed(5)
+    x, m = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t = torch.randint(0, 19, (2,), generator=g).to(DEV)
+    ops_mod.EpsSource._instances = 0
+    torch.manual_seed(42)
+    model = CausalBioVAE3D().to(DEV).train()
+    opt = FusedAdam(model.parameters(), lr=1e-4, device_step=True)
+    gs = GraphedTrainStep(model, opt, (x, m, t), None, warmup=3)
+    sd_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd_opt = {"state": {i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in opt.state_dict()["state"].items()},
+              "param_groups": opt.state_dict()["param_groups"]}
+    eps_state = model._eps.state()
+    a = [float(gs()[0]) for _ in range(3)]
+    model.load_state_dict(sd_model)                     # nn.Module.load_state_dict copies in place
+    opt.load_state_dict(sd_opt)
+    model._eps.load_state(eps_state)
+    b = [float(gs()[0]) for _ in range(3)]
+    assert a == b, (a, b)
+    assert int(opt._step_dev) == 6
+
+
 def test_split_backward_capture_matches_eager_steps():
     """GraphedTrainStep(overlap_exchange=True): the backward captured in two graphs around the encoder output (the multi-GPU exchange
     overlap; no process group here, so no exchange happens) == the eager step: losses and weights after 3 + 3 steps, every gradient
