@@ -15,7 +15,7 @@
 //     from the packed global panels into a register ring ("BD"); the other forms stream them through a double-buffered LDS panel, 4 taps
 //     per barrier.  A second `up` kernel (conv_up_full_kernel) stages the halo of ALL input channels once and walks the output parities
 //     inside the workgroup; it serves the large grids of the decode sweep.
-//   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain).
+//   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain);  fp8: v_mfma_scale_f32_32x32x64_f8f6f4.
 //   * epilogue fuses bias + ReLU/Sigmoid (forward use) or the ReLU mask of the saved activation (backward use).
 // wgrad — M = Cs, N = Cl, K = positions.  Both operands are [position][channel] in memory, i.e. K-strided: bf16 uses
 //   the gfx950 transposing LDS read (ds_read_b64_tr_b16) to build K-contiguous fragments; fp32's 32x32x2 MFMA takes
@@ -83,19 +83,39 @@ struct ConvGeom {
 };
 
 // ---------------------------------------------------------------------------------------------- fragments
+// f8x2: TWO consecutive fp8 (e4m3) channels as one 2-byte element.  With it the fp8 product is, byte for byte, the bf16 kernel on a tensor of
+// Cin / 2 "elements": a 16-byte piece is 16 channels, a halo stage (two pieces per position) is 32 channels, the packed weight panels are
+// [tap][Cin / 32][N][32 fp8] = [tap][Cin' / 16][N][16 elements] — the same LDS images, the same conflict-free layout, the same staging.  The one
+// difference is the MFMA: v_mfma_scale_f32_32x32x64_f8f6f4 (block-scaled; unit block scales give plain per-tensor fp8) multiplies K = 64
+// per instruction at twice the bf16 rate per FLOP, so TWO k-steps (two taps of a 32-channel stage) feed ONE instruction: registers 0-3 of
+// both operands hold k-step s, registers 4-7 k-step s + 1.  The order of K inside an instruction does not matter to a dot product as
+// long as both operands use the same one, which the symmetric A / B operand maps guarantee.
+struct f8x2 { unsigned short v; };
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <typename T> struct IsF8 { static constexpr bool value = false; };
+template <> struct IsF8<f8x2> { static constexpr bool value = true; };
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { bf16x8 v; };
 template <> struct Frag<float> { float v[8]; };
-template <> struct Frag<fp8> { long v; };
+template <> struct Frag<f8x2> { i32x4 v; };
 
 __device__ __forceinline__ void lds_load(Frag<bf16>& f, const char* p) { f.v = *(const bf16x8*)p; }
 __device__ __forceinline__ void lds_load(Frag<float>& f, const char* p) {
     const float4 a = *(const float4*)p, b = *(const float4*)(p + 16);
     f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
-__device__ __forceinline__ void lds_load(Frag<fp8>& f, const char* p) { f.v = *(const long*)p; }
-__device__ __forceinline__ void mma(f32x16& acc, const Frag<fp8>& a, const Frag<fp8>& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a.v, b.v, acc, 0, 0, 0);      // non-scaled fp8: the bf16 instruction's shape and rate, half the operand bytes
+__device__ __forceinline__ void lds_load(Frag<f8x2>& f, const char* p) { f.v = *(const i32x4*)p; }
+#define CVAE_E8M0_ONE 0x7F7F7F7F        // block scale 2^0 in every byte: the scaled instruction then is a plain fp8 x fp8 product
+// two k-steps at once (the fp8 form); for the other dtypes simply the two products in order
+__device__ __forceinline__ void mma2(f32x16& acc, const Frag<f8x2>& a0, const Frag<f8x2>& a1, const Frag<f8x2>& b0, const Frag<f8x2>& b1) {
+    const i32x8 a = {a0.v[0], a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3]};
+    const i32x8 b = {b0.v[0], b0.v[1], b0.v[2], b0.v[3], b1.v[0], b1.v[1], b1.v[2], b1.v[3]};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, CVAE_E8M0_ONE, 0, CVAE_E8M0_ONE);
+}
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<f8x2>& a, const Frag<f8x2>& b) {       // never reached: every f8x2 loop pairs its k-steps
+    const Frag<f8x2> z{{0, 0, 0, 0}};
+    mma2(acc, a, z, b, z);
 }
 // lane (r = lane & 31, h = lane >> 5) holds elements k = 8h .. 8h+7 of its row/column in both precisions
 __device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
@@ -104,6 +124,11 @@ __device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag
 __device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ void mma2(f32x16& acc, const Frag<T>& a0, const Frag<T>& a1, const Frag<T>& b0, const Frag<T>& b1) {
+    mma(acc, a0, b0);
+    mma(acc, a1, b1);
 }
 
 template <int ND, int BM> struct Tile;
@@ -140,7 +165,7 @@ template <> struct HaloPitch<2, true> { static constexpr int RS = 20; };
 // is always written as "issue ALL loads of a tile, then store them": the loads overlap each other (and, for the weight
 // panels, the MFMA work placed between the two halves) instead of paying one memory latency per piece.
 template <typename T> struct PieceW { using type = uint4; static constexpr int N = (8 * sizeof(T)) / 16; };
-template <> struct PieceW<fp8> { using type = uint2; static constexpr int N = 1; };
+template <> struct PieceW<fp8> { using type = uint2; static constexpr int N = 1; };       // 8 fp8 codes: an OUTPUT piece (8 channels of one position)
 __device__ __forceinline__ uint4 piece_sel(bool ok, uint4 v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); }
 __device__ __forceinline__ uint2 piece_sel(bool ok, uint2 v) { return make_uint2(ok ? v.x : 0u, ok ? v.y : 0u); }
 template <typename T> struct Piece { typename PieceW<T>::type v[PieceW<T>::N]; };
@@ -193,10 +218,40 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // TS ("K split", BD only): TS = 2 wave groups of WM x WN waves each own every second k-step (odd / even taps for KH = 1, the two 16-channel halves
 // of a stage for KH = 2) of the WHOLE tile and add their accumulators through LDS once, before the epilogue.  With WM = 1 no two waves fetch the
 // same weight fragment, and a fetched fragment feeds MI = 4 MFMAs: half the bytes per MFMA on the vector-memory path the BD tap loop is bound by.
+// 8 floats -> 8 fp8 (e4m3) codes of v * mul, saturating at +-448 (v_cvt_pk_fp8_f32 alone would produce NaN past the range)
+__device__ __forceinline__ uint2 pack8_fp8(const float (&v)[8], float mul) {
+    float c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] = __builtin_amdgcn_fmed3f(v[q] * mul, -CVAE_FP8_MAX, CVAE_FP8_MAX);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+// max over the wave, then ONE atomicMax on one of CVAE_AMAX_SLOTS words (spread by `salt`: same-address atomics serialise at the memory side)
+__device__ __forceinline__ void amax_publish(unsigned* slots, float amx, unsigned salt) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    if ((threadIdx.x & 63) == 0 && amx > 0.f) atomicMax(slots + (salt & 63u), __float_as_uint(amx));
+}
+// fp8 side channel (f8x2 products only; all members may be null): `dscale` = device floats {acc_scale, 1 / s_out8} that replace the by-value
+// scales (a captured training step re-reads them on every replay: delayed scaling), `out8` = a second copy of the result as fp8 codes of
+// result / s_out8 (what the next fp8 layer reads, while `out` keeps the bf16 activation the backward pass needs), `amax` = CVAE_AMAX_SLOTS
+// words that receive max |result| as float bits (non-negative floats order like unsigned integers: one atomicMax per wave, order-independent).
+struct F8Side {
+    const float* dscale;
+    fp8* out8;
+    unsigned* amax;
+};
+static_assert(CVAE_AMAX_SLOTS == 64, "amax_publish spreads over 64 slots");
+
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = false, int TS = 1, int XB = 1>
 __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                   const TO* __restrict__ mask, TO* __restrict__ out, ConvGeom g, int act,
-                                                                  float* __restrict__ ws, int ksplit, float acc_scale, float out_scale) {
+                                                                  float* __restrict__ ws, int ksplit, float acc_scale, float out_scale, F8Side f8) {
+    constexpr bool F8 = IsF8<T>::value;
+    static_assert(!F8 || sizeof(TO) <= 2, "fp8 products leave as bf16 or as fp8 codes");
     static_assert(TS == 1 || (TS == 2 && BD && MI % 2 == 0), "the K split needs the per-wave weight fetch and an even number of M sub-tiles");
     constexpr int NT = WM * WN * TS * 64;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -242,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     const int wm = wv / WN, wn = wv % WN;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z * XB;
-    const int Cin = UP ? g.Cs : g.Cl, Cout = UP ? g.Cl : g.Cs;
+    const int Cin = (UP ? g.Cs : g.Cl) / (F8 ? 2 : 1), Cout = UP ? g.Cl : g.Cs;      // fp8: input channels counted in 2-channel elements
     const int nblocks = Cout / BN;
     constexpr int NPAR = UP ? (ND == 3 ? 8 : 4) : 1;
     // blockIdx.y = (ks * NPAR + par) * nblocks + nb; par: output parity class (UP only); ks: split-K slice of the channel chunks
@@ -347,6 +402,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     // 16-channel half of the stage — a constant offset of this wave's LDS and weight base addresses.
     constexpr int STEPS = NG * 4 * KH / TS, GS = STEPS >= 64 ? CVAE_BD_GS : (STEPS >= 16 ? (MI >= 4 ? 4 : 8) : STEPS / 2), NGRP = STEPS / GS;      // MI = 4: a step is 4 MFMAs, 4 steps are as long as 8
     static_assert(!BD || (NGRP % 2 == 0 && GS * NGRP == STEPS && (GS * TS) % KH == 0), "BD walks the groups in pairs");
+    static_assert(!(BD && F8) || GS % 2 == 0, "fp8 pairs the k-steps of a weight group");
     static_assert(TS == 1 || KH <= 2, "K split: one or two k-steps per stage");
     const long long w_tap = (long long)nch16 * Cout * 16;     // elements between two taps of the packed panels
     const long long w_ts = (TS == 1) ? 0 : (KH == 2 ? (long long)ts * Cout * 16 : (UP ? -2 * ts * w_tap : ts * w_tap));
@@ -361,20 +417,6 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
             const int wt = tap_weight_idx(tj >> 2, tj & 3);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) lds_load(q[i][ni], (const char*)(wl + ((size_t)(wt * nch16 + chunk * KH + kk) * Cout + ni * 32) * 16));
-        }
-    };
-    auto compute_q = [&](const Frag<T> (&q)[BD ? GS : 1][NI], int gidx) {
-#pragma unroll
-        for (int i = 0; i < GS; ++i) {
-            const int kk = (i * TS) % KH, tj = gidx * (GS * TS / KH) + (i * TS) / KH;
-            const int toff = tap_halo_off(tj >> 2, tj & 3);
-            Frag<T> a[MI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo_a + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], q[i][ni], a[mi]);
         }
     };
     STAMP(1);
@@ -424,7 +466,8 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     auto bd_pair = [&](int chunk, int gp) {
         constexpr int NS = 2 * GS, APW = (MI >= 4) ? 2 : CVAE_APIPE, APD = APW < NS ? APW : NS - 1;      // MI = 4: 4 reads per step, 2 steps ahead is as many in flight
         load_q(qb, chunk, gp + 1);
-        Frag<T> ar[APD + 1][MI];
+        constexpr int RING = APD + 1 + (F8 ? 1 : 0);       // fp8: step i - 1 must outlive the read-ahead issued in front of step i (the pair shares one MFMA)
+        Frag<T> ar[RING][MI];
         auto lda = [&](int slot, int i) {
             const int gidx = gp + i / GS, ii = i % GS;
             const int kk = (ii * TS) % KH, tj = gidx * (GS * TS / KH) + (ii * TS) / KH;
@@ -436,16 +479,24 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
         for (int d = 0; d < APD; ++d) lda(d, d);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            if (i + APD < NS) lda((i + APD) % (APD + 1), i + APD);
+            if (i + APD < NS) lda((i + APD) % RING, i + APD);
             if (i == GS) {
                 const bool wrap = gp + 2 >= NGRP;
                 if (!wrap || chunk + 1 < (ks + 1) * chunk_per) load_q(qa, wrap ? chunk + 1 : chunk, wrap ? 0 : gp + 2);
             }
             __builtin_amdgcn_sched_barrier(0);             // keep the reads where they are written: the scheduler would sink them back to their uses
+            if constexpr (!F8) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], (i < GS ? qa[i % GS] : qb[i % GS])[ni], ar[i % (APD + 1)][mi]);
+                    for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], (i < GS ? qa[i % GS] : qb[i % GS])[ni], ar[i % RING][mi]);
+            } else if (i & 1) {                            // k-steps i - 1 and i: one K = 64 instruction (GS is even: both weights are in the same group)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        mma2(acc[mi][ni], (i < GS ? qa[(i - 1) % GS] : qb[(i - 1) % GS])[ni], (i < GS ? qa[i % GS] : qb[i % GS])[ni], ar[(i - 1) % RING][mi], ar[i % RING][mi]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -491,6 +542,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
             // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
             // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
             auto taps = [&](int grp, const char* btb) {
+                  if constexpr (!F8) {
     #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int toff = tap_halo_off(grp, j);
@@ -507,6 +559,25 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
                             for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
                     }
                 }
+              } else {
+    #pragma unroll
+                for (int sp = 0; sp < 4 * KH; sp += 2) {   // k-steps (tap j, k-step kk) in pairs: fp8 feeds one K = 64 instruction per pair
+                    Frag<T> a[2][MI], bf[2][NI];
+    #pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = (sp + u) / KH, kk = (sp + u) % KH;
+                        const int toff = tap_halo_off(grp, j);
+    #pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) lds_load(a[u][mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
+    #pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) lds_load(bf[u][ni], btb + (((j * KH + kk) * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
+                    }
+    #pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) mma2(acc[mi][ni], bf[0][ni], bf[1][ni], a[0][mi], a[1][mi]);     // D = W^T x X^T: rows = channels (see epilogue)
+                }
+              }
             };
             Piece<T> pbA[BP], pbB[BP];
             if (NG > 1) load_b(pbA, chunk, 1);
@@ -534,6 +605,8 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     // two 8-channel pieces, each ONE 16-byte (bf16) store and ONE 16-byte mask load instead of eight 2-byte ones.
     // the exchange and the epilogue index the accumulators with ts: written once as a generic lambda and called with the wave's ts as a compile-time
     // constant (a run-time index would put the accumulator array in scratch memory)
+    float amx = 0.f;                                          // fp8 side channel: largest |result| this lane stored
+    const float accs = (F8 && f8.dscale) ? f8.dscale[0] : acc_scale, o8s = (F8 && f8.dscale) ? f8.dscale[1] : out_scale;
     auto finish = [&](auto TSV) {
         constexpr int tsc = decltype(TSV)::value, mi0c = tsc * MO;
         if constexpr (TS == 2) {
@@ -602,7 +675,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
                 const int c = n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float x = (sizeof(T) == 1 ? v[j][q] * acc_scale : v[j][q]) + bpre[ni][j][q];
+                    float x = (F8 ? v[j][q] * accs : v[j][q]) + bpre[ni][j][q];
                     if (EPI == 1) x = relu_f32(x);
                     else if (EPI == 2) x = apply_act(x, act);
                     v[j][q] = x;
@@ -614,13 +687,22 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
                     for (int q = 0; q < 8; ++q)
                         if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
                 }
+                if constexpr (F8) {
+                    if (f8.amax) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) amx = fmaxf(amx, fabsf(v[j][q]));
+                    }
+                    if (f8.out8) *(uint2*)(f8.out8 + pidx + c) = pack8_fp8(v[j], o8s);
+                }
                 if constexpr (sizeof(TO) == 2 && sizeof(T) == 2) {           // bf16: one v_cvt_pk_bf16_f32 per pair
                     *(uint4*)(out + pidx + c) = make_uint4(pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3]), pack2_bf16(v[j][4], v[j][5]), pack2_bf16(v[j][6], v[j][7]));
+                } else if constexpr (F8) {                                   // fp8 codes only (the inference chain between two fp8 layers)
+                    *(uint2*)(out + pidx + c) = pack8_fp8(v[j], o8s);
                 } else {
                     Piece<TO> op;
                     TO* ov = (TO*)&op;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(sizeof(T) == 1 ? v[j][q] * out_scale : v[j][q]);
+                    for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(v[j][q]);
                     piece_store<TO>(op, (char*)(out + pidx + c));
                 }
             }
@@ -632,6 +714,9 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     } else {
         finish(std::integral_constant<int, 0>{});
     }
+    if constexpr (F8) {
+        if (f8.amax && ksplit == 1) amax_publish(f8.amax, amx, blockIdx.x + blockIdx.y + wave);
+    }
 #ifdef CVAE_STAMP
     __builtin_amdgcn_s_waitcnt(0);                         // vmcnt(0): the stores have left the wave
     STAMP(27);
@@ -639,32 +724,40 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
 #endif
 }
 
-// out[p][c] = act(sum_ks ws[ks][p][c] + bias[c]) (* mask > 0): 8 channels per thread, 16-byte bf16 stores.
+// out[p][c] = act(acc_scale * sum_ks ws[ks][p][c] + bias[c]) (* mask > 0): 8 channels per thread, 16-byte bf16 stores.  acc_scale is 1 except behind an
+// fp8 product (x * 1.0f is exact: the other dtypes' bits do not change), whose side channel (second fp8 output, amax) is served here too.
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias, const T* __restrict__ mask,
-                                                                  T* __restrict__ out, int64_t total, int Cout, int ksplit, int act) {
+                                                                  T* __restrict__ out, int64_t total, int Cout, int ksplit, int act, float acc_scale, F8Side f8) {
     const int64_t i8 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (i8 >= total) return;
-    float v[8];
+    float amx = 0.f;
+    if (i8 < total) {
+        float v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = 0.f;
-    for (int k = 0; k < ksplit; ++k) {
-        const float4 a = *(const float4*)(ws + (size_t)k * total + i8), b = *(const float4*)(ws + (size_t)k * total + i8 + 4);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-    }
-    const int c = (int)(i8 % Cout);
-    Piece<T> mp, op;
-    if (mask) piece_load_raw<T>(mp, mask + i8);
-    const T* mv = (const T*)&mp;
-    T* ov = (T*)&op;
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        for (int k = 0; k < ksplit; ++k) {
+            const float4 a = *(const float4*)(ws + (size_t)k * total + i8), b = *(const float4*)(ws + (size_t)k * total + i8 + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        const float accs = f8.dscale ? f8.dscale[0] : acc_scale;
+        const int c = (int)(i8 % Cout);
+        Piece<T> mp, op;
+        if (mask) piece_load_raw<T>(mp, mask + i8);
+        const T* mv = (const T*)&mp;
+        T* ov = (T*)&op;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        float x = v[q] + (bias ? bias[c + q] : 0.f);
-        x = apply_act_t<EPI>(x, act);
-        if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
-        ov[q] = from_f32<T>(x);
+        for (int q = 0; q < 8; ++q) {
+            float x = v[q] * accs + (bias ? bias[c + q] : 0.f);
+            x = apply_act_t<EPI>(x, act);
+            if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
+            v[q] = x;
+            ov[q] = from_f32<T>(x);
+            amx = fmaxf(amx, fabsf(x));
+        }
+        piece_store<T>(op, (char*)(out + i8));
+        if (f8.out8) *(uint2*)(f8.out8 + i8) = pack8_fp8(v, f8.dscale ? f8.dscale[1] : 1.f);
     }
-    piece_store<T>(op, (char*)(out + i8));
+    if (f8.amax) amax_publish(f8.amax, amx, blockIdx.x + (threadIdx.x >> 6));
 }
 
 #ifndef CVAE_XPAIR
@@ -693,7 +786,7 @@ static int pick_ksplit(bool up, long long nwg, int nchunks) {
 
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = (CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2), int TS = 1, int XB = 1>
 int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
-                    size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f) {
+                    size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f, F8Side f8 = F8Side{nullptr, nullptr, nullptr}) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
     constexpr int ID = (ND == 3) ? (UP ? TL::TD + 1 : 2 * TL::TD + 2) : 1;
@@ -705,11 +798,11 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     constexpr size_t LDS = LDS_MAIN > LDS_X ? LDS_MAIN : LDS_X;
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
     const int md = UP ? ((ND == 3) ? (g.ld + 1) / 2 : 1) : g.sd, mh = UP ? (g.lh + 1) / 2 : g.sh, mw = UP ? (g.lw + 1) / 2 : g.sw;
-    if constexpr (CVAE_XPAIR && XB == 1 && UP && ND == 3 && (TS == 2 || sizeof(T) == 1)) {
+    if constexpr (CVAE_XPAIR && XB == 1 && UP && ND == 3 && (TS == 2 || IsF8<T>::value)) {
         // a layer at most half a tile wide, on a launch that fills the chip several times over (the decode sweep's 4^3 -> 8^3 layer): two samples per tile
         const long long wgs = (long long)((md + TL::TD - 1) / TL::TD) * ((mh + TL::TH - 1) / TL::TH) * ((UP ? g.Cl : g.Cs) / BN) * 8 * g.B;
         if (mw <= TL::TW / 2 && g.B >= 2 && wgs >= g_xpair_min_wgs)
-            return launch_data_epi<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, 2>(in, wp, bias, mask, out, g, act, workspace, workspace_bytes, stream, acc_scale, out_scale);
+            return launch_data_epi<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, 2>(in, wp, bias, mask, out, g, act, workspace, workspace_bytes, stream, acc_scale, out_scale, f8);
     }
     auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, XB>;
     static bool attr_set = false;
@@ -718,23 +811,23 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
         attr_set = true;
     }
     g.tiles_d = (md + TL::TD - 1) / TL::TD; g.tiles_h = (mh + TL::TH - 1) / TL::TH; g.tiles_w = (mw + TL::TW - 1) / TL::TW;
-    const int Cout = UP ? g.Cl : g.Cs, Cin = UP ? g.Cs : g.Cl;
+    const int Cout = UP ? g.Cl : g.Cs, Cin = (UP ? g.Cs : g.Cl) / (IsF8<T>::value ? 2 : 1);
     const int npar = UP ? ((ND == 3) ? 8 : 4) : 1;
     const long long tiles = (long long)g.tiles_d * g.tiles_h * g.tiles_w;
     long long gy = (long long)(Cout / BN) * npar;
     const int64_t total = (int64_t)g.B * (UP ? (int64_t)g.ld * g.lh * g.lw : (int64_t)g.sd * g.sh * g.sw) * Cout;
     int ksplit = pick_ksplit(UP, tiles * gy * g.B, Cin / (16 * KH));
     if (!workspace || workspace_bytes < (size_t)ksplit * total * sizeof(float)) ksplit = 1;     // no (or too small a) workspace: unsplit
-    if (sizeof(T) == 1) ksplit = 1;                          // fp8: forward `up` only, never split
+    if (IsF8<T>::value && sizeof(TO) != 2) ksplit = 1;       // the finish pass writes bf16
     gy *= ksplit;
     if (gy > 65535 || g.B > 65535) return CVAE_E_BADSHAPE;
     dim3 grid((unsigned)tiles, (unsigned)gy, (unsigned)((g.B + XB - 1) / XB));
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * TS * 64), LDS, stream, (const T*)in, (const T*)wp, bias, (const TO*)mask, (TO*)out, g, act, (float*)workspace, ksplit,
-                       acc_scale, out_scale);
+                       acc_scale, out_scale, f8);
     CVAE_CHECK_LAUNCH();
-    if constexpr (sizeof(T) != 1) if (ksplit > 1) {
-        hipLaunchKernelGGL((conv_splitk_finish_kernel<T, EPI>), dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, bias,
-                           (const T*)mask, (T*)out, total, Cout, ksplit, act);
+    if constexpr (sizeof(TO) != 1) if (ksplit > 1) {
+        hipLaunchKernelGGL((conv_splitk_finish_kernel<TO, EPI>), dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, bias,
+                           (const TO*)mask, (TO*)out, total, Cout, ksplit, act, IsF8<T>::value ? acc_scale : 1.f, f8);
         CVAE_CHECK_LAUNCH();
     }
     return CVAE_OK;
@@ -1085,18 +1178,102 @@ int try_up_full(const void* in, const void* wp, const float* bias, const void* m
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing
-template <typename T>
+// CH: input channels per panel chunk — 16 (bf16 / fp32: one MFMA k-step) or 32 (fp8: the f8x2 element is two channels, so a chunk of 16
+// elements is 32 channels; see Frag<f8x2>)
+template <typename T, int CH = 16>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cs, int Cl, int taps, int for_up, float mul = 1.f) {
     const int64_t n = (int64_t)Cs * Cl * taps;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         // i enumerates the OUTPUT so writes are contiguous
-        const int e = (int)(i & 15);
-        int64_t rr = i >> 4;
+        const int e = (int)(i % CH);
+        int64_t rr = i / CH;
         int cs, cl, tap;
-        if (!for_up) { cs = (int)(rr % Cs); rr /= Cs; const int ch = (int)(rr % (Cl / 16)); tap = (int)(rr / (Cl / 16)); cl = ch * 16 + e; }
-        else { cl = (int)(rr % Cl); rr /= Cl; const int ch = (int)(rr % (Cs / 16)); tap = (int)(rr / (Cs / 16)); cs = ch * 16 + e; }
+        if (!for_up) { cs = (int)(rr % Cs); rr /= Cs; const int ch = (int)(rr % (Cl / CH)); tap = (int)(rr / (Cl / CH)); cl = ch * CH + e; }
+        else { cl = (int)(rr % Cl); rr /= Cl; const int ch = (int)(rr % (Cs / CH)); tap = (int)(rr / (Cs / CH)); cs = ch * CH + e; }
         out[i] = from_f32<T>(sizeof(T) == 1 ? w[((int64_t)cs * Cl + cl) * taps + tap] * mul : w[((int64_t)cs * Cl + cl) * taps + tap]);
     }
+}
+
+// fp8 panels of several layers in one launch, scales read from DEVICE memory (a captured training step re-reads them on every replay), and the
+// largest |w| of every layer recorded for the next step's scale (delayed scaling: cvae_fp8_scale_update).
+#define F8PACK_MAX 12
+struct F8PackTable {
+    const float* w[F8PACK_MAX];
+    fp8* out[F8PACK_MAX];
+    const float* inv_scale[F8PACK_MAX];      // device: 1 / s_w
+    unsigned* amax[F8PACK_MAX];              // device: CVAE_AMAX_SLOTS words, or null
+    int Cs[F8PACK_MAX], Cl[F8PACK_MAX], for_up[F8PACK_MAX], blk_start[F8PACK_MAX + 1];
+    int count, taps;
+};
+__global__ __launch_bounds__(256) void pack_weight_fp8_multi_kernel(F8PackTable tb) {
+    constexpr int CH = 32;
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.blk_start[ti + 1]) ++ti;
+    const int Cs = tb.Cs[ti], Cl = tb.Cl[ti], taps = tb.taps, for_up = tb.for_up[ti];
+    const float* w = tb.w[ti];
+    fp8* out = tb.out[ti];
+    const float mul = tb.inv_scale[ti][0];
+    const int64_t n = (int64_t)Cs * Cl * taps;
+    const int nb = tb.blk_start[ti + 1] - tb.blk_start[ti];
+    float amx = 0.f;
+    for (int64_t i = (((int64_t)blockIdx.x - tb.blk_start[ti]) * 256 + threadIdx.x) * 4; i < n; i += (int64_t)nb * 1024) {      // 4 consecutive codes per thread: one dword store
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t iu = i + u;
+            const int e = (int)(iu % CH);
+            int64_t rr = iu / CH;
+            int cs, cl, tap;
+            if (!for_up) { cs = (int)(rr % Cs); rr /= Cs; const int ch = (int)(rr % (Cl / CH)); tap = (int)(rr / (Cl / CH)); cl = ch * CH + e; }
+            else { cl = (int)(rr % Cl); rr /= Cl; const int ch = (int)(rr % (Cs / CH)); tap = (int)(rr / (Cs / CH)); cs = ch * CH + e; }
+            v[u] = w[((int64_t)cs * Cl + cl) * taps + tap];
+            amx = fmaxf(amx, fabsf(v[u]));
+            v[u] = __builtin_amdgcn_fmed3f(v[u] * mul, -CVAE_FP8_MAX, CVAE_FP8_MAX);
+        }
+        int c = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        c = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], c, true);
+        *(int*)(out + i) = c;
+    }
+    if (tb.amax[ti]) amax_publish(tb.amax[ti], amx, blockIdx.x + (threadIdx.x >> 6));
+}
+
+// Delayed scaling, once per step: every tracked tensor i gets scale[i] = headroom * amax_i / 448 from the largest value recorded since the last
+// call (its slots are cleared; a tensor that recorded nothing keeps its scale), then every fp8 layer l its pair {s_in * s_w, 1 / s_out}.
+#define F8LAYER_MAX 16
+struct F8LayerIdx { int in[F8LAYER_MAX], w[F8LAYER_MAX], out[F8LAYER_MAX]; int count; };
+__global__ __launch_bounds__(64) void fp8_scale_update_kernel(unsigned* __restrict__ amax, float* __restrict__ scale, float* __restrict__ inv_scale, int n, float headroom,
+                                                              F8LayerIdx li, float* __restrict__ dscale) {
+    __shared__ float sh[64];
+    const int lane = threadIdx.x;
+    for (int i = 0; i < n; ++i) {
+        unsigned* sl = amax + (size_t)i * CVAE_AMAX_SLOTS;
+        float a = __uint_as_float(sl[lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+        sl[lane] = 0u;
+        if (lane == 0) {
+            float s = scale[i];
+            if (a > 0.f) {
+                s = headroom * a / CVAE_FP8_MAX;
+                scale[i] = s;
+                inv_scale[i] = 1.f / s;
+            }
+            sh[i] = s;
+        }
+    }
+    __syncthreads();
+    if (lane < li.count) {
+        dscale[2 * lane] = sh[li.in[lane]] * sh[li.w[lane]];
+        dscale[2 * lane + 1] = li.out[lane] >= 0 ? 1.f / sh[li.out[lane]] : 0.f;
+    }
+}
+
+// max |x| of a tensor into CVAE_AMAX_SLOTS words (calibration of the first step's scales; the training step records its amax in the producers' epilogues)
+__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ src, int dtype, int64_t n, unsigned* __restrict__ slots) {
+    float amx = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        amx = fmaxf(amx, fabsf(dtype == CVAE_BF16 ? to_f32(((const bf16*)src)[i]) : ((const float*)src)[i]));
+    amax_publish(slots, amx, blockIdx.x + (threadIdx.x >> 6));
 }
 
 // All conv weights of a model packed in ONE launch (the table rides in the kernel arguments): the per-step re-pack of the
@@ -1913,57 +2090,147 @@ extern "C" int cvae_conv_wgrad_multi(int count, const void* const* S, const void
     return nd == 3 ? wgrad_multi_t<float, 3>(count, S, L, dW, dbias, dbias_side, workspace, dims, st) : wgrad_multi_t<float, 2>(count, S, L, dW, dbias, dbias_side, workspace, dims, st);
 }
 
-// ---------------------------------------------------------------------------------------------- fp8 (e4m3) inference path
-// The decoder-only counterfactual sweep (BASELINE.json configs[4]) decodes hundreds of stacked rows with frozen weights:
-// the ConvTranspose layers with C_in >= 32 and C_out > 1 run with fp8 operands (per-tensor scales from a calibration pass, fp32
-// accumulate) on v_mfma_f32_32x32x16_fp8_fp8 — the bf16 instruction's shape and rate, half the LDS / L2 bytes per operand, which is what
-// bounds these kernels.  Same tiles, same halo staging, same epilogue as the bf16 kernel (conv_data_kernel<fp8, .., TO>).
-__global__ void quantize_fp8_kernel(const void* __restrict__ src, int src_dtype, fp8* __restrict__ dst, int64_t n, float inv_scale) {
+// ---------------------------------------------------------------------------------------------- fp8 (e4m3) products
+// BASELINE.json configs[4].  Conv / ConvTranspose products with C_in >= 32 and C_out > 1 on fp8 operands with per-tensor scales and fp32
+// accumulation, on the block-scaled CDNA4 MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (K = 64 per instruction, twice the
+// bf16 FLOPs per clock).  conv_data_kernel<f8x2, ..>: the bf16 kernel's tiles, staging and epilogue on half the operand bytes (see Frag<f8x2>).
+//   * inference (the counterfactual decode sweep): static scales from a calibration pass, fp8 codes travel between fp8 layers;
+//   * training forward (the step of causal_cascade/train.py:19-39 with fp8 conv inputs): scales live on the device and follow the tensors with
+//     one step of delay (cvae_fp8_scale_update), every producer leaves its result twice — bf16 for the backward pass, fp8 for the next layer —
+//     and records its amax; the backward pass runs the bf16 kernels on the bf16 copies.
+__global__ void quantize_fp8_kernel(const void* __restrict__ src, int src_dtype, fp8* __restrict__ dst, int64_t n, float inv_scale, const float* __restrict__ inv_scale_dev,
+                                    unsigned* __restrict__ amax) {
+    const float mul = inv_scale_dev ? inv_scale_dev[0] : inv_scale;
+    float amx = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = src_dtype == CVAE_BF16 ? to_f32(((const bf16*)src)[i]) : ((const float*)src)[i];
-        dst[i] = from_f32<fp8>(v * inv_scale);
+        amx = fmaxf(amx, fabsf(v));
+        dst[i] = from_f32<fp8>(v * mul);
     }
+    if (amax) amax_publish(amax, amx, blockIdx.x + (threadIdx.x >> 6));
 }
 extern "C" int cvae_quantize_fp8(const void* src, int src_dtype, void* dst, int64_t n, float inv_scale, void* stream) {
     if (n < 0 || !(inv_scale > 0.f)) return CVAE_E_BADSHAPE;
     if (src_dtype != CVAE_F32 && src_dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (n == 0) return CVAE_OK;
     if (!src || !dst) return CVAE_E_NULLPTR;
-    hipLaunchKernelGGL(quantize_fp8_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, (fp8*)dst, n, inv_scale);
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, (fp8*)dst, n, inv_scale, (const float*)nullptr, (unsigned*)nullptr);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
+extern "C" int cvae_quantize_fp8_dev(const void* src, int src_dtype, void* dst, int64_t n, const float* inv_scale_dev, void* amax_slots, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (src_dtype != CVAE_F32 && src_dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (n == 0) return CVAE_OK;
+    if (!src || !dst || !inv_scale_dev) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, (fp8*)dst, n, 1.f, inv_scale_dev, (unsigned*)amax_slots);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+extern "C" int cvae_absmax(const void* src, int dtype, int64_t n, void* amax_slots, void* stream) {
+    if (n < 0) return CVAE_E_BADSHAPE;
+    if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (n == 0) return CVAE_OK;
+    if (!src || !amax_slots) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(absmax_kernel, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dtype, n, (unsigned*)amax_slots);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+static bool fp8_pack_ok(int64_t Cs, int64_t Cl, int for_up) { return for_up ? (Cs % 32 == 0 && Cl % 32 == 0 && Cl > 1) : (Cl % 32 == 0 && Cs % 64 == 0); }
 extern "C" int cvae_conv_pack_weight_fp8(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, float inv_scale, void* stream) {
     if ((nd != 2 && nd != 3) || Cs <= 0 || Cl <= 0 || !(inv_scale > 0.f)) return CVAE_E_BADSHAPE;
-    if ((!for_up && Cl % 16) || (for_up && (Cs % 16 || Cl % 32))) return CVAE_E_UNSUPPORTED;      // what cvae_conv_up_fp8 accepts
+    if (!fp8_pack_ok(Cs, Cl, for_up)) return CVAE_E_UNSUPPORTED;      // what cvae_conv_fp8 accepts
     if (!w || !packed) return CVAE_E_NULLPTR;
     const int taps = (nd == 3) ? 64 : 16;
     const int64_t n = Cs * Cl * taps;
-    hipLaunchKernelGGL(pack_weight_kernel<fp8>, dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (fp8*)packed, (int)Cs, (int)Cl, taps, for_up, inv_scale);
+    hipLaunchKernelGGL((pack_weight_kernel<fp8, 32>), dim3(cvae_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (fp8*)packed, (int)Cs, (int)Cl, taps, for_up, inv_scale);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
-template <int ND, typename TO>
-static int conv_up_fp8_t(const void* S, const void* w, const float* bias, void* L, ConvGeom g, int act, float acc_scale, float out_scale, hipStream_t st) {
-    const bool wide = (g.Cl % 64) == 0;
-#define UPF8(WM, WN, EPI) launch_data_epi<fp8, ND, true, WM, WN, 2, 1, EPI, 1, TO>(S, w, bias, nullptr, L, g, act, nullptr, 0, st, acc_scale, out_scale)
-    if (wide) { if (act == CVAE_ACT_NONE) return UPF8(2, 2, 0); if (act == CVAE_ACT_RELU) return UPF8(2, 2, 1); return UPF8(2, 2, 2); }
-    if (act == CVAE_ACT_NONE) return UPF8(4, 1, 0);
-    if (act == CVAE_ACT_RELU) return UPF8(4, 1, 1);
-    return UPF8(4, 1, 2);
-#undef UPF8
+extern "C" int cvae_conv_pack_weights_fp8(const float* const* w, void* const* packed, const int64_t* Cs, const int64_t* Cl, const int* for_up,
+                                           const float* const* inv_scale_dev, void* const* amax_slots, int count, int nd, void* stream) {
+    if ((nd != 2 && nd != 3) || count < 0 || count > F8PACK_MAX) return CVAE_E_BADSHAPE;
+    if (count == 0) return CVAE_OK;
+    if (!w || !packed || !Cs || !Cl || !for_up || !inv_scale_dev) return CVAE_E_NULLPTR;
+    F8PackTable tb;
+    tb.taps = (nd == 3) ? 64 : 16;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (Cs[i] <= 0 || Cl[i] <= 0) return CVAE_E_BADSHAPE;
+        if (!fp8_pack_ok(Cs[i], Cl[i], for_up[i])) return CVAE_E_UNSUPPORTED;
+        if (!w[i] || !packed[i] || !inv_scale_dev[i]) return CVAE_E_NULLPTR;
+        tb.w[i] = w[i]; tb.out[i] = (fp8*)packed[i]; tb.inv_scale[i] = inv_scale_dev[i]; tb.amax[i] = amax_slots ? (unsigned*)amax_slots[i] : nullptr;
+        tb.Cs[i] = (int)Cs[i]; tb.Cl[i] = (int)Cl[i]; tb.for_up[i] = for_up[i];
+        tb.blk_start[i] = blocks;
+        int64_t nb = (Cs[i] * Cl[i] * tb.taps + 4095) / 4096;
+        if (nb > 1024) nb = 1024;
+        blocks += (int)nb;
+    }
+    tb.blk_start[count] = blocks;
+    tb.count = count;
+    hipLaunchKernelGGL(pack_weight_fp8_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
 }
+extern "C" int cvae_fp8_scale_update(void* amax_slots, float* scale, float* inv_scale, int n, float headroom, const int* layer_in, const int* layer_w, const int* layer_out,
+                                     int n_layers, float* dscale, void* stream) {
+    if (n < 0 || n > 64 || n_layers < 0 || n_layers > F8LAYER_MAX || !(headroom > 0.f)) return CVAE_E_BADSHAPE;
+    if (n == 0) return CVAE_OK;
+    if (!amax_slots || !scale || !inv_scale || (n_layers && (!layer_in || !layer_w || !layer_out || !dscale))) return CVAE_E_NULLPTR;
+    F8LayerIdx li;
+    li.count = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        if (layer_in[l] < 0 || layer_in[l] >= n || layer_w[l] < 0 || layer_w[l] >= n || layer_out[l] >= n) return CVAE_E_BADSHAPE;
+        li.in[l] = layer_in[l]; li.w[l] = layer_w[l]; li.out[l] = layer_out[l];
+    }
+    hipLaunchKernelGGL(fp8_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned*)amax_slots, scale, inv_scale, n, headroom, li, dscale);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// One fp8 product.  up = 0: S = conv(L) ("down"), up = 1: L = convT(S).  out_dtype CVAE_BF16 (bf16 result; `out8` may ask for a second copy as fp8
+// codes) or CVAE_FP8 (codes only).  Scales: by value (acc_scale = s_in * s_w, out8_inv_scale = 1 / s_out8), or, when `dscale` is not null,
+// read from the device pair {acc_scale, out8_inv_scale} at run time.
+template <int ND, bool UP, typename TO>
+static int conv_fp8_t(const void* in, const void* w, const float* bias, void* out, ConvGeom g, int act, float acc_scale, float out_scale, F8Side f8, void* ws, size_t wsb, hipStream_t st) {
+    const int Cout = UP ? g.Cl : g.Cs;
+    const bool wide = (Cout % 64) == 0;
+    // the bf16 launches' tile shapes: 64-channel tiles as (K split) x (N sub-tile) waves with the per-wave weight fetch, 32-channel tiles as 4 x 1 waves on LDS panels
+#define F8L(WM, WN, MI, TS, EPI) launch_data_epi<f8x2, ND, UP, WM, WN, MI, 1, EPI, 1, TO, (CVAE_BDIRECT && WM <= 2), TS>(in, w, bias, nullptr, out, g, act, ws, wsb, st, acc_scale, out_scale, f8)
+#define F8E(WM, WN, MI, TS) (act == CVAE_ACT_NONE ? F8L(WM, WN, MI, TS, 0) : (act == CVAE_ACT_RELU ? F8L(WM, WN, MI, TS, 1) : F8L(WM, WN, MI, TS, 2)))
+    if (wide) {
+        if constexpr (ND == 3) return F8E(1, 2, 4, 2);
+        else return F8E(2, 2, 2, 1);
+    }
+    if constexpr (UP) return F8E(4, 1, 2, 1);
+    else return CVAE_E_UNSUPPORTED;
+#undef F8E
+#undef F8L
+}
+extern "C" int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, void* out, int out_dtype, void* out8, const float* dscale, float acc_scale,
+                             float out8_inv_scale, void* amax_slots, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl,
+                             int nd, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || (up != 0 && up != 1)) return CVAE_E_BADSHAPE;
+    if (out_dtype != CVAE_FP8 && out_dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (!dscale && (!(acc_scale > 0.f) || ((out_dtype == CVAE_FP8 || out8) && !(out8_inv_scale > 0.f)))) return CVAE_E_BADSHAPE;
+    if (out_dtype == CVAE_FP8 && out8) return CVAE_E_BADSHAPE;        // codes-only output: there is no second copy to ask for
+    if (B == 0) return CVAE_OK;
+    if (!in8 || !w8 || !out) return CVAE_E_NULLPTR;
+    if (!fp8_pack_ok(Cs, Cl, up)) return CVAE_E_UNSUPPORTED;
+    if (up ? (lh != 2 * sh || lw != 2 * sw || (nd == 3 && ld != 2 * sd)) : false) return CVAE_E_UNSUPPORTED;   // forward products only: exact 2x extents
+    GEOM_INIT();
+    hipStream_t st = (hipStream_t)stream;
+    const F8Side f8{dscale, (fp8*)out8, (unsigned*)amax_slots};
+#define F8D(ND_, UP_) (out_dtype == CVAE_FP8 ? conv_fp8_t<ND_, UP_, fp8>(in8, w8, bias, out, g, act, acc_scale, out8_inv_scale, f8, nullptr, 0, st) \
+                                             : conv_fp8_t<ND_, UP_, bf16>(in8, w8, bias, out, g, act, acc_scale, out8_inv_scale, f8, workspace, workspace_bytes, st))
+    if (nd == 3) return up ? F8D(3, true) : F8D(3, false);
+    return up ? F8D(2, true) : F8D(2, false);
+#undef F8D
+}
+// the inference entry point of round 2, kept: static scales by value, result as bf16 or as codes
 extern "C" int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
                                 int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                                 void* stream) {
-    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || !(acc_scale > 0.f)) return CVAE_E_BADSHAPE;
-    if (out_dtype != CVAE_FP8 && out_dtype != CVAE_BF16) return CVAE_E_DTYPE;
-    if (out_dtype == CVAE_FP8 && !(out_inv_scale > 0.f)) return CVAE_E_BADSHAPE;
-    if (B == 0) return CVAE_OK;
-    if (!S || !w || !L) return CVAE_E_NULLPTR;
-    if (Cl == 1 || Cs % 16 || Cl % 32) return CVAE_E_UNSUPPORTED;
-    GEOM_INIT();
-    hipStream_t st = (hipStream_t)stream;
-    if (out_dtype == CVAE_FP8) return nd == 3 ? conv_up_fp8_t<3, fp8>(S, w, bias, L, g, act, acc_scale, out_inv_scale, st) : conv_up_fp8_t<2, fp8>(S, w, bias, L, g, act, acc_scale, out_inv_scale, st);
-    return nd == 3 ? conv_up_fp8_t<3, bf16>(S, w, bias, L, g, act, acc_scale, 1.f, st) : conv_up_fp8_t<2, bf16>(S, w, bias, L, g, act, acc_scale, 1.f, st);
+    return cvae_conv_fp8(1, S, w, bias, L, out_dtype, nullptr, nullptr, acc_scale, out_dtype == CVAE_FP8 ? out_inv_scale : 1.f, nullptr, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, act,
+                         nullptr, 0, stream);
 }

@@ -639,18 +639,102 @@ def pack_weight_fp8(w, nd, for_up, scale):
 def conv_up_fp8(Sq, wq, bias, Cl, nd, act, acc_scale, out_scale=None):
     """nn.ConvTranspose{2,3}d(k4, s2, p1) + bias + activation on fp8 operands (forward only).  Sq: uint8 codes [B, sd, sh, sw, Cs]; result bf16
     (out_scale None) or fp8 codes of result / out_scale."""
-    L.require_gpu(Sq)
-    B, sd, sh, sw, Cs = _cl_dims(Sq)
-    if Sq.dtype != torch.uint8 or wq.dtype != torch.uint8:
-        raise L.CvaeError("conv_up_fp8: activations and weight panels must be fp8 codes (uint8 tensors from quantize_fp8 / pack_weight_fp8)")
-    if wq.numel() != Cs * Cl * 4 ** nd:
-        raise L.CvaeError(f"conv_up_fp8: weight panels hold {wq.numel()} codes, expected Cs * Cl * 4^nd = {Cs * Cl * 4 ** nd}")
-    Sq = Sq.contiguous()
-    ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
-    Lt = torch.empty((B, ld, lh, lw, Cl), dtype=torch.bfloat16 if out_scale is None else torch.uint8, device=Sq.device)
-    check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up_fp8, ptr(Sq), ptr(wq), ptr(bias), ptr(Lt), L.BF16 if out_scale is None else L.FP8,
-                  float(acc_scale), 0.0 if out_scale is None else 1.0 / float(out_scale), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.act_code(act), stream()), "conv_up_fp8")
-    return Lt
+    return conv_fp8(True, Sq, wq, bias, Cl, nd, act, acc_scale=acc_scale, out8_scale=out_scale, codes_only=out_scale is not None)
+
+
+AMAX_SLOTS = 64          # CVAE_AMAX_SLOTS
+
+
+def conv_fp8(up, xq, wq, bias, Cout, nd, act, acc_scale=None, out8_scale=None, codes_only=False, dscale=None, want_out8=False, amax=None):
+    """One fp8 (e4m3) product on the block-scaled MFMA (cvae_conv_fp8; forward only).  up False: nn.Conv (k4, s2, p1) of xq [B, ld, lh, lw, Cin];
+    up True: nn.ConvTranspose of xq [B, sd, sh, sw, Cin].  xq, wq: uint8 codes (quantize_fp8 / pack_weight_fp8 panels).
+    Scales by value (acc_scale = s_x * s_w; out8_scale = the scale of the fp8 copy of the result) or on the device (dscale: float32 tensor
+    {acc_scale, 1 / out8_scale}, re-read by every launch — the training step's delayed scaling).
+    Returns the bf16 result; with codes_only the fp8 codes instead; with want_out8 (or out8_scale and not codes_only) the pair (bf16, codes).
+    amax: optional uint32 tensor of AMAX_SLOTS words that records max |result|."""
+    L.require_gpu(xq)
+    if xq.dtype != torch.uint8 or wq.dtype != torch.uint8:
+        raise L.CvaeError("conv_fp8: activations and weight panels must be fp8 codes (uint8 tensors from quantize_fp8 / pack_weight_fp8)")
+    xq = xq.contiguous()
+    B, d, h, w_, Cin = _cl_dims(xq)
+    if wq.numel() != Cin * Cout * 4 ** nd:
+        raise L.CvaeError(f"conv_fp8: weight panels hold {wq.numel()} codes, expected Cin * Cout * 4^nd = {Cin * Cout * 4 ** nd}")
+    if up:
+        sd, sh, sw, Cs, Cl = d, h, w_, Cin, Cout
+        ld, lh, lw = (2 * sd if nd == 3 else 1), 2 * sh, 2 * sw
+        oshape = (B, ld, lh, lw, Cl)
+    else:
+        ld, lh, lw, Cl, Cs = d, h, w_, Cin, Cout
+        sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
+        oshape = (B, sd, sh, sw, Cs)
+    if dscale is None and acc_scale is None:
+        raise L.CvaeError("conv_fp8: give acc_scale (by value) or dscale (device pair)")
+    pair = (want_out8 or out8_scale is not None) and not codes_only
+    out = torch.empty(oshape, dtype=torch.uint8 if codes_only else torch.bfloat16, device=xq.device)
+    out8 = torch.empty(oshape, dtype=torch.uint8, device=xq.device) if pair else None
+    ws, nbytes = (None, 0) if codes_only else _conv_data_workspace(xq.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, int(bool(up)))
+    label = (f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}" if up else f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}")
+    check(L.timed(label, lib.cvae_conv_fp8, int(bool(up)), ptr(xq), ptr(wq), ptr(bias), ptr(out), L.FP8 if codes_only else L.BF16, ptr(out8), ptr(dscale),
+                  float(acc_scale if acc_scale is not None else 1.0), (1.0 / float(out8_scale)) if out8_scale is not None else 1.0, ptr(amax),
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.act_code(act), ptr(ws), nbytes, stream()), "conv_fp8")
+    return (out, out8) if pair else out
+
+
+def absmax(x, slots):
+    """Record max |x| in `slots` (AMAX_SLOTS uint32 / int32 words of float bits; atomicMax — accumulates over calls until cleared)."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    check(lib.cvae_absmax(ptr(x), L.dtype_code(x.dtype), x.numel(), ptr(slots), stream()), "absmax")
+
+
+def quantize_fp8_dev(x, inv_scale_dev, amax=None):
+    """quantize_fp8 with 1 / scale read from a device float (one-element tensor); optionally records max |x|."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib.cvae_quantize_fp8_dev(ptr(x), L.dtype_code(x.dtype), ptr(q), x.numel(), ptr(inv_scale_dev), ptr(amax), stream()), "quantize_fp8_dev")
+    return q
+
+
+def pack_weights_fp8(weights, nd, for_up, inv_scale_devs, amaxes=None, outs=None):
+    """fp8 operand panels of several conv weights in one launch (cvae_conv_pack_weights_fp8): 1 / s_w of each from device memory, max |w| recorded.
+    outs: optional preallocated uint8 tensors (a captured step reuses them)."""
+    k = len(weights)
+    ws = [w.contiguous() for w in weights]
+    if outs is None:
+        outs = [torch.empty(w.numel(), dtype=torch.uint8, device=w.device) for w in ws]
+    if k:
+        vp = lambda ts: (C_.c_void_p * k)(*[(t.data_ptr() if t is not None else None) for t in ts])
+        check(lib.cvae_conv_pack_weights_fp8(vp(ws), vp(outs), (C_.c_int64 * k)(*[w.shape[0] for w in ws]), (C_.c_int64 * k)(*[w.shape[1] for w in ws]),
+                                             (C_.c_int * k)(*[int(bool(f)) for f in for_up]), vp(inv_scale_devs), vp(amaxes if amaxes is not None else [None] * k),
+                                             k, nd, stream()), "conv_pack_weights_fp8")
+    return outs
+
+
+class Fp8Scales:
+    """Device-resident delayed scaling for the fp8 forward of a training step: `n` tracked tensors (activations and weights), each with an amax
+    record, a scale and its reciprocal; `layers` = [(input tensor, weight tensor, output tensor or -1)] per fp8 product, whose {s_in * s_w, 1 / s_out}
+    pairs land in `dscale[l]`.  update() (one tiny launch, capturable) turns the amaxes recorded since the last call into the scales of the next
+    step: scale = headroom * amax / 448 — e4m3 is a floating-point format, so headroom costs no precision until the subnormals."""
+
+    def __init__(self, n, layers, device, headroom=2.0):
+        self.n, self.layers, self.headroom = int(n), [tuple(int(v) for v in l) for l in layers], float(headroom)
+        self.amax = torch.zeros(self.n, AMAX_SLOTS, dtype=torch.int32, device=device)
+        self.scale = torch.ones(self.n, dtype=torch.float32, device=device)
+        self.inv_scale = torch.ones(self.n, dtype=torch.float32, device=device)
+        self.dscale = torch.zeros(max(len(self.layers), 1), 2, dtype=torch.float32, device=device)
+        k = len(self.layers)
+        self._li = [(C_.c_int * max(k, 1))(*([l[j] for l in self.layers] or [0])) for j in range(3)]
+
+    def update(self):
+        check(lib.cvae_fp8_scale_update(ptr(self.amax), ptr(self.scale), ptr(self.inv_scale), self.n, self.headroom, self._li[0], self._li[1], self._li[2],
+                                        len(self.layers), ptr(self.dscale), stream()), "fp8_scale_update")
+
+    def state(self):
+        return {"scale": self.scale.detach().cpu().clone(), "amax": self.amax.detach().cpu().clone()}
+
+    def load_state(self, st):
+        self.scale.copy_(st["scale"]); self.inv_scale.copy_(1.0 / st["scale"].to(self.scale.device)); self.amax.copy_(st["amax"])
 
 
 class Activation(torch.autograd.Function):

@@ -51,7 +51,7 @@ extern "C" {
 
 #define CVAE_F32  0
 #define CVAE_BF16 1
-#define CVAE_FP8  2          /* OCP e4m3 with a per-tensor scale kept by the caller: inference-only entry points (cvae_conv_up_fp8 ...) */
+#define CVAE_FP8  2          /* OCP e4m3 codes with a per-tensor scale kept by the caller (cvae_conv_fp8 ...) */
 
 #define CVAE_ACT_NONE    0
 #define CVAE_ACT_RELU    1
@@ -117,19 +117,45 @@ int cvae_conv_down_image(const void* L, int l_dtype, const float* w, const float
                          int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, void* stream);
 int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                           int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, void* stream);
-/* ---- fp8 (OCP e4m3) inference path of the ConvTranspose layers: the batched counterfactual decode (BASELINE.json configs[4]; replaces the
- * per-value decode loop of vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:77-99) ----
- * A tensor x is held as fp8 codes q with a per-tensor scale s kept by the caller: x ~ s * q, s = amax(x) / 448 from a calibration pass.
- *   cvae_quantize_fp8          dst[i] = fp8(src[i] * inv_scale)               (src fp32 or bf16; saturating)
- *   cvae_conv_pack_weight_fp8  cvae_conv_pack_weight with fp8 codes fp8(w * inv_scale)
- *   cvae_conv_up_fp8           L = act(scatter(S_q, w_q) * acc_scale + bias) with acc_scale = s_S * s_w, fp32 accumulate on
- *                              v_mfma_f32_32x32x16_fp8_fp8; L written as bf16 (out_dtype CVAE_BF16) or as fp8 codes fp8(L * out_inv_scale)
- *                              (out_dtype CVAE_FP8) for the next fp8 layer.  Cs % 16 == 0, Cl % 32 == 0, Cl > 1; forward only. */
+/* ---- fp8 (OCP e4m3) products (BASELINE.json configs[4]): the batched counterfactual decode (replaces the per-value decode loop of
+ * vessel_analysis/04_generate_counterfactual/generate_counterfactual.py:77-99) and the forward convolutions of the train step
+ * (causal_cascade/train.py:19-39 with fp8 conv inputs; the backward pass stays bf16) ----
+ * A tensor x is held as fp8 codes q with a per-tensor scale s kept by the caller: x ~ s * q.  Products accumulate in fp32 on the block-scaled
+ * CDNA4 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales): twice the bf16 FLOPs per clock.  Channel counts: C_in % 32 == 0,
+ * C_out % 64 == 0 (conv) / C_out % 32 == 0, C_out > 1 (ConvTranspose).
+ *   cvae_quantize_fp8           dst[i] = fp8(src[i] * inv_scale)               (src fp32 or bf16; saturating)
+ *   cvae_quantize_fp8_dev       the same with 1 / s read from DEVICE memory; amax_slots (optional): records max |src| (see below)
+ *   cvae_absmax                 max |src| into amax_slots (calibration of the first step)
+ *   cvae_conv_pack_weight_fp8   fp32 [Cs][Cl][taps] -> operand panels [tap][C_in / 32][C_out][32] of fp8(w * inv_scale)
+ *   cvae_conv_pack_weights_fp8  the same for a list of layers in one launch, 1 / s_w read from device memory, max |w| recorded
+ *   cvae_conv_fp8               up = 0: S = act(conv(L_q, w_q) * acc_scale + bias); up = 1: L = act(scatter(S_q, w_q) * acc_scale + bias), acc_scale =
+ *                               s_in * s_w.  out_dtype CVAE_BF16: `out` bf16, and `out8` (optional) a second copy as codes fp8(out * out8_inv_scale) for
+ *                               the next fp8 layer; out_dtype CVAE_FP8: `out` holds the codes only.  dscale (optional, device): {acc_scale,
+ *                               out8_inv_scale} read at run time instead of the two by-value arguments (delayed scaling under graph replay).
+ *                               amax_slots (optional): records max |out|.  workspace: cvae_conv_data_workspace_bytes of the same geometry (split-K
+ *                               of the small `down` grids; NULL = unsplit).
+ *   cvae_conv_up_fp8            = cvae_conv_fp8(up = 1) with by-value scales and no side outputs (round-2 entry point, kept)
+ *   cvae_fp8_scale_update       once per step: for each of n tracked tensors, scale[i] = headroom * amax_i / 448 (amax_i = the largest value
+ *                               recorded in its CVAE_AMAX_SLOTS words since the last call; the words are cleared; nothing recorded = scale kept),
+ *                               inv_scale[i] = 1 / scale[i]; then for each fp8 layer l: dscale[2l] = scale[layer_in[l]] * scale[layer_w[l]],
+ *                               dscale[2l + 1] = 1 / scale[layer_out[l]] (0 when layer_out[l] < 0).  layer_* are HOST arrays.
+ * An amax record is CVAE_AMAX_SLOTS unsigned words holding float bits (non-negative floats order like unsigned integers; atomicMax, so the
+ * result does not depend on the order of arrival); the caller zero-fills it once. */
+#define CVAE_AMAX_SLOTS 64
 int cvae_quantize_fp8(const void* src, int src_dtype, void* dst, int64_t n, float inv_scale, void* stream);
+int cvae_quantize_fp8_dev(const void* src, int src_dtype, void* dst, int64_t n, const float* inv_scale_dev, void* amax_slots, void* stream);
+int cvae_absmax(const void* src, int dtype, int64_t n, void* amax_slots, void* stream);
 int cvae_conv_pack_weight_fp8(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, float inv_scale, void* stream);
+int cvae_conv_pack_weights_fp8(const float* const* w, void* const* packed, const int64_t* Cs, const int64_t* Cl, const int* for_up,
+                               const float* const* inv_scale_dev, void* const* amax_slots, int count, int nd, void* stream);
+int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, void* out, int out_dtype, void* out8, const float* dscale, float acc_scale,
+                  float out8_inv_scale, void* amax_slots, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl,
+                  int nd, int act, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                      void* stream);
+int cvae_fp8_scale_update(void* amax_slots, float* scale, float* inv_scale, int n, float headroom, const int* layer_in, const int* layer_w, const int* layer_out,
+                          int n_layers, float* dscale, void* stream);
 /* ---- Exact-2x linear resize (decoder output d x h x w, one channel -> 2d x 2h x 2w; D == d == 1 for 2D) fused with the ELBO ----
  * causal_cascade/models.py:84-87 + train.py:5-17: the resized volume is recomputed from the small tensor wherever it is needed
  * instead of being written and re-read (csrc/recon_loss.hip).  cvae_up2x_supported: 1 when the shapes qualify (w % 4 == 0). */

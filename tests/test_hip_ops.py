@@ -263,6 +263,73 @@ def test_conv_up_fp8_matches_dequantised_reference(nd, B, Cl, Cs, ssize, act, q_
         close(from_cl(y, nd), ref, torch.bfloat16, "y")
 
 
+@pytest.mark.parametrize("nd,B,Cl,Cs,lsize,splitk", [(3, 2, 32, 64, (16, 16, 16), True), (3, 2, 64, 128, (8, 8, 16), True), (3, 3, 128, 256, (8, 8, 8), True),
+                                                     (3, 1, 128, 256, (8, 8, 8), False), (2, 2, 32, 64, (24, 40), True), (3, 1, 32, 64, (10, 12, 18), True)])
+def test_conv_down_fp8_dual_output_device_scales_and_amax(nd, B, Cl, Cs, lsize, splitk):
+    """cvae_conv_fp8(up = 0) — the training forward: fp8 codes in, the result TWICE (bf16 for the backward pass, fp8 codes for the next layer), scales read
+    from device memory, max |result| recorded.  Against conv (fp32, CPU) of the DEQUANTISED operands; the split-K form (small grids) and the whole-K
+    form must agree with it alike."""
+    g = torch.Generator().manual_seed(15)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    x = torch.randn(B, Cl, *lsize, generator=g).abs()
+    w = torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cl * 4 ** nd)
+    b = torch.randn(Cs, generator=g) * 0.1
+    sx, sw = float(x.abs().max()) / ops.FP8_MAX, float(w.abs().max()) / ops.FP8_MAX
+    xq = ops.quantize_fp8(to_cl(x, torch.bfloat16), sx)
+    wq_codes = ops.quantize_fp8(w.to(DEV), sw)
+    wq = ops.pack_weight_fp8(w.to(DEV), nd, False, sw)
+    ref = F.relu(conv(from_cl(_e4m3_decode(xq) * sx, nd), _e4m3_decode(wq_codes) * sw, b, stride=2, padding=1))
+    so = 2.0 * float(ref.abs().max()) / ops.FP8_MAX
+    dscale = torch.tensor([sx * sw, 1.0 / so], dtype=torch.float32, device=DEV)
+    amax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+    old = ops.SPLIT_K
+    ops.SPLIT_K = splitk
+    try:
+        y, y8 = ops.conv_fp8(False, xq, wq, b.to(DEV), Cs, nd, "relu", dscale=dscale, want_out8=True, amax=amax)
+    finally:
+        ops.SPLIT_K = old
+    assert y.dtype == torch.bfloat16 and y8.dtype == torch.uint8 and y8.shape == y.shape
+    close(from_cl(y, nd), ref, torch.bfloat16, "y")
+    got8 = from_cl(_e4m3_decode(y8) * so, nd)
+    torch.testing.assert_close(got8, ref, rtol=2.0 ** -3, atol=so * 2.0 ** -9 * 1.01)
+    assert float((got8 - ref).norm() / ref.norm()) < 2.0 ** -5
+    rec = float(amax.cpu().view(torch.float32).max())
+    assert abs(rec - float(ref.abs().max())) <= 2.0 ** -7 * float(ref.abs().max()), (rec, float(ref.abs().max()))
+
+
+def test_fp8_scale_update_and_weight_pack_from_device_scales():
+    """cvae_fp8_scale_update: scale = headroom * amax / 448 from the recorded slots (cleared afterwards; a tensor that recorded nothing keeps its scale) and
+    the per-layer {s_in * s_w, 1 / s_out} pairs; cvae_conv_pack_weights_fp8: the panels of cvae_conv_pack_weight_fp8 with 1 / s_w read from the device,
+    max |w| recorded."""
+    g = torch.Generator().manual_seed(16)
+    n = 5
+    amax = torch.zeros(n, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+    vals = [3.0, 0.25, 0.0, 17.5, 1e-3]
+    for i, v in enumerate(vals):
+        if v > 0:
+            ops.absmax(torch.tensor([0.1 * v, -v, 0.5 * v], device=DEV), amax[i])
+    st = ops.Fp8Scales(n, [(0, 1, 3), (3, 4, -1)], DEV, headroom=2.0)
+    st.scale.fill_(7.0); st.inv_scale.fill_(1.0 / 7.0)
+    st.amax.copy_(amax)
+    st.update()
+    sc = st.scale.cpu()
+    for i, v in enumerate(vals):
+        want = 2.0 * v / ops.FP8_MAX if v > 0 else 7.0
+        assert abs(float(sc[i]) - want) <= 1e-6 * want, (i, float(sc[i]), want)
+    assert int(st.amax.abs().sum()) == 0
+    ds = st.dscale.cpu()
+    torch.testing.assert_close(ds[0], torch.stack([sc[0] * sc[1], 1.0 / sc[3]]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(ds[1], torch.stack([sc[3] * sc[4], torch.tensor(0.0)]), rtol=1e-6, atol=0)
+    w = (torch.randn(64, 128, 4, 4, 4, generator=g) * 0.05).to(DEV)
+    sw = float(w.abs().max()) / ops.FP8_MAX
+    st.inv_scale[1] = 1.0 / sw
+    for for_up in (False, True):
+        out = ops.pack_weights_fp8([w], 3, [for_up], [st.inv_scale[1:2]], [st.amax[1]])[0]
+        assert torch.equal(out, ops.pack_weight_fp8(w, 3, for_up, sw))
+        assert abs(float(st.amax[1].cpu().view(torch.float32).max()) - float(w.abs().max())) < 1e-7
+        st.amax.zero_()
+
+
 def test_conv_up_fp8_bad_arguments_fail_loudly():
     xq = torch.zeros(1, 4, 4, 4, 64, dtype=torch.uint8, device=DEV)
     w = torch.zeros(64, 32, 4, 4, 4, device=DEV)
