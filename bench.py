@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_FLOPS = 2.5e15     # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8_FLOPS = 5.0e15      # dense fp8 on the block-scaled MFMA (same table)
 PEAK_F32_FLOPS = 157.3e12    # fp32 MFMA / vector peak
 PEAK_HBM = 8.0e12            # HBM3E spec (6.3 TB/s achievable)
 METRIC = "training samples/sec on 128^3 vessel volumes (3D CausalVAE train step)"
@@ -268,9 +269,12 @@ def run_volume(args, rank, world, dev):
     from causal_vae_amd.causal_cascade import CausalBioVAE3D, loss_function, train_step
     from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters
     vessel = args.workload == "vol128-vessel"
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    fp8 = args.dtype == "fp8"                                        # configs[4]: the bf16 step with its C_in >= 32 forward convs on fp8 operands
+    dtype = torch.bfloat16 if args.dtype in ("bf16", "fp8") else torch.float32
     torch.manual_seed(42)                                            # causal_cascade/main.py:28
     model = CausalBioVAE3D().to(dev).train().set_compute_dtype(dtype)
+    if fp8:
+        model.set_fp8_forward(True)
     broadcast_parameters(model)
     opt = FusedAdam(model.parameters(), lr=args.lr, device_step=True)   # main.py:50
     if world == 1 and args.overlap_adam:
@@ -360,7 +364,7 @@ def run_volume(args, rank, world, dev):
     res.update(timing_fields(reps, args.steps, world * args.batch))
     loss_name = ("vessel recipe: pos-weighted MSE-sum + 0.3*background-L1 + 0.5*KLD + Gaussian-NLL(m), clip 5.0" if vessel
                  else "ELBO = MSE-sum + 2000*MSE-sum(m) + KLD")
-    res["config"] = {"workload": f"3D vessel CausalVAE train step, {args.size}^3 {args.dtype} volumes ({'binary ~10 % density' if vessel else 'z-scored N(0,1)'}), "
+    res["config"] = {"workload": f"3D vessel CausalVAE train step, {args.size}^3 {'bf16 volumes, fp8 (e4m3) forward convs (C_in >= 32), bf16 backward' if fp8 else args.dtype + ' volumes'} ({'binary ~10 % density' if vessel else 'z-scored N(0,1)'}), "
                                  f"batch {args.batch}/GPU, Adam lr {args.lr:g}, {loss_name}",
                      "global_batch": world * args.batch, "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}", "params": n_params}
     res["exchange"] = ("split backward: decoder + bottleneck bucket all-reduced under the encoder backward" if (use_graph and want_split) else
@@ -369,10 +373,26 @@ def run_volume(args, rank, world, dev):
         res["capture_fallback"] = capture_fallback
     res.update({"final_loss": fin(final_loss), "lr": args.lr, "hip_graph": use_graph, "deferred_wgrad": bool(_ops.DEFER_WGRAD)})
     step_ms = res["ms_per_step"]
-    fl, byt = step_algorithmic(args.batch, args.size, 2 if args.dtype == "bf16" else 4, n_params, conv_params)
+    fl, byt = step_algorithmic(args.batch, args.size, 4 if args.dtype == "f32" else 2, n_params, conv_params)
     if timer is not None:
-        roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, args.dtype, step_ms, fl, byt,
+        roof, kernels, fams = roofline_from_timer(timer, args.roofline_steps, "bf16" if fp8 else args.dtype, step_ms, fl, byt,
                                                   use_traffic=(args.size == 128 and args.batch == 4 and args.dtype == "bf16"))
+        if fp8 and roof is not None:
+            # the forward products of the six fp8 layers run at the fp8 peak, everything else at the bf16 peak: the step's MFMA fraction is the time
+            # the two parts would take at their own peaks over the measured step
+            s_, f8fl = args.size, 0.0
+            for i, (ci, co) in enumerate([(1, 32), (32, 64), (64, 128), (128, 256)]):
+                s_ //= 2
+                f8fl += 2.0 * args.batch * s_ ** 3 * ci * co * 64 if i else 0.0
+            d_ = 4
+            for ci, co in [(256, 128), (128, 64), (64, 32)]:
+                f8fl += 2.0 * args.batch * d_ ** 3 * ci * co * 64
+                d_ *= 2
+            roof["step"]["fp8_gflop"] = f8fl / 1e9
+            roof["step"]["mfma_frac"] = (f8fl / PEAK_FP8_FLOPS + (fl - f8fl) / PEAK_BF16_FLOPS) / (step_ms * 1e-3)
+            roof["step"]["mfma_frac_rule"] = "fp8 forward FLOPs at the 5 PFLOP/s fp8 peak + the rest at the 2.5 PFLOP/s bf16 peak, over the measured step"
+            roof["note_fp8"] = ("labels conv_down (C_in >= 32) and conv_up (C_out > 1) cover an fp8 forward launch AND a bf16 backward-data launch of the same "
+                                "geometry; their TFLOP/s are priced here against the bf16 peak")
         res["roofline"] = roof
         res["conv_ms_per_step"] = sum(v["ms_per_step"] for v in fams.values())
         res["families"] = fams
@@ -407,6 +427,8 @@ def run_volume(args, rank, world, dev):
         _ops.EpsSource._instances = 0
         torch.manual_seed(42)
         m2 = CausalBioVAE3D().to(dev).train().set_compute_dtype(dtype)
+        if fp8:
+            m2.set_fp8_forward(True)
         o2 = FusedAdam(m2.parameters(), lr=args.lr)
         gl = [float(train_step(m2, o2, x, m, t, eps=eps)[0]) for _ in range(K + 1)]
         res["elbo_rel_err_after_k"] = {"k": K, "value": abs(gl[K] - ref_losses[K]) / abs(ref_losses[K]), "gpu": gl[K], "oracle": ref_losses[K],
@@ -527,7 +549,7 @@ def run_decode(args, rank, world, dev):
     return res
 
 
-SECONDARY = (("mnist", "mnist", None, {}), ("vol64-f32", "vol64-f32", None, {}), ("decode-bf16", "decode", "bf16", {}), ("decode-fp8", "decode", "fp8", {}))
+SECONDARY = (("mnist", "mnist", None, {}), ("vol64-f32", "vol64-f32", None, {}), ("vol128-fp8", "vol128", "fp8", {}), ("decode-bf16", "decode", "bf16", {}), ("decode-fp8", "decode", "fp8", {}))
 
 
 def secondary_lines(args, dev):
@@ -572,7 +594,7 @@ def main():
     ap.add_argument("--workload", default="vol128", choices=["vol128", "vol64-f32", "mnist", "decode", "vol128-vessel"])
     ap.add_argument("--size", type=int, default=None, help="volume edge (default: the workload's)")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8"], help="fp8: decode workload only (e4m3 conv operands)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8"], help="fp8 (e4m3 conv operands): the decode workload, or vol128 = the bf16 train step with its C_in >= 32 forward convs on fp8")
     ap.add_argument("--min-timed-s", type=float, default=0.2, help="repeat the K-step timed region until this much has been timed; the median repetition is reported")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg: half for the main figure, a quarter each for the 8-thread and all-physical-cores ones (0 disables)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the main cpu_baseline leg (0 = min(physical cores in the affinity mask, cgroup CPU quota))")
@@ -596,8 +618,8 @@ def main():
     args.size = args.size or dsz
     args.batch = args.batch or dB
     args.dtype = args.dtype or ddt
-    if args.dtype == "fp8" and args.workload != "decode":
-        raise SystemExit("--dtype fp8 is the inference decode path only (--workload decode)")
+    if args.dtype == "fp8" and args.workload not in ("decode", "vol128"):
+        raise SystemExit("--dtype fp8: the decode sweep (--workload decode) or the 128^3 train step with fp8 forward convs (--workload vol128)")
 
     from causal_vae_amd import ops as _ops
     from causal_vae_amd.parallel import init_distributed

@@ -50,6 +50,28 @@ class CausalBioVAE(nn.Module):
         hl.set_compute_dtype(self, dtype)
         return self
 
+    def set_fp8_forward(self, on=True, headroom=2.0):
+        """Training forward of the conv layers with C_in >= 32 on fp8 (e4m3) operands (BASELINE.json configs[4]; causal_vae_amd.fp8): the bf16 model's
+        step with the forward products of enc_conv[2..6] / dec_conv[0..4] on the block-scaled MFMA; the backward pass stays bf16.  Needs the bf16
+        compute dtype and the fused training path (2 <= B <= 16); the first step after switching it on calibrates the scales (and runs bf16)."""
+        if on and self.enc_conv.compute_dtype != torch.bfloat16:
+            raise ops.L.CvaeError("set_fp8_forward: set_compute_dtype(torch.bfloat16) first (the backward pass and the single-channel layers run bf16)")
+        self._fp8_on, self._fp8_headroom = bool(on), float(headroom)
+        if not on:
+            self._fp8 = None
+        return self
+
+    _fp8_on, _fp8, _fp8_headroom = False, None, 2.0
+
+    def _fp8_plan(self, device):
+        if not self._fp8_on:
+            return None
+        if self._fp8 is None or self._fp8.device != device:
+            from ..fp8 import Fp8Forward
+            convs = lambda stack: [m_ for m_ in stack if isinstance(m_, hl._ConvBase)]
+            self._fp8 = Fp8Forward([("enc", convs(self.enc_conv), False), ("dec", convs(self.dec_conv), True)], self._ND, device, self._fp8_headroom)
+        return self._fp8
+
     # ---- reference surface -----------------------------------------------------------------------------------
     def encode(self, x, m, t_onehot):
         h = self.enc_fc(self.enc_conv.forward_cat(x, [m, t_onehot]))
@@ -105,8 +127,11 @@ class CausalBioVAE(nn.Module):
                 or any(s % 16 for s in x.shape[2:]) or not bn.track_running_stats or bn.momentum is None):
             return None
         we, wd = self.enc_conv.conv_weights(), self.dec_conv.conv_weights()
-        packed = ops.pack_weights(we + wd, nd, self.enc_conv.compute_dtype)          # every conv weight of the model, one launch
-        h, rest, last_act = self.enc_conv.features_cl(x, packed=packed[:len(we)])
+        f8 = self._fp8_plan(x.device)
+        if f8 is not None:
+            f8.begin_step()
+        packed = ops.pack_weights(we + wd, nd, self.enc_conv.compute_dtype, f8spec=f8.pack_spec() if f8 is not None else None)   # every conv weight of the model, one launch
+        h, rest, last_act = self.enc_conv.features_cl(x, packed=packed[:len(we)], f8=f8)
         self._enc_out = h                                    # graph.GraphedTrainStep splits the backward here (exchange overlap)
         if not ops.BioBottleneck.supported(h, out_size, True) or last_act != "relu":
             raise ops.L.CvaeError("fused bottleneck: unexpected encoder output " + str(tuple(h.shape)))
@@ -119,7 +144,10 @@ class CausalBioVAE(nn.Module):
             t = ops.one_hot(t, self.t_dim)
         mu, logvar, m_hat, dec_cl = ops.BioBottleneck.apply(h, m, t, eps, *params, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                                             bn.momentum, bn.eps, out_size)
-        return mu, logvar, m_hat, self.dec_conv.forward_from_cl(dec_cl, packed=packed[len(we):])
+        out_cl = self.dec_conv.forward_from_cl(dec_cl, packed=packed[len(we):], f8=f8)
+        if f8 is not None:
+            f8.end_step()
+        return mu, logvar, m_hat, out_cl
 
     def _forward_cl(self, x, m, t, eps):
         """Everything up to the decoder output, channels-last [B, d, h, w, C] in the conv dtype (before the resize to x's size)."""

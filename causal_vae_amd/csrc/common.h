@@ -49,6 +49,50 @@ template <> __device__ __forceinline__ fp8 from_f32<fp8>(float x) {             
     return fp8{(unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff)};
 }
 
+// 8 floats -> 8 fp8 (e4m3) codes of v * mul, saturating at +-448 (v_cvt_pk_fp8_f32 alone would produce NaN past the range)
+__device__ __forceinline__ uint2 pack8_fp8(const float (&v)[8], float mul) {
+    float c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] = __builtin_amdgcn_fmed3f(v[q] * mul, -CVAE_FP8_MAX, CVAE_FP8_MAX);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+// The MFMA epilogues leave lane (r, h) with channels 8h..8h+7 (`a`) and 16+8h..23+8h (`b`) of its position's 32-channel block, as 8-byte fp8 pieces.
+// One v_permlane32_swap per dword hands lane h = 0 channels 0..15 and lane h = 1 channels 16..31: ONE 16-byte store per lane at channel 16 h instead
+// of two 8-byte ones (the swap exchanges the first operand of lanes 32-63 with the second operand of lanes 0-31).
+__device__ __forceinline__ uint4 fp8_pair_to_16(uint2 a, uint2 b) {
+    const auto x = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    return make_uint4(x[0], y[0], x[1], y[1]);
+}
+// fp8 side channel of a producing kernel (all members may be null): `dscale` = device floats {acc_scale, 1 / s_out8} that replace by-value scales
+// (a captured training step re-reads them on every replay: delayed scaling), `out8` = a second copy of the result as fp8 codes of result / s_out8
+// (what the next fp8 layer reads, while the bf16 result stays for the backward pass), `amax` = CVAE_AMAX_SLOTS words that receive max |result| as
+// float bits (non-negative floats order like unsigned integers).
+struct F8Side {
+    const float* dscale;
+    fp8* out8;
+    unsigned* amax;
+};
+// max |.| of the workgroup (`red`: one float per wave, in LDS), then ONE atomicMax per WORKGROUP on the slot of its linear index: with
+// CVAE_AMAX_SLOTS = 4096 the workgroups of a launch rarely share a word.  (One atomic per wave on 64 slots cost the 64 -> 32 channel layer 14 of
+// its 23 us: same-address atomics serialise at the memory side at ~100 ns each.)  Every thread of the workgroup must call this.
+__device__ __forceinline__ void amax_publish_wg(unsigned* slots, float amx, unsigned wg, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+        if (m > 0.f) atomicMax(slots + (wg & (CVAE_AMAX_SLOTS - 1)), __float_as_uint(m));
+    }
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case CVAE_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -175,10 +175,12 @@ template <int ND, int MS> struct TileC1V;
 template <int MS> struct TileC1V<3, MS> { static constexpr int TD = MS / 2, TH = 8, TW = 32; };   // wide in x: a halo row is 160-288 contiguous bytes, an output row 2 KB
 template <int MS> struct TileC1V<2, MS> { static constexpr int TD = 1, TH = 8 * MS, TW = 16; };
 
-template <typename TL, int ND, int EPI, bool MASKED, int MS>
+// SIDE8 (the first layer of a training forward whose next conv runs on fp8 operands, causal_vae_amd/fp8.py): S is left a second time as fp8 (e4m3)
+// codes of S * f8.dscale[0] (f8.dscale -> ONE device float, 1 / s_S) in f8.out8, and max |S| is recorded in f8.amax (common.h).
+template <typename TL, int ND, int EPI, bool MASKED, int MS, bool SIDE8 = false>
 __global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__ L, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const bf16* __restrict__ mask, bf16* __restrict__ S, int sd, int sh, int sw, int ld, int lh, int lw,
-                                                          int tiles_d, int tiles_h, int tiles_w, int ntiles, int act) {
+                                                          int tiles_d, int tiles_h, int tiles_w, int ntiles, int act, F8Side f8) {
     using TLE = TileC1V<ND, MS>;
     using OP = C1Ops<bf16>;
     constexpr int CS = 32;
@@ -231,6 +233,8 @@ __global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__
     };
     int tile = blockIdx.x;
     issue_loads(tile);
+    float amx = 0.f;
+    const float o8s = (SIDE8 && f8.out8) ? f8.dscale[0] : 1.f;
     typename OP::BFrag bfr[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) OP::load_b(bfr[kb], w + (size_t)r * TAPS, kb, h);
@@ -300,12 +304,28 @@ __global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__
                     *(uint4*)(S + tile_org + loff + c) = make_uint4(pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3]), pack2_bf16(v[j][4], v[j][5]), pack2_bf16(v[j][6], v[j][7]));
                 }
             }
+            if constexpr (SIDE8) {
+                if (ok && f8.amax) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) amx = fmaxf(amx, fmaxf(fabsf(v[0][q]), fabsf(v[1][q])));
+                }
+                if (f8.out8) {                                // every lane takes part in the lane swap; `ok` only guards the store
+                    const uint4 q16 = fp8_pair_to_16(pack8_fp8(v[0], o8s), pack8_fp8(v[1], o8s));
+                    if (ok) *(uint4*)(f8.out8 + tile_org + loff + 16 * h) = q16;
+                }
+            }
         }
         if (!has_next) break;
         __syncthreads();                                     // every wave is done with this tile's LDS image
         store_lds();
         __syncthreads();
         tile = next;
+    }
+    if constexpr (SIDE8) {
+        if (f8.amax) {
+            __syncthreads();                                 // the halo image is spent: its first floats carry the per-wave maxima
+            amax_publish_wg(f8.amax, amx, blockIdx.x, (float*)halo);
+        }
     }
 }
 
@@ -937,9 +957,11 @@ static bool image_vec_ok(const void* L, int64_t lw, int l_dtype) {
     return lw % epv == 0 && lw >= epv && (((uintptr_t)L) & 15) == 0;
 }
 int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
-                      int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream) {
+                      int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, F8Side f8) {
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
     const int epi = CVAE_EPI_OF(act);
+    const bool side8 = f8.out8 || f8.amax;
+    if (side8 && !(dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype) && !mask)) return CVAE_E_UNSUPPORTED;
     if (dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype)) {          // bf16 output: the 16-byte-load form, image in its own dtype
         // 512 positions per workgroup once that still leaves ~4 workgroups per CU, else 256
         const bool big = B * ((sd + 1) / 2) * ((sh + 7) / 8) * ((sw + 31) / 32) >= 1024 || nd == 2;
@@ -950,10 +972,11 @@ int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* b
         if (ntiles_ll > 0x7fffffff) return CVAE_E_BADSHAPE;
         const int ntiles = (int)ntiles_ll;
         dim3 grid((unsigned)(ntiles < CVAE_C1_MAX_WG ? ntiles : CVAE_C1_MAX_WG), 1, 1);       // <= 4 resident workgroups per CU; each walks ntiles / grid tiles
-#define LAUNCH_DOWN_VEC__(TLT, ND, EPI, MASKED, MS)                                                                                                    \
-    hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND, EPI, MASKED, MS>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
-                       (int)sw, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, ntiles, act)
-#define LAUNCH_DOWN_VEC_(TLT, ND, EPI, MS) do { if (mask) LAUNCH_DOWN_VEC__(TLT, ND, EPI, true, MS); else LAUNCH_DOWN_VEC__(TLT, ND, EPI, false, MS); } while (0)
+#define LAUNCH_DOWN_VEC__(TLT, ND, EPI, MASKED, MS, SIDE)                                                                                              \
+    hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND, EPI, MASKED, MS, SIDE>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
+                       (int)sw, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, ntiles, act, f8)
+#define LAUNCH_DOWN_VEC_(TLT, ND, EPI, MS) do { if (mask) LAUNCH_DOWN_VEC__(TLT, ND, EPI, true, MS, false); else if (side8) LAUNCH_DOWN_VEC__(TLT, ND, EPI, false, MS, true); \
+                                                else LAUNCH_DOWN_VEC__(TLT, ND, EPI, false, MS, false); } while (0)
 #define LAUNCH_DOWN_VEC(TLT, ND, MS)                                                                                                      \
     do { if (epi == 0) LAUNCH_DOWN_VEC_(TLT, ND, 0, MS); else if (epi == 1) LAUNCH_DOWN_VEC_(TLT, ND, 1, MS); else LAUNCH_DOWN_VEC_(TLT, ND, 2, MS); } while (0)
         if (l_dtype == CVAE_F32) { if (nd == 2) LAUNCH_DOWN_VEC(float, 2, 4); else if (ms == 4) LAUNCH_DOWN_VEC(float, 3, 4); else LAUNCH_DOWN_VEC(float, 3, 2); }

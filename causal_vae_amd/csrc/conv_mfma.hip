@@ -107,16 +107,6 @@ __device__ __forceinline__ void lds_load(Frag<float>& f, const char* p) {
 }
 __device__ __forceinline__ void lds_load(Frag<f8x2>& f, const char* p) { f.v = *(const i32x4*)p; }
 #define CVAE_E8M0_ONE 0x7F7F7F7F        // block scale 2^0 in every byte: the scaled instruction then is a plain fp8 x fp8 product
-// two k-steps at once (the fp8 form); for the other dtypes simply the two products in order
-__device__ __forceinline__ void mma2(f32x16& acc, const Frag<f8x2>& a0, const Frag<f8x2>& a1, const Frag<f8x2>& b0, const Frag<f8x2>& b1) {
-    const i32x8 a = {a0.v[0], a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3]};
-    const i32x8 b = {b0.v[0], b0.v[1], b0.v[2], b0.v[3], b1.v[0], b1.v[1], b1.v[2], b1.v[3]};
-    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, CVAE_E8M0_ONE, 0, CVAE_E8M0_ONE);
-}
-__device__ __forceinline__ void mma(f32x16& acc, const Frag<f8x2>& a, const Frag<f8x2>& b) {       // never reached: every f8x2 loop pairs its k-steps
-    const Frag<f8x2> z{{0, 0, 0, 0}};
-    mma2(acc, a, z, b, z);
-}
 // lane (r = lane & 31, h = lane >> 5) holds elements k = 8h .. 8h+7 of its row/column in both precisions
 __device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
@@ -125,10 +115,20 @@ __device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Fra
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
-template <typename T>
-__device__ __forceinline__ void mma2(f32x16& acc, const Frag<T>& a0, const Frag<T>& a1, const Frag<T>& b0, const Frag<T>& b1) {
-    mma(acc, a0, b0);
-    mma(acc, a1, b1);
+// What ONE MFMA consumes: a k-step's fragment — or, for fp8, the fragments of TWO k-steps as one 8-register operand, put together where they are
+// LOADED (two 16-byte reads into the halves of one register tuple).  Joining single-step fragments in front of each MFMA instead made the
+// register allocator juggle 4-register values into 8-register tuples: 256 VGPRs + 59 spilled on the `down` form, a 20 k-cycle epilogue.
+struct Frag2 { i32x8 v; };
+template <typename T> struct StepFrag { using type = Frag<T>; static constexpr int PW = 1; };
+template <> struct StepFrag<f8x2> { using type = Frag2; static constexpr int PW = 2; };
+template <typename F>
+__device__ __forceinline__ void load_step(F& f, const char* p0, const char*) { lds_load(f, p0); }
+__device__ __forceinline__ void load_step(Frag2& f, const char* p0, const char* p1) {
+    const i32x4 lo = *(const i32x4*)p0, hi = *(const i32x4*)p1;
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void mma(f32x16& acc, const Frag2& a, const Frag2& b) {
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a.v, b.v, acc, 0, 0, 0, CVAE_E8M0_ONE, 0, CVAE_E8M0_ONE);
 }
 
 template <int ND, int BM> struct Tile;
@@ -218,34 +218,6 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // TS ("K split", BD only): TS = 2 wave groups of WM x WN waves each own every second k-step (odd / even taps for KH = 1, the two 16-channel halves
 // of a stage for KH = 2) of the WHOLE tile and add their accumulators through LDS once, before the epilogue.  With WM = 1 no two waves fetch the
 // same weight fragment, and a fetched fragment feeds MI = 4 MFMAs: half the bytes per MFMA on the vector-memory path the BD tap loop is bound by.
-// 8 floats -> 8 fp8 (e4m3) codes of v * mul, saturating at +-448 (v_cvt_pk_fp8_f32 alone would produce NaN past the range)
-__device__ __forceinline__ uint2 pack8_fp8(const float (&v)[8], float mul) {
-    float c[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) c[q] = __builtin_amdgcn_fmed3f(v[q] * mul, -CVAE_FP8_MAX, CVAE_FP8_MAX);
-    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
-    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
-    return make_uint2((unsigned)lo, (unsigned)hi);
-}
-// max over the wave, then ONE atomicMax on one of CVAE_AMAX_SLOTS words (spread by `salt`: same-address atomics serialise at the memory side)
-__device__ __forceinline__ void amax_publish(unsigned* slots, float amx, unsigned salt) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
-    if ((threadIdx.x & 63) == 0 && amx > 0.f) atomicMax(slots + (salt & 63u), __float_as_uint(amx));
-}
-// fp8 side channel (f8x2 products only; all members may be null): `dscale` = device floats {acc_scale, 1 / s_out8} that replace the by-value
-// scales (a captured training step re-reads them on every replay: delayed scaling), `out8` = a second copy of the result as fp8 codes of
-// result / s_out8 (what the next fp8 layer reads, while `out` keeps the bf16 activation the backward pass needs), `amax` = CVAE_AMAX_SLOTS
-// words that receive max |result| as float bits (non-negative floats order like unsigned integers: one atomicMax per wave, order-independent).
-struct F8Side {
-    const float* dscale;
-    fp8* out8;
-    unsigned* amax;
-};
-static_assert(CVAE_AMAX_SLOTS == 64, "amax_publish spreads over 64 slots");
-
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = false, int TS = 1, int XB = 1>
 __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kernel(const T* __restrict__ in, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                   const TO* __restrict__ mask, TO* __restrict__ out, ConvGeom g, int act,
@@ -402,21 +374,30 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     // 16-channel half of the stage — a constant offset of this wave's LDS and weight base addresses.
     constexpr int STEPS = NG * 4 * KH / TS, GS = STEPS >= 64 ? CVAE_BD_GS : (STEPS >= 16 ? (MI >= 4 ? 4 : 8) : STEPS / 2), NGRP = STEPS / GS;      // MI = 4: a step is 4 MFMAs, 4 steps are as long as 8
     static_assert(!BD || (NGRP % 2 == 0 && GS * NGRP == STEPS && (GS * TS) % KH == 0), "BD walks the groups in pairs");
-    static_assert(!(BD && F8) || GS % 2 == 0, "fp8 pairs the k-steps of a weight group");
     static_assert(TS == 1 || KH <= 2, "K split: one or two k-steps per stage");
     const long long w_tap = (long long)nch16 * Cout * 16;     // elements between two taps of the packed panels
     const long long w_ts = (TS == 1) ? 0 : (KH == 2 ? (long long)ts * Cout * 16 : (UP ? -2 * ts * w_tap : ts * w_tap));
     const int a_ts = (TS == 1) ? 0 : (KH == 2 ? ts * 2 * PLANE : (UP ? ts : ts * NROWS * RS));
     const T* wl = wp + ((size_t)(n0 + wn * NI * 32 + r)) * 16 + 8 * h + w_ts;
     const char* halo_a = halo + (size_t)a_ts * FB;
-    Frag<T> qa[BD ? GS : 1][NI], qb[BD ? GS : 1][NI];
-    auto load_q = [&](Frag<T> (&q)[BD ? GS : 1][NI], int chunk, int gidx) {
+    constexpr int PW = StepFrag<T>::PW;                       // k-steps per MFMA (fp8: 2)
+    using SF = typename StepFrag<T>::type;
+    constexpr int GSX = GS / PW;                              // MFMAs (per accumulator) of a weight group
+    static_assert(GS % PW == 0, "a weight group holds whole MFMA steps");
+    SF qa[BD ? GSX : 1][NI], qb[BD ? GSX : 1][NI];
+    auto load_q = [&](SF (&q)[BD ? GSX : 1][NI], int chunk, int gidx) {
 #pragma unroll
-        for (int i = 0; i < GS; ++i) {
-            const int kk = (i * TS) % KH, tj = gidx * (GS * TS / KH) + (i * TS) / KH;
-            const int wt = tap_weight_idx(tj >> 2, tj & 3);
+        for (int ix = 0; ix < GSX; ++ix) {
+            const T* wsrc[2];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) lds_load(q[i][ni], (const char*)(wl + ((size_t)(wt * nch16 + chunk * KH + kk) * Cout + ni * 32) * 16));
+            for (int u = 0; u < PW; ++u) {
+                const int i = ix * PW + u;
+                const int kk = (i * TS) % KH, tj = gidx * (GS * TS / KH) + (i * TS) / KH;
+                const int wt = tap_weight_idx(tj >> 2, tj & 3);
+                wsrc[u] = wl + (size_t)(wt * nch16 + chunk * KH + kk) * Cout * 16;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) load_step(q[ix][ni], (const char*)(wsrc[0] + (size_t)ni * 32 * 16), (const char*)(wsrc[PW - 1] + (size_t)ni * 32 * 16));
         }
     };
     STAMP(1);
@@ -437,7 +418,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
 #pragma unroll
                 for (int q = 0; q < 8; ++q) bpre[ni][j][q] = bias ? bias[c + q] : 0.f;
             }
-        if (mask) {
+        if (!F8 && mask) {                                   // fp8 products are forward products: no mask, and no registers held for one
 #pragma unroll
             for (int mo = 0; mo < MO; ++mo) {
                 const int mi = mi0 + mo, ms = wm * MI + mi;
@@ -464,39 +445,36 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     // MFMA never waits for a read issued right before it — left to itself the compiler emits read / s_waitcnt / MFMA per step and the loop runs at
     // LDS latency (~35 % of the MFMA rate by the stamp probes, one wave per SIMD).
     auto bd_pair = [&](int chunk, int gp) {
-        constexpr int NS = 2 * GS, APW = (MI >= 4) ? 2 : CVAE_APIPE, APD = APW < NS ? APW : NS - 1;      // MI = 4: 4 reads per step, 2 steps ahead is as many in flight
+        // in MFMA steps (fp8: one step = two k-steps).  MI = 4: 4 reads per k-step, 2 k-steps ahead is as many in flight
+        constexpr int NS = 2 * GSX, APW = (MI >= 4) ? 2 / PW : (CVAE_APIPE + PW - 1) / PW, APD = APW < NS ? APW : NS - 1;
         load_q(qb, chunk, gp + 1);
-        constexpr int RING = APD + 1 + (F8 ? 1 : 0);       // fp8: step i - 1 must outlive the read-ahead issued in front of step i (the pair shares one MFMA)
-        Frag<T> ar[RING][MI];
-        auto lda = [&](int slot, int i) {
-            const int gidx = gp + i / GS, ii = i % GS;
-            const int kk = (ii * TS) % KH, tj = gidx * (GS * TS / KH) + (ii * TS) / KH;
-            const int toff = tap_halo_off(tj >> 2, tj & 3);
+        SF ar[APD + 1][MI];
+        auto lda = [&](int slot, int ix) {
+            int off[2];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) lds_load(ar[slot][mi], halo_a + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
+            for (int u = 0; u < PW; ++u) {
+                const int i = ix * PW + u;
+                const int gidx = gp + i / GS, ii = i % GS;
+                const int kk = (ii * TS) % KH, tj = gidx * (GS * TS / KH) + (ii * TS) / KH;
+                off[u] = (kk * 2 + h) * PLANE + tap_halo_off(tj >> 2, tj & 3);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) load_step(ar[slot][mi], halo_a + (size_t)(off[0] + pbase[mi]) * FB, halo_a + (size_t)(off[PW - 1] + pbase[mi]) * FB);
         };
 #pragma unroll
         for (int d = 0; d < APD; ++d) lda(d, d);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            if (i + APD < NS) lda((i + APD) % RING, i + APD);
-            if (i == GS) {
+            if (i + APD < NS) lda((i + APD) % (APD + 1), i + APD);
+            if (i == GSX) {
                 const bool wrap = gp + 2 >= NGRP;
                 if (!wrap || chunk + 1 < (ks + 1) * chunk_per) load_q(qa, wrap ? chunk + 1 : chunk, wrap ? 0 : gp + 2);
             }
             __builtin_amdgcn_sched_barrier(0);             // keep the reads where they are written: the scheduler would sink them back to their uses
-            if constexpr (!F8) {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], (i < GS ? qa[i % GS] : qb[i % GS])[ni], ar[i % RING][mi]);
-            } else if (i & 1) {                            // k-steps i - 1 and i: one K = 64 instruction (GS is even: both weights are in the same group)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        mma2(acc[mi][ni], (i < GS ? qa[(i - 1) % GS] : qb[(i - 1) % GS])[ni], (i < GS ? qa[i % GS] : qb[i % GS])[ni], ar[(i - 1) % RING][mi], ar[i % RING][mi]);
-            }
+                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], (i < GSX ? qa[i % GSX] : qb[i % GSX])[ni], ar[i % (APD + 1)][mi]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -542,42 +520,25 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
             // stored to LDS at the end of group g+1, so every panel load has two groups of MFMA work to land (one group is
             // shorter than the L2 latency).  The loop is unrolled by two so the register sets pbA / pbB stay static.
             auto taps = [&](int grp, const char* btb) {
-                  if constexpr (!F8) {
     #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int toff = tap_halo_off(grp, j);
+                for (int sp = 0; sp < 4 * KH; sp += PW) {   // k-steps (tap j, k-step kk); fp8 feeds one K = 64 instruction per pair
+                    SF a[MI], bf[NI];
+                    int aoff[2], boff[2];
     #pragma unroll
-                    for (int kk = 0; kk < KH; ++kk) {
-                        Frag<T> a[MI], bf[NI];
-    #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) lds_load(a[mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
-    #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) lds_load(bf[ni], btb + (((j * KH + kk) * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
-    #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-    #pragma unroll
-                            for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
-                    }
-                }
-              } else {
-    #pragma unroll
-                for (int sp = 0; sp < 4 * KH; sp += 2) {   // k-steps (tap j, k-step kk) in pairs: fp8 feeds one K = 64 instruction per pair
-                    Frag<T> a[2][MI], bf[2][NI];
-    #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < PW; ++u) {
                         const int j = (sp + u) / KH, kk = (sp + u) % KH;
-                        const int toff = tap_halo_off(grp, j);
-    #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) lds_load(a[u][mi], halo + ((size_t)(kk * 2 + h) * PLANE + pbase[mi] + toff) * FB);
-    #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) lds_load(bf[u][ni], btb + (((j * KH + kk) * 2 + h) * BN + (wn * NI + ni) * 32 + r) * FB);
+                        aoff[u] = (kk * 2 + h) * PLANE + tap_halo_off(grp, j);
+                        boff[u] = ((j * KH + kk) * 2 + h) * BN;
                     }
+    #pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) load_step(a[mi], halo + (size_t)(aoff[0] + pbase[mi]) * FB, halo + (size_t)(aoff[PW - 1] + pbase[mi]) * FB);
+    #pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) load_step(bf[ni], btb + (boff[0] + (wn * NI + ni) * 32 + r) * FB, btb + (boff[PW - 1] + (wn * NI + ni) * 32 + r) * FB);
     #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
     #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mma2(acc[mi][ni], bf[0][ni], bf[1][ni], a[0][mi], a[1][mi]);     // D = W^T x X^T: rows = channels (see epilogue)
+                        for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], bf[ni], a[mi]);     // D = W^T x X^T: rows = channels (see epilogue)
                 }
-              }
             };
             Piece<T> pbA[BP], pbB[BP];
             if (NG > 1) load_b(pbA, chunk, 1);
@@ -681,7 +642,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
                     v[j][q] = x;
                 }
                 if (!ok) continue;
-                if (mask) {
+                if (!F8 && mask) {
                     const TO* mv = (const TO*)&mpre[mo][ni][j];
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
@@ -692,18 +653,24 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
 #pragma unroll
                         for (int q = 0; q < 8; ++q) amx = fmaxf(amx, fabsf(v[j][q]));
                     }
-                    if (f8.out8) *(uint2*)(f8.out8 + pidx + c) = pack8_fp8(v[j], o8s);
                 }
                 if constexpr (sizeof(TO) == 2 && sizeof(T) == 2) {           // bf16: one v_cvt_pk_bf16_f32 per pair
                     *(uint4*)(out + pidx + c) = make_uint4(pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3]), pack2_bf16(v[j][4], v[j][5]), pack2_bf16(v[j][6], v[j][7]));
-                } else if constexpr (F8) {                                   // fp8 codes only (the inference chain between two fp8 layers)
-                    *(uint2*)(out + pidx + c) = pack8_fp8(v[j], o8s);
+                } else if constexpr (F8) {                                   // fp8 codes only (the inference chain between two fp8 layers): below, 16 bytes per lane
                 } else {
                     Piece<TO> op;
                     TO* ov = (TO*)&op;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(v[j][q]);
                     piece_store<TO>(op, (char*)(out + pidx + c));
+                }
+            }
+            if constexpr (F8) {
+                // the fp8 copy of this 32-channel block: 16 bytes per lane (all lanes take part in the lane swap; `ok` only guards the store)
+                fp8* o8 = sizeof(TO) == 1 ? (fp8*)out : f8.out8;
+                if (o8) {
+                    const uint4 q16 = fp8_pair_to_16(pack8_fp8(v[0], o8s), pack8_fp8(v[1], o8s));
+                    if (ok) *(uint4*)(o8 + pidx + n0 + (wn * NI + ni) * 32 + 16 * h) = q16;
                 }
             }
         }
@@ -715,7 +682,10 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
         finish(std::integral_constant<int, 0>{});
     }
     if constexpr (F8) {
-        if (f8.amax && ksplit == 1) amax_publish(f8.amax, amx, blockIdx.x + blockIdx.y + wave);
+        if (f8.amax && ksplit == 1) {                          // uniform over the workgroup
+            __syncthreads();                                   // the LDS image (halo / accumulator exchange) is spent
+            amax_publish_wg(f8.amax, amx, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), (float*)smem);
+        }
     }
 #ifdef CVAE_STAMP
     __builtin_amdgcn_s_waitcnt(0);                         // vmcnt(0): the stores have left the wave
@@ -757,7 +727,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
         piece_store<T>(op, (char*)(out + i8));
         if (f8.out8) *(uint2*)(f8.out8 + i8) = pack8_fp8(v, f8.dscale ? f8.dscale[1] : 1.f);
     }
-    if (f8.amax) amax_publish(f8.amax, amx, blockIdx.x + (threadIdx.x >> 6));
+    __shared__ float red[4];
+    if (f8.amax) amax_publish_wg(f8.amax, amx, blockIdx.x, red);
 }
 
 #ifndef CVAE_XPAIR
@@ -1234,38 +1205,55 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_multi_kernel(F8PackTable 
         c = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], c, true);
         *(int*)(out + i) = c;
     }
-    if (tb.amax[ti]) amax_publish(tb.amax[ti], amx, blockIdx.x + (threadIdx.x >> 6));
+    __shared__ float red[4];
+    if (tb.amax[ti]) amax_publish_wg(tb.amax[ti], amx, blockIdx.x, red);
 }
 
 // Delayed scaling, once per step: every tracked tensor i gets scale[i] = headroom * amax_i / 448 from the largest value recorded since the last
 // call (its slots are cleared; a tensor that recorded nothing keeps its scale), then every fp8 layer l its pair {s_in * s_w, 1 / s_out}.
 #define F8LAYER_MAX 16
 struct F8LayerIdx { int in[F8LAYER_MAX], w[F8LAYER_MAX], out[F8LAYER_MAX]; int count; };
-__global__ __launch_bounds__(64) void fp8_scale_update_kernel(unsigned* __restrict__ amax, float* __restrict__ scale, float* __restrict__ inv_scale, int n, float headroom,
-                                                              F8LayerIdx li, float* __restrict__ dscale) {
-    __shared__ float sh[64];
-    const int lane = threadIdx.x;
-    for (int i = 0; i < n; ++i) {
-        unsigned* sl = amax + (size_t)i * CVAE_AMAX_SLOTS;
-        float a = __uint_as_float(sl[lane]);
+// One workgroup per tracked tensor reduces that tensor's record (a single workgroup reading all of them ran at one CU's load rate: 11.6 us for 12 tensors).
+// The per-layer pairs need EVERY scale: the workgroup whose ticket add comes last computes them.  Hand-off per MI355X_MICROARCH.md (visibility, valid forms):
+// every scale is written by an agent-scope (sc1) atomic store, the writing lane drains it (s_waitcnt vmcnt(0)) before its agent-scope ticket add, and the last
+// arriver — told by the value its add returned — reads the scales with agent-scope atomic loads, never through its L1.  `ticket` is one device word that the
+// last arriver resets, so a replayed graph finds it zero.
+__global__ __launch_bounds__(1024) void fp8_scale_update_kernel(unsigned* __restrict__ amax, float* __restrict__ scale, float* __restrict__ inv_scale, int n, float headroom,
+                                                                F8LayerIdx li, float* __restrict__ dscale, unsigned* __restrict__ ticket) {
+    static_assert(CVAE_AMAX_SLOTS == 4096, "one uint4 per thread");
+    __shared__ float red[16];
+    __shared__ unsigned last;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = blockIdx.x;
+    uint4* a4 = (uint4*)amax + (size_t)i * (CVAE_AMAX_SLOTS / 4);
+    const uint4 v = a4[t];
+    a4[t] = make_uint4(0u, 0u, 0u, 0u);
+    float a = fmaxf(fmaxf(__uint_as_float(v.x), __uint_as_float(v.y)), fmaxf(__uint_as_float(v.z), __uint_as_float(v.w)));
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
-        sl[lane] = 0u;
-        if (lane == 0) {
-            float s = scale[i];
-            if (a > 0.f) {
-                s = headroom * a / CVAE_FP8_MAX;
-                scale[i] = s;
-                inv_scale[i] = 1.f / s;
-            }
-            sh[i] = s;
+    for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    if (t == 0) {
+        float m = 0.f;
+        for (int w_ = 0; w_ < 16; ++w_) m = fmaxf(m, red[w_]);
+        if (m > 0.f) {
+            const float s_ = headroom * m / CVAE_FP8_MAX;
+            __hip_atomic_store(scale + i, s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(inv_scale + i, 1.f / s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left this CU before the ticket says so
+        const unsigned got = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (got == (unsigned)n - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (lane < li.count) {
-        dscale[2 * lane] = sh[li.in[lane]] * sh[li.w[lane]];
-        dscale[2 * lane + 1] = li.out[lane] >= 0 ? 1.f / sh[li.out[lane]] : 0.f;
+    if (last && li.count > 0) {
+        if (t < li.count) {
+            const float si = __hip_atomic_load(scale + li.in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float sw = __hip_atomic_load(scale + li.w[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dscale[2 * t] = si * sw;
+            dscale[2 * t + 1] = li.out[t] >= 0 ? 1.f / __hip_atomic_load(scale + li.out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
     }
+    if (last && t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // max |x| of a tensor into CVAE_AMAX_SLOTS words (calibration of the first step's scales; the training step records its amax in the producers' epilogues)
@@ -1273,7 +1261,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ sr
     float amx = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         amx = fmaxf(amx, fabsf(dtype == CVAE_BF16 ? to_f32(((const bf16*)src)[i]) : ((const float*)src)[i]));
-    amax_publish(slots, amx, blockIdx.x + (threadIdx.x >> 6));
+    __shared__ float red[4];
+    amax_publish_wg(slots, amx, blockIdx.x, red);
 }
 
 // All conv weights of a model packed in ONE launch (the table rides in the kernel arguments): the per-step re-pack of the
@@ -1315,6 +1304,12 @@ struct PairTable {
     void* up[PAIR_MAX];
     int Cs[PAIR_MAX], Cl[PAIR_MAX], blk_start[PAIR_MAX + 1];
     int count;
+    // fp8 training forward: f8dir 1 / 2 = the `down` / `up` panel of this weight is written as fp8 codes of w * *inv_scale ([tap][C_in / 32][C_out][32],
+    // into f8out) INSTEAD of its bf16 panel (the forward product reads the fp8 one; the other direction serves the bf16 backward pass); amax records max |w|
+    int f8dir[PAIR_MAX];
+    fp8* f8out[PAIR_MAX];
+    const float* inv_scale[PAIR_MAX];
+    unsigned* amax[PAIR_MAX];
 };
 template <typename T, int TAPS>
 __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(PairTable tb) {
@@ -1328,16 +1323,20 @@ __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(PairTable tb) {
     const int nclt = Cl / 16, ncst = Cs / 16;
     const int cst = blk / nclt, clt = blk % nclt, cs0 = cst * 16, cl0 = clt * 16;
     const float* w = tb.w[ti];
+    const int f8dir = tb.f8dir[ti];
+    float amx = 0.f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int i = threadIdx.x + it * 256, f = i & 3, cl = (i >> 2) & 15, cs = i >> 6;
         const float4 v = *(const float4*)(w + ((size_t)(cs0 + cs) * Cl + cl0 + cl) * TAPS + tq * TT + 4 * f);
         float* d = tile + (cs * 17 + cl) * TP + 4 * f;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     __syncthreads();
     T* od = (T*)tb.down[ti];
     T* ou = (T*)tb.up[ti];
+    const float mul8 = f8dir ? tb.inv_scale[ti][0] : 1.f;
     // per tap both panels are 256 contiguous elements ([16][16]); a thread writes 8 of them (16 bytes bf16) for one of 8 taps at a time
     const int tg = threadIdx.x >> 5, e0 = (threadIdx.x & 31) * 8, a = e0 >> 4, b0 = e0 & 15;
 #pragma unroll
@@ -1352,8 +1351,26 @@ __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(PairTable tb) {
         T* pd = od + ((size_t)(tap * nclt + clt) * Cs + cs0 + a) * 16 + b0;
         T* pu = ou + ((size_t)(tap * ncst + cst) * Cl + cl0 + a) * 16 + b0;
         constexpr int NU = (8 * sizeof(T)) / 16;
+        if (f8dir != 1) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) { ((uint4*)pd)[u] = ((const uint4*)vd)[u]; ((uint4*)pu)[u] = ((const uint4*)vu)[u]; }
+            for (int u = 0; u < NU; ++u) ((uint4*)pd)[u] = ((const uint4*)vd)[u];
+        }
+        if (f8dir != 2) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) ((uint4*)pu)[u] = ((const uint4*)vu)[u];
+        }
+        if (f8dir) {                                         // 32-channel chunks: this 16-wide tile is one half of a chunk row
+            float v8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v8[q] = f8dir == 1 ? tile[(a * 17 + b0 + q) * TP + tl] : tile[((b0 + q) * 17 + a) * TP + tl];
+            fp8* p8 = f8dir == 1 ? tb.f8out[ti] + ((size_t)(tap * (Cl / 32) + (cl0 >> 5)) * Cs + cs0 + a) * 32 + (cl0 & 16) + b0
+                                 : tb.f8out[ti] + ((size_t)(tap * (Cs / 32) + (cs0 >> 5)) * Cl + cl0 + a) * 32 + (cs0 & 16) + b0;
+            *(uint2*)p8 = pack8_fp8(v8, mul8);
+        }
+    }
+    if (f8dir && tb.amax[ti]) {                              // uniform over the workgroup
+        __syncthreads();
+        amax_publish_wg(tb.amax[ti], amx, blockIdx.x, tile);
     }
 }
 
@@ -1765,7 +1782,7 @@ bool geom_ok(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t 
 
 // C1 kernels live in conv_c1.hip
 int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
-                      int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
+                      int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, F8Side f8 = F8Side{nullptr, nullptr, nullptr});
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd);
@@ -1841,8 +1858,11 @@ extern "C" int cvae_conv_pack_weights(const float* const* w, void* const* packed
     return CVAE_OK;
 }
 
-extern "C" int cvae_conv_pack_weight_pairs(const float* const* w, void* const* packed_down, void* const* packed_up, const int64_t* Cs, const int64_t* Cl,
-                                           int count, int nd, int dtype, void* stream) {
+// channel counts an fp8 product accepts (cvae_conv_fp8): conv C_in % 32, C_out % 64; ConvTranspose C_in % 32, C_out % 32, C_out > 1
+static bool fp8_pack_ok(int64_t Cs, int64_t Cl, int for_up) { return for_up ? (Cs % 32 == 0 && Cl % 32 == 0 && Cl > 1) : (Cl % 32 == 0 && Cs % 64 == 0); }
+extern "C" int cvae_conv_pack_weight_pairs_f8(const float* const* w, void* const* packed_down, void* const* packed_up, const int64_t* Cs, const int64_t* Cl,
+                                              const int* f8dir, void* const* f8out, const float* const* inv_scale_dev, void* const* amax_slots,
+                                              int count, int nd, int dtype, void* stream) {
     if ((nd != 2 && nd != 3) || count < 0) return CVAE_E_BADSHAPE;
     if (count == 0) return CVAE_OK;
     if (!w || !packed_down || !packed_up || !Cs || !Cl) return CVAE_E_NULLPTR;
@@ -1856,8 +1876,17 @@ extern "C" int cvae_conv_pack_weight_pairs(const float* const* w, void* const* p
             const int64_t cs = Cs[c0 + i], cl = Cl[c0 + i];
             if (cs <= 0 || cl <= 0) return CVAE_E_BADSHAPE;
             if (cs % 16 || cl % 16) return CVAE_E_UNSUPPORTED;
-            if (!w[c0 + i] || !packed_down[c0 + i] || !packed_up[c0 + i]) return CVAE_E_NULLPTR;
+            const int fd = f8dir ? f8dir[c0 + i] : 0;
+            if (fd < 0 || fd > 2) return CVAE_E_BADSHAPE;
+            if (fd) {
+                if (dtype != CVAE_BF16) return CVAE_E_DTYPE;
+                if (!fp8_pack_ok(cs, cl, fd == 2)) return CVAE_E_UNSUPPORTED;
+                if (!f8out || !f8out[c0 + i] || !inv_scale_dev || !inv_scale_dev[c0 + i]) return CVAE_E_NULLPTR;
+            }
+            if (!w[c0 + i] || (fd != 1 && !packed_down[c0 + i]) || (fd != 2 && !packed_up[c0 + i])) return CVAE_E_NULLPTR;
             tb.w[i] = w[c0 + i]; tb.down[i] = packed_down[c0 + i]; tb.up[i] = packed_up[c0 + i]; tb.Cs[i] = (int)cs; tb.Cl[i] = (int)cl;
+            tb.f8dir[i] = fd; tb.f8out[i] = fd ? (fp8*)f8out[c0 + i] : nullptr; tb.inv_scale[i] = fd ? inv_scale_dev[c0 + i] : nullptr;
+            tb.amax[i] = (fd && amax_slots) ? (unsigned*)amax_slots[c0 + i] : nullptr;
             tb.blk_start[i] = (int)blocks;
             blocks += (cs / 16) * (cl / 16) * tsplit;
             if (blocks > (1 << 30)) return CVAE_E_BADSHAPE;
@@ -1876,6 +1905,10 @@ extern "C" int cvae_conv_pack_weight_pairs(const float* const* w, void* const* p
         CVAE_CHECK_LAUNCH();
     }
     return CVAE_OK;
+}
+extern "C" int cvae_conv_pack_weight_pairs(const float* const* w, void* const* packed_down, void* const* packed_up, const int64_t* Cs, const int64_t* Cl,
+                                           int count, int nd, int dtype, void* stream) {
+    return cvae_conv_pack_weight_pairs_f8(w, packed_down, packed_up, Cs, Cl, nullptr, nullptr, nullptr, nullptr, count, nd, dtype, stream);
 }
 
 #define GEOM_INIT() ConvGeom g{(int)B, (int)sd, (int)sh, (int)sw, (int)Cs, (int)ld, (int)lh, (int)lw, (int)Cl, 0, 0, 0}
@@ -1929,6 +1962,15 @@ extern "C" int cvae_conv_down_image(const void* L, int l_dtype, const float* w, 
     if (!L || !w || !S) return CVAE_E_NULLPTR;
     if (!cvae_conv_image_supported(L, lw, l_dtype, dtype)) return CVAE_E_UNSUPPORTED;
     return cvae_conv_down_c1(L, l_dtype, w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, (hipStream_t)stream);
+}
+extern "C" int cvae_conv_down_image_f8(const void* L, int l_dtype, const float* w, const float* bias, void* S, void* S8, const float* inv_scale_dev, void* amax_slots,
+                                       int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int act, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, 1, nd)) return CVAE_E_BADSHAPE;
+    if (l_dtype != CVAE_F32 && l_dtype != CVAE_BF16) return CVAE_E_DTYPE;
+    if (B == 0) return CVAE_OK;
+    if (!L || !w || !S || (S8 && !inv_scale_dev)) return CVAE_E_NULLPTR;
+    if (!cvae_conv_image_supported(L, lw, l_dtype, CVAE_BF16) && l_dtype != CVAE_BF16) return CVAE_E_UNSUPPORTED;
+    return cvae_conv_down_c1(L, l_dtype, w, bias, nullptr, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, CVAE_BF16, act, (hipStream_t)stream, F8Side{inv_scale_dev, (fp8*)S8, (unsigned*)amax_slots});
 }
 extern "C" int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, void* stream) {
@@ -2107,7 +2149,8 @@ __global__ void quantize_fp8_kernel(const void* __restrict__ src, int src_dtype,
         amx = fmaxf(amx, fabsf(v));
         dst[i] = from_f32<fp8>(v * mul);
     }
-    if (amax) amax_publish(amax, amx, blockIdx.x + (threadIdx.x >> 6));
+    __shared__ float red[4];
+    if (amax) amax_publish_wg(amax, amx, blockIdx.x, red);
 }
 extern "C" int cvae_quantize_fp8(const void* src, int src_dtype, void* dst, int64_t n, float inv_scale, void* stream) {
     if (n < 0 || !(inv_scale > 0.f)) return CVAE_E_BADSHAPE;
@@ -2136,7 +2179,6 @@ extern "C" int cvae_absmax(const void* src, int dtype, int64_t n, void* amax_slo
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
-static bool fp8_pack_ok(int64_t Cs, int64_t Cl, int for_up) { return for_up ? (Cs % 32 == 0 && Cl % 32 == 0 && Cl > 1) : (Cl % 32 == 0 && Cs % 64 == 0); }
 extern "C" int cvae_conv_pack_weight_fp8(const float* w, void* packed, int64_t Cs, int64_t Cl, int nd, int for_up, float inv_scale, void* stream) {
     if ((nd != 2 && nd != 3) || Cs <= 0 || Cl <= 0 || !(inv_scale > 0.f)) return CVAE_E_BADSHAPE;
     if (!fp8_pack_ok(Cs, Cl, for_up)) return CVAE_E_UNSUPPORTED;      // what cvae_conv_fp8 accepts
@@ -2173,17 +2215,17 @@ extern "C" int cvae_conv_pack_weights_fp8(const float* const* w, void* const* pa
     return CVAE_OK;
 }
 extern "C" int cvae_fp8_scale_update(void* amax_slots, float* scale, float* inv_scale, int n, float headroom, const int* layer_in, const int* layer_w, const int* layer_out,
-                                     int n_layers, float* dscale, void* stream) {
-    if (n < 0 || n > 64 || n_layers < 0 || n_layers > F8LAYER_MAX || !(headroom > 0.f)) return CVAE_E_BADSHAPE;
+                                     int n_layers, float* dscale, void* ticket, void* stream) {
+    if (n < 0 || n > 4096 || n_layers < 0 || n_layers > F8LAYER_MAX || !(headroom > 0.f)) return CVAE_E_BADSHAPE;
     if (n == 0) return CVAE_OK;
-    if (!amax_slots || !scale || !inv_scale || (n_layers && (!layer_in || !layer_w || !layer_out || !dscale))) return CVAE_E_NULLPTR;
+    if (!amax_slots || !scale || !inv_scale || !ticket || (n_layers && (!layer_in || !layer_w || !layer_out || !dscale))) return CVAE_E_NULLPTR;
     F8LayerIdx li;
     li.count = n_layers;
     for (int l = 0; l < n_layers; ++l) {
         if (layer_in[l] < 0 || layer_in[l] >= n || layer_w[l] < 0 || layer_w[l] >= n || layer_out[l] >= n) return CVAE_E_BADSHAPE;
         li.in[l] = layer_in[l]; li.w[l] = layer_w[l]; li.out[l] = layer_out[l];
     }
-    hipLaunchKernelGGL(fp8_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned*)amax_slots, scale, inv_scale, n, headroom, li, dscale);
+    hipLaunchKernelGGL(fp8_scale_update_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, (unsigned*)amax_slots, scale, inv_scale, n, headroom, li, dscale, (unsigned*)ticket);
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }
@@ -2196,13 +2238,19 @@ static int conv_fp8_t(const void* in, const void* w, const float* bias, void* ou
     const int Cout = UP ? g.Cl : g.Cs;
     const bool wide = (Cout % 64) == 0;
     // the bf16 launches' tile shapes: 64-channel tiles as (K split) x (N sub-tile) waves with the per-wave weight fetch, 32-channel tiles as 4 x 1 waves on LDS panels
-#define F8L(WM, WN, MI, TS, EPI) launch_data_epi<f8x2, ND, UP, WM, WN, MI, 1, EPI, 1, TO, (CVAE_BDIRECT && WM <= 2), TS>(in, w, bias, nullptr, out, g, act, ws, wsb, st, acc_scale, out_scale, f8)
-#define F8E(WM, WN, MI, TS) (act == CVAE_ACT_NONE ? F8L(WM, WN, MI, TS, 0) : (act == CVAE_ACT_RELU ? F8L(WM, WN, MI, TS, 1) : F8L(WM, WN, MI, TS, 2)))
+#ifndef CVAE_F8_FORM
+#define CVAE_F8_FORM 0      // 64-channel tiles: 0 = (K split) x (N sub-tile) waves with the per-wave weight fetch (the bf16 form), 1 = 2 x 2 waves on LDS weight panels,
+#endif                      // 2 = 2 x 2 waves with the per-wave fetch
+#define F8L(WM, WN, MI, TS, BDX, EPI) launch_data_epi<f8x2, ND, UP, WM, WN, MI, 1, EPI, 1, TO, BDX, TS>(in, w, bias, nullptr, out, g, act, ws, wsb, st, acc_scale, out_scale, f8)
+#define F8E(WM, WN, MI, TS, BDX) (act == CVAE_ACT_NONE ? F8L(WM, WN, MI, TS, BDX, 0) : (act == CVAE_ACT_RELU ? F8L(WM, WN, MI, TS, BDX, 1) : F8L(WM, WN, MI, TS, BDX, 2)))
     if (wide) {
-        if constexpr (ND == 3) return F8E(1, 2, 4, 2);
-        else return F8E(2, 2, 2, 1);
+        // measured (rocprofv3 device durations, 4 x 128^3 shapes, profiles/r03_fp8_forms.txt): the `down` products want their weights on LDS panels — the
+        // per-wave fetch form needs > 256 VGPRs with 8-register fp8 operands (59 spilled; enc2 57 us against 36 us) — the `up` products keep the bf16
+        // launch's (K split) x (N sub-tile) waves with the per-wave fetch (dec1 9.9 vs 11.2 us, dec2 8.1 vs 8.4 us)
+        if constexpr (UP && ND == 3 && CVAE_F8_FORM == 0) return F8E(1, 2, 4, 2, true);
+        else return F8E(2, 2, 2, 1, (CVAE_F8_FORM == 2));
     }
-    if constexpr (UP) return F8E(4, 1, 2, 1);
+    if constexpr (UP) return F8E(4, 1, 2, 1, false);
     else return CVAE_E_UNSUPPORTED;
 #undef F8E
 #undef F8L

@@ -29,7 +29,13 @@ class _ConvBase:
     _nd = 2
     _fn = ops.ConvDown
 
-    def forward_cl(self, x_cl, act=None, in_is_relu_out=False, grad_premasked=False, packed=None, out_dtype=None):
+    def forward_cl(self, x_cl, act=None, in_is_relu_out=False, grad_premasked=False, packed=None, out_dtype=None, f8=None):
+        """f8 (training forward on fp8 operands, causal_vae_amd.fp8): dict(xq, wq, dscale, want_out8, amax); the layer leaves the codes of its
+        result in f8["y8"] when asked.  The backward pass is the bf16 one either way."""
+        if f8 is not None:
+            if self._fn is ops.ConvDown:
+                return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked, packed, out_dtype, f8)
+            return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked, packed, f8)
         if out_dtype is not None:
             return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked, packed, out_dtype)
         return self._fn.apply(x_cl, self.weight, self.bias, self._nd, act, in_is_relu_out, grad_premasked, packed)
@@ -176,23 +182,32 @@ class ConvStack(nn.Sequential):
     def conv_weights(self):
         return [m.weight for m in self if isinstance(m, _ConvBase)]
 
-    def features_cl(self, x, packed=None):
+    def features_cl(self, x, packed=None, f8=None):
         """Run the conv chain; returns the last activation channels-last (compute dtype) and the layers left over.
-        `packed`: this stack's entries of an ops.pack_weights call made by the caller (one launch for the whole model)."""
+        `packed`: this stack's entries of an ops.pack_weights call made by the caller (one launch for the whole model).
+        f8: a causal_vae_amd.fp8.Fp8Forward whose "enc" layers run their forward product on fp8 operands."""
         mods = list(self)
         convs = [m for m in mods if isinstance(m, _ConvBase)]
         if not convs or x.shape[1] != convs[0].in_channels:
             raise RuntimeError(f"expected input with {convs[0].in_channels if convs else '?'} channels, got {tuple(x.shape)}")
         h, first_dtype = _image_cl(x, self.compute_dtype)
         packed = iter(packed if packed is not None else ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))
-        i, prev_act = 0, None
+        i, prev_act, j, h8 = 0, None, 0, None
         while i < len(mods) and isinstance(mods[i], _ConvBase):
             act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
+            rec = f8.layer("enc", j) if f8 is not None else None
             # every consumer of a ReLU output inside this stack (next conv, final pool) folds that ReLU's mask
-            h = mods[i].forward_cl(h, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu"), packed=next(packed),
-                                   out_dtype=first_dtype if i == 0 else None)
+            if rec is not None:
+                h, h8 = f8.run(rec, mods[i], h, h8, act, prev_act == "relu", act == "relu", next(packed))
+            else:
+                # a bf16 layer in front of an fp8 one leaves the codes of its result itself when it can (the image layer's kernel): no quantise pass
+                side = f8.side_for("enc", j + 1, mods[i], h, first_dtype if i == 0 else None) if f8 is not None else None
+                h = mods[i].forward_cl(h, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu"), packed=next(packed),
+                                       out_dtype=first_dtype if i == 0 else None, f8=side)
+                h8 = side.get("y8") if side is not None else None
             prev_act = act
             i += 2 if act else 1
+            j += 1
         return h, mods[i:], prev_act
 
     def _pooled(self, x):
@@ -226,20 +241,26 @@ class DeconvStack(nn.Sequential):
     def conv_weights(self):
         return [m.weight for m in self if isinstance(m, _ConvBase)]
 
-    def forward_from_cl(self, x, packed=None):
-        """The deconv chain on an input that is already channels-last in the compute dtype."""
+    def forward_from_cl(self, x, packed=None, f8=None):
+        """The deconv chain on an input that is already channels-last in the compute dtype.  f8: a causal_vae_amd.fp8.Fp8Forward whose "dec"
+        layers run their forward product on fp8 operands."""
         mods = list(self)
         convs = [m for m in mods if isinstance(m, _ConvBase)]
         packed = iter(packed if packed is not None else ops.pack_weights([m.weight for m in convs], convs[0]._nd, self.compute_dtype))
-        i, prev_act = 0, None
+        i, prev_act, j, x8 = 0, None, 0, None
         while i < len(mods):
             if not isinstance(mods[i], _ConvBase):
                 raise CvaeError(f"DeconvStack: unexpected layer {type(mods[i]).__name__} at index {i}")
             act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
             nxt = i + (2 if act else 1)
-            x = mods[i].forward_cl(x, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu" and nxt < len(mods)), packed=next(packed))
+            rec = f8.layer("dec", j) if f8 is not None else None
+            if rec is not None:
+                x, x8 = f8.run(rec, mods[i], x, x8, act, prev_act == "relu", act == "relu" and nxt < len(mods), next(packed))
+            else:
+                x, x8 = mods[i].forward_cl(x, act=act, in_is_relu_out=(prev_act == "relu"), grad_premasked=(act == "relu" and nxt < len(mods)), packed=next(packed)), None
             prev_act = act
             i = nxt
+            j += 1
         return x
 
     def forward(self, h):
@@ -258,7 +279,7 @@ class DeconvStack(nn.Sequential):
         with torch.no_grad():
             for j, (i, conv) in enumerate(convs):
                 act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
-                if conv.weight.shape[1] > 1 and conv.weight.shape[0] % 16 == 0 and conv.weight.shape[1] % 32 == 0:
+                if conv.weight.shape[1] > 1 and conv.weight.shape[0] % 32 == 0 and conv.weight.shape[1] % 32 == 0:
                     sx = max(float(x.float().abs().max()), 1e-12) * headroom / ops.FP8_MAX
                     sw = max(float(conv.weight.abs().max()), 1e-12) / ops.FP8_MAX
                     plan.append(dict(index=i, act=act, sx=sx, sw=sw, wq=ops.pack_weight_fp8(conv.weight.detach(), nd, True, sw)))

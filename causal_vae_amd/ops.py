@@ -310,26 +310,39 @@ def pack_weight(w, nd, for_up, dtype):
     return out
 
 
-def pack_weights(weights, nd, dtype):
+def pack_weights(weights, nd, dtype, f8spec=None):
     """Pack the weights of several conv layers for BOTH directions in one launch (cvae_conv_pack_weight_pairs).
-    Returns [(packed_down, packed_up)] per weight; a Cl == 1 layer gets its fp32 weight back for both (not packed)."""
+    Returns [(packed_down, packed_up)] per weight; a Cl == 1 layer gets its fp32 weight back for both (not packed).
+    f8spec (fp8 training forward, causal_vae_amd.fp8): {id(weight): (f8dir, f8out, inv_scale_dev, amax)} — that weight's forward-direction panel
+    (f8dir 1 = down, 2 = up) is written as fp8 codes into f8out instead of bf16 (its entry in the returned pair is None), max |w| recorded."""
     import ctypes as C
-    outs, ws, pd, pu, cs, cl = [], [], [], [], [], []
-    for w in weights:
-        w = w.contiguous()
+    outs, ws, pd, pu, cs, cl, fd, fo, fi, fa = [], [], [], [], [], [], [], [], [], []
+    for w0 in weights:
+        w = w0.contiguous()
         Cs, Cl = w.shape[0], w.shape[1]
         if Cl == 1:
             outs.append((w, w))
             continue
         n = Cs * Cl * _taps(nd)
-        both = torch.empty(2 * n, dtype=dtype, device=w.device)
-        d, u = both[:n], both[n:]
+        spec = f8spec.get(id(w0)) if f8spec else None
+        if spec is not None:
+            one = torch.empty(n, dtype=dtype, device=w.device)
+            d, u = (None, one) if spec[0] == 1 else (one, None)
+        else:
+            both = torch.empty(2 * n, dtype=dtype, device=w.device)
+            d, u = both[:n], both[n:]
         outs.append((d, u))
-        ws.append(w.data_ptr()); pd.append(d.data_ptr()); pu.append(u.data_ptr()); cs.append(Cs); cl.append(Cl)
+        ws.append(w.data_ptr()); pd.append(d.data_ptr() if d is not None else None); pu.append(u.data_ptr() if u is not None else None); cs.append(Cs); cl.append(Cl)
+        fd.append(spec[0] if spec else 0); fo.append(spec[1].data_ptr() if spec else None); fi.append(spec[2].data_ptr() if spec else None)
+        fa.append(spec[3].data_ptr() if (spec and spec[3] is not None) else None)
     k = len(ws)
     if k:
-        check(lib.cvae_conv_pack_weight_pairs((C.c_void_p * k)(*ws), (C.c_void_p * k)(*pd), (C.c_void_p * k)(*pu), (C.c_int64 * k)(*cs), (C.c_int64 * k)(*cl),
-                                              k, nd, L.dtype_code(dtype), stream()), "conv_pack_weight_pairs")
+        vp = lambda v: (C.c_void_p * k)(*v)
+        if any(fd):
+            check(lib.cvae_conv_pack_weight_pairs_f8(vp(ws), vp(pd), vp(pu), (C.c_int64 * k)(*cs), (C.c_int64 * k)(*cl), (C.c_int * k)(*fd), vp(fo), vp(fi), vp(fa),
+                                                     k, nd, L.dtype_code(dtype), stream()), "conv_pack_weight_pairs_f8")
+        else:
+            check(lib.cvae_conv_pack_weight_pairs(vp(ws), vp(pd), vp(pu), (C.c_int64 * k)(*cs), (C.c_int64 * k)(*cl), k, nd, L.dtype_code(dtype), stream()), "conv_pack_weight_pairs")
     return outs
 
 
@@ -531,15 +544,33 @@ class ConvDown(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None, out_dtype=None):
+    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None, out_dtype=None, f8=None):
         """out_dtype (single-channel image layer only): compute / output dtype when it differs from x's — the fp32 input batch of a bf16 model
-        is read as it is, without a cast pass."""
+        is read as it is, without a cast pass.
+        f8 (causal_vae_amd.fp8): the forward product on fp8 operands — dict(xq = codes of x, wq = fp8 weight panels, dscale, want_out8, amax); the
+        codes of the result are left in f8["y8"].  x (bf16) is still what the backward pass reads."""
         L.require_gpu(x, weight, bias)
         Cs = weight.shape[0]
         if out_dtype is not None and out_dtype == x.dtype:
             out_dtype = None
-        wp = packed[0] if packed is not None else pack_weight(weight, nd, False, out_dtype or x.dtype)
-        y = _conv_down(x, wp, bias, None, Cs, nd, act, out_dtype)
+        if f8 is not None and f8.get("side"):
+            # the single-channel image layer of an fp8 forward: bf16 arithmetic as always, and the result a second time as fp8 codes (+ its amax)
+            # for the fp8 conv that follows (cvae_conv_down_image_f8)
+            B, ld, lh, lw, Cl = _cl_dims(x)
+            if Cl != 1 or (out_dtype or x.dtype) != torch.bfloat16:
+                raise L.CvaeError("the fp8 side output exists for the single-channel image layer of a bf16 model only")
+            sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
+            y = _empty((B, sd, sh, sw, Cs), torch.bfloat16, x)
+            y8 = torch.empty((B, sd, sh, sw, Cs), dtype=torch.uint8, device=x.device)
+            check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down_image_f8, ptr(x), L.dtype_code(x.dtype), ptr(weight.contiguous()), ptr(bias),
+                          ptr(y), ptr(y8), ptr(f8["inv_scale"]), ptr(f8.get("amax")), B, sd, sh, sw, Cs, ld, lh, lw, nd, L.act_code(act), stream()), "conv_down_image_f8")
+            f8["y8"] = y8
+        elif f8 is not None:
+            res = conv_fp8(False, f8["xq"], f8["wq"], bias, Cs, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"))
+            y, f8["y8"] = res if isinstance(res, tuple) else (res, None)
+        else:
+            wp = packed[0] if packed is not None else pack_weight(weight, nd, False, out_dtype or x.dtype)
+            y = _conv_down(x, wp, bias, None, Cs, nd, act, out_dtype)
         ctx.save_for_backward(x, weight, y)
         ctx.bias_ref = bias
         ctx.packed_bwd = packed[1] if packed is not None else None
@@ -571,18 +602,22 @@ class ConvDown(torch.autograd.Function):
                 raise L.CvaeError("the image read in its own dtype carries no gradient (cast it first if it needs one)")
             dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None, l_dims=x.shape[1:4])
         fork.join(dw, db)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class ConvUp(torch.autograd.Function):
     """nn.ConvTranspose{2,3}d(k=4, s=2, p=1) + bias + activation on channels-last tensors (flags as ConvDown)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None):
+    def forward(ctx, x, weight, bias, nd, act, in_is_relu_out, grad_premasked, packed=None, f8=None):
         L.require_gpu(x, weight, bias)
         Cl = weight.shape[1]
-        wp = packed[1] if packed is not None else pack_weight(weight, nd, True, x.dtype)
-        y = _conv_up(x, wp, bias, None, Cl, nd, act)
+        if f8 is not None:                                   # forward product on fp8 operands (see ConvDown.forward)
+            res = conv_fp8(True, f8["xq"], f8["wq"], bias, Cl, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"))
+            y, f8["y8"] = res if isinstance(res, tuple) else (res, None)
+        else:
+            wp = packed[1] if packed is not None else pack_weight(weight, nd, True, x.dtype)
+            y = _conv_up(x, wp, bias, None, Cl, nd, act)
         ctx.save_for_backward(x, weight, y)
         ctx.bias_ref = bias
         ctx.packed_bwd = packed[0] if packed is not None else None
@@ -612,7 +647,7 @@ class ConvUp(torch.autograd.Function):
             wp_dn = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, False, g.dtype)
             dx = _conv_down(g, wp_dn, None, x if in_relu else None, weight.shape[0], nd, None)
         fork.join(dw, db)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ fp8 inference (decode only)
@@ -642,7 +677,7 @@ def conv_up_fp8(Sq, wq, bias, Cl, nd, act, acc_scale, out_scale=None):
     return conv_fp8(True, Sq, wq, bias, Cl, nd, act, acc_scale=acc_scale, out8_scale=out_scale, codes_only=out_scale is not None)
 
 
-AMAX_SLOTS = 64          # CVAE_AMAX_SLOTS
+AMAX_SLOTS = 4096        # CVAE_AMAX_SLOTS
 
 
 def conv_fp8(up, xq, wq, bias, Cout, nd, act, acc_scale=None, out8_scale=None, codes_only=False, dscale=None, want_out8=False, amax=None):
@@ -723,12 +758,13 @@ class Fp8Scales:
         self.scale = torch.ones(self.n, dtype=torch.float32, device=device)
         self.inv_scale = torch.ones(self.n, dtype=torch.float32, device=device)
         self.dscale = torch.zeros(max(len(self.layers), 1), 2, dtype=torch.float32, device=device)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=device)
         k = len(self.layers)
         self._li = [(C_.c_int * max(k, 1))(*([l[j] for l in self.layers] or [0])) for j in range(3)]
 
     def update(self):
         check(lib.cvae_fp8_scale_update(ptr(self.amax), ptr(self.scale), ptr(self.inv_scale), self.n, self.headroom, self._li[0], self._li[1], self._li[2],
-                                        len(self.layers), ptr(self.dscale), stream()), "fp8_scale_update")
+                                        len(self.layers), ptr(self.dscale), ptr(self.ticket), stream()), "fp8_scale_update")
 
     def state(self):
         return {"scale": self.scale.detach().cpu().clone(), "amax": self.amax.detach().cpu().clone()}

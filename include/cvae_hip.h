@@ -138,10 +138,11 @@ int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, 
  *   cvae_fp8_scale_update       once per step: for each of n tracked tensors, scale[i] = headroom * amax_i / 448 (amax_i = the largest value
  *                               recorded in its CVAE_AMAX_SLOTS words since the last call; the words are cleared; nothing recorded = scale kept),
  *                               inv_scale[i] = 1 / scale[i]; then for each fp8 layer l: dscale[2l] = scale[layer_in[l]] * scale[layer_w[l]],
- *                               dscale[2l + 1] = 1 / scale[layer_out[l]] (0 when layer_out[l] < 0).  layer_* are HOST arrays.
+ *                               dscale[2l + 1] = 1 / scale[layer_out[l]] (0 when layer_out[l] < 0).  layer_* are HOST arrays; `ticket` is one device
+ *                               word, zero before the first call (the kernel's workgroups count themselves in on it and the last one resets it).
  * An amax record is CVAE_AMAX_SLOTS unsigned words holding float bits (non-negative floats order like unsigned integers; atomicMax, so the
- * result does not depend on the order of arrival); the caller zero-fills it once. */
-#define CVAE_AMAX_SLOTS 64
+ * result does not depend on the order of arrival; one word per workgroup of the producing launch, modulo the slot count); the caller zero-fills it once. */
+#define CVAE_AMAX_SLOTS 4096
 int cvae_quantize_fp8(const void* src, int src_dtype, void* dst, int64_t n, float inv_scale, void* stream);
 int cvae_quantize_fp8_dev(const void* src, int src_dtype, void* dst, int64_t n, const float* inv_scale_dev, void* amax_slots, void* stream);
 int cvae_absmax(const void* src, int dtype, int64_t n, void* amax_slots, void* stream);
@@ -154,8 +155,18 @@ int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, vo
 int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                      void* stream);
+/* cvae_conv_down_image with bf16 S and the fp8 side channel of a training forward whose next conv runs on fp8 operands: S8 (optional) = fp8(S * *inv_scale_dev),
+ * amax_slots (optional) records max |S|.  Needs the 16-byte-row form (cvae_conv_image_supported). */
+int cvae_conv_down_image_f8(const void* L, int l_dtype, const float* w, const float* bias, void* S, void* S8, const float* inv_scale_dev, void* amax_slots,
+                            int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int act, void* stream);
 int cvae_fp8_scale_update(void* amax_slots, float* scale, float* inv_scale, int n, float headroom, const int* layer_in, const int* layer_w, const int* layer_out,
-                          int n_layers, float* dscale, void* stream);
+                          int n_layers, float* dscale, void* ticket, void* stream);
+/* cvae_conv_pack_weight_pairs for a training step with fp8 forward products: f8dir[i] = 1 / 2 writes the `down` / `up` panel of weight i as fp8 codes of
+ * w * *inv_scale_dev[i] into f8out[i] (layout of cvae_conv_pack_weight_fp8) INSTEAD of its bf16 panel (packed_down[i] / packed_up[i] may then be NULL), and
+ * records max |w| in amax_slots[i] (optional); f8dir[i] = 0 (or f8dir == NULL): both bf16 / fp32 panels as cvae_conv_pack_weight_pairs. */
+int cvae_conv_pack_weight_pairs_f8(const float* const* w, void* const* packed_down, void* const* packed_up, const int64_t* Cs, const int64_t* Cl,
+                                   const int* f8dir, void* const* f8out, const float* const* inv_scale_dev, void* const* amax_slots,
+                                   int count, int nd, int dtype, void* stream);
 /* ---- Exact-2x linear resize (decoder output d x h x w, one channel -> 2d x 2h x 2w; D == d == 1 for 2D) fused with the ELBO ----
  * causal_cascade/models.py:84-87 + train.py:5-17: the resized volume is recomputed from the small tensor wherever it is needed
  * instead of being written and re-read (csrc/recon_loss.hip).  cvae_up2x_supported: 1 when the shapes qualify (w % 4 == 0). */

@@ -568,6 +568,71 @@ def test_fused_adam_load_state_dict_after_capture_reaches_the_replayed_update():
     assert int(opt._step_dev) == 6
 
 
+@pytest.mark.parametrize("B,size", [(2, 64), (4, 128)], ids=["2x64", "4x128"])
+def test_fp8_forward_train_step_close_to_bf16_step(B, size):
+    """BASELINE.json configs[4], train leg: the bf16 step with the forward products of enc_conv[2..6] / dec_conv[0..4] on fp8 (e4m3) operands
+    (model.set_fp8_forward; scaled MFMA, delayed per-tensor scales, bf16 backward) against the bf16 step from the same weights on the same batch
+    (causal_cascade/train.py:19-39).  Stated bounds: ELBO 1e-4 relative (the BASELINE target, here between the two precisions), reconstruction
+    rel-L2 5e-2 (e4m3 carries 3 mantissa bits: 2^-4 per operand, averaged down by the K = 2048-long sums), per-layer gradient rel-L2 as listed —
+    the gradients themselves are bf16 products of (fp8-forward) activations, so they inherit the forward's error through the ReLU masks."""
+    g = torch.Generator().manual_seed(91)
+    x, m = torch.randn(B, 1, size, size, size, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
+    t, eps = torch.randint(0, 19, (B,), generator=g).to(DEV), torch.randn(B, 64, generator=g).to(DEV)
+    res = {}
+    for mode in ("bf16", "fp8"):
+        torch.manual_seed(42)
+        model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+        if mode == "fp8":
+            model.set_fp8_forward(True)
+            model.forward_elbo(x, m, t, eps=eps)                     # step 0 calibrates the scales (bf16 arithmetic)
+            assert model._fp8.calibrated
+        for p in model.parameters():
+            p.grad = None
+        out_cl, m_hat, mu, logvar = model._forward_cl(x, m, t, eps)
+        loss, recon, m_loss, _ = ops_mod.ElboUp2x.apply(out_cl, x, m_hat, m, mu, logvar, 2000.0) if ops_mod.ElboUp2x.supported(out_cl, x) else \
+            ops_mod.Elbo.apply(model._resize_to(out_cl, x), x, m_hat, m, mu, logvar, 2000.0)
+        ops_mod.backward_from(loss)
+        res[mode] = dict(loss=float(loss), out=out_cl.detach().float().cpu(), mu=mu.detach().cpu(), grads={k: p.grad.detach().cpu() for k, p in model.named_parameters()})
+    a, b = res["bf16"], res["fp8"]
+    rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-30))
+    assert abs(b["loss"] - a["loss"]) <= 1e-4 * abs(a["loss"]), (a["loss"], b["loss"])
+    assert rel(b["out"], a["out"]) < 5e-2, rel(b["out"], a["out"])
+    assert rel(b["mu"], a["mu"]) < 5e-2, rel(b["mu"], a["mu"])
+    worst = {}
+    for k in a["grads"]:
+        if k == "mechanism_net.0.bias":                              # true gradient 0 (feeds train-mode BatchNorm): rounding noise in both arms
+            continue
+        worst[k] = rel(b["grads"][k], a["grads"][k])
+    print("fp8-forward vs bf16 gradient rel-L2:", {k: round(v, 4) for k, v in worst.items()})
+    for k, v in worst.items():
+        # Observed at random init (printed above), bounded with ~1.3x margin: the backward pass is the bf16 one applied to fp8-forward activations, so the
+        # difference enters through every ReLU mask and activation the forward changed and grows towards the input end of the backward chain
+        # (the last decoder layers 2e-3 .. 2e-2, the first decoder layer / bottleneck 0.25, the encoder 0.35 - 0.40); the same layers are the widest between
+        # bf16 and the fp32 oracle (BF16_GRAD_REL_L2).  mechanism_net sees no conv activations at all.
+        if k.startswith("mechanism_net"):
+            bound = 1e-3
+        elif k.startswith("enc_conv"):
+            bound = 0.52
+        elif k.startswith(("enc_fc", "fc_", "dec_input", "dec_conv.0")):
+            bound = 0.36
+        elif k.startswith("dec_conv.2"):
+            bound = 0.2
+        else:
+            bound = 0.05
+        assert v < bound, (k, v)
+    cat = lambda gr: torch.cat([v.flatten() for k, v in gr.items() if k != "mechanism_net.0.bias"])
+    ga, gb = cat(a["grads"]), cat(b["grads"])
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert cos > 0.9, cos
+    # delayed scaling keeps the step capturable and stable: three more steps change the scales by less than the headroom
+    s0 = model._fp8.scales.scale.clone()
+    opt = FusedAdam(model.parameters(), lr=1e-4)
+    for _ in range(3):
+        train_step(model, opt, x, m, t, eps=eps)
+    ratio = (model._fp8.scales.scale / s0).cpu()
+    assert float(ratio.max()) < 2.0 and float(ratio.min()) > 0.5, ratio
+
+
 def test_split_backward_capture_matches_eager_steps():
     """GraphedTrainStep(overlap_exchange=True): the backward captured in two graphs around the encoder output (the multi-GPU exchange
     overlap; no process group here, so no exchange happens) == the eager step: losses and weights after 3 + 3 steps, every gradient

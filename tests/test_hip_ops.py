@@ -297,6 +297,33 @@ def test_conv_down_fp8_dual_output_device_scales_and_amax(nd, B, Cl, Cs, lsize, 
     assert abs(rec - float(ref.abs().max())) <= 2.0 ** -7 * float(ref.abs().max()), (rec, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("nd,B,lsize,xdtype", [(3, 2, (32, 32, 64), torch.float32), (3, 1, (16, 24, 40), torch.float32), (2, 2, (48, 64), torch.float32), (3, 2, (16, 16, 32), torch.bfloat16)])
+def test_image_layer_fp8_side_output(nd, B, lsize, xdtype):
+    """cvae_conv_down_image_f8: the single-channel first layer leaves its bf16 result AND the fp8 codes of it (scale read from the device), and records
+    max |result| — the bf16 result is bit-identical to the plain launch, the codes are the e4m3 rounding of the fp32 result."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, *lsize, 1, generator=g).to(DEV).to(xdtype)
+    w = (torch.randn(32, 1, *([4] * nd), generator=g) * 0.2).to(DEV)
+    b = (torch.randn(32, generator=g) * 0.1).to(DEV)
+    if nd == 2:
+        x = x.view(B, 1, *lsize, 1)
+    y_plain = ops.ConvDown.apply(x, w, b, nd, "relu", False, False, None, torch.bfloat16)
+    s8 = 2.0 * float(y_plain.float().abs().max()) / ops.FP8_MAX
+    inv = torch.tensor([1.0 / s8], device=DEV)
+    amax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+    side = dict(side=True, inv_scale=inv, amax=amax)
+    y = ops.ConvDown.apply(x, w, b, nd, "relu", False, False, None, torch.bfloat16, side)
+    assert torch.equal(y, y_plain)
+    y8 = side["y8"]
+    assert y8.dtype == torch.uint8 and y8.shape == y.shape
+    got = _e4m3_decode(y8) * s8
+    ref = y_plain.float().cpu()
+    torch.testing.assert_close(got, ref, rtol=2.0 ** -3, atol=s8 * 2.0 ** -9 * 1.01 + 2.0 ** -8 * float(ref.abs().max()))
+    assert float((got - ref).norm() / ref.norm()) < 2.0 ** -5
+    rec = float(amax.cpu().view(torch.float32).max())
+    assert abs(rec - float(ref.max())) <= 2.0 ** -7 * float(ref.max())
+
+
 def test_fp8_scale_update_and_weight_pack_from_device_scales():
     """cvae_fp8_scale_update: scale = headroom * amax / 448 from the recorded slots (cleared afterwards; a tensor that recorded nothing keeps its scale) and
     the per-layer {s_in * s_w, 1 / s_out} pairs; cvae_conv_pack_weights_fp8: the panels of cvae_conv_pack_weight_fp8 with 1 / s_w read from the device,
@@ -326,6 +353,16 @@ def test_fp8_scale_update_and_weight_pack_from_device_scales():
     for for_up in (False, True):
         out = ops.pack_weights_fp8([w], 3, [for_up], [st.inv_scale[1:2]], [st.amax[1]])[0]
         assert torch.equal(out, ops.pack_weight_fp8(w, 3, for_up, sw))
+        assert abs(float(st.amax[1].cpu().view(torch.float32).max()) - float(w.abs().max())) < 1e-7
+        st.amax.zero_()
+        # the model's one weight-pack launch writes the same fp8 panel in place of the bf16 one of that direction (cvae_conv_pack_weight_pairs_f8)
+        panel = torch.zeros(w.numel(), dtype=torch.uint8, device=DEV)
+        w2 = (torch.randn(128, 64, 4, 4, 4, generator=g) * 0.05).to(DEV)
+        outs = ops.pack_weights([w, w2], 3, torch.bfloat16, f8spec={id(w): (2 if for_up else 1, panel, st.inv_scale[1:2], st.amax[1])})
+        assert torch.equal(panel, ops.pack_weight_fp8(w, 3, for_up, sw))
+        plain = ops.pack_weights([w, w2], 3, torch.bfloat16)
+        assert outs[0][0 if for_up else 1] is not None and outs[0][1 if for_up else 0] is None
+        assert torch.equal(outs[0][0 if for_up else 1], plain[0][0 if for_up else 1]) and torch.equal(outs[1][0], plain[1][0]) and torch.equal(outs[1][1], plain[1][1])
         assert abs(float(st.amax[1].cpu().view(torch.float32).max()) - float(w.abs().max())) < 1e-7
         st.amax.zero_()
 

@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-splitk", action="store_true", help="data kernels: no split-K scratch (unsplit launches)")
     ap.add_argument("--mask", action="store_true", help="data kernels: fuse a ReLU mask of the output's shape (the backward-data form)")
+    ap.add_argument("--fp8", action="store_true", help="forward data kernels with C_in >= 32 on fp8 operands (cvae_conv_fp8: bf16 + fp8 output, amax record), as the fp8 training forward runs them")
+    ap.add_argument("--fp8-plain", action="store_true", help="with --fp8: bf16 output only, no amax")
+    ap.add_argument("--fp8-side", default="both", choices=["both", "out8", "amax"], help="with --fp8: which side outputs ride along")
     args = ap.parse_args()
     if args.no_splitk:
         ops.SPLIT_K = False
@@ -53,7 +56,19 @@ def main():
         Lt = (torch.randn(B, *lp, Cl, device=dev) * 0.5).to(dt)
         w = torch.randn(Cs, Cl, 4, 4, 4, device=dev) * 0.05
         bias_s, bias_l = torch.randn(Cs, device=dev), torch.randn(Cl, device=dev)
-        if kind == "down":
+        if args.fp8 and kind in ("down", "up") and name.endswith(".fwd") and min(Cs, Cl) >= 32:
+            src = Lt if kind == "down" else S
+            xq = ops.quantize_fp8(src.abs(), float(src.abs().max()) / 448.0)
+            wq = ops.pack_weight_fp8(w, 3, kind == "up", float(w.abs().max()) / 448.0)
+            amax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=dev)
+            dsc = torch.tensor([1e-3, 1.0], device=dev)
+            bb = bias_s if kind == "down" else bias_l
+            co = Cs if kind == "down" else Cl
+            if args.fp8_plain:
+                fn = lambda: ops.conv_fp8(kind == "up", xq, wq, bb, co, 3, "relu", dscale=dsc)
+            else:
+                fn = lambda: ops.conv_fp8(kind == "up", xq, wq, bb, co, 3, "relu", dscale=dsc, want_out8=args.fp8_side != "amax", amax=amax if args.fp8_side != "out8" else None)
+        elif kind == "down":
             wp = ops.pack_weight(w, 3, False, dt)
             fn = (lambda: ops._conv_down(Lt, wp, None, S, Cs, 3, None)) if args.mask else (lambda: ops._conv_down(Lt, wp, bias_s, None, Cs, 3, "relu"))
         elif kind == "up":

@@ -3,7 +3,7 @@
 kbench.py's HIP-event timing is host-bound below ~40 us per launch; this reads the device-side durations instead."""
 import collections, csv, glob, os, sys
 
-f = max(glob.glob(os.path.join(sys.argv[1], "*", "*kernel_trace.csv")), key=os.path.getmtime)
+f = max(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     agg[r["Kernel_Name"][:90] + "  grid " + "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

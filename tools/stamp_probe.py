@@ -20,7 +20,15 @@ lp = tuple(2 * s for s in sp)
 S = (torch.randn(B, *sp, Cs, device="cuda") * 0.5).to(dt)
 Lt = (torch.randn(B, *lp, Cl, device="cuda") * 0.5).to(dt)
 w = torch.randn(Cs, Cl, 4, 4, 4, device="cuda") * 0.05
-if kind == "down":
+FP8 = "--fp8" in sys.argv            # the fp8 forward form of the same product (dual output + amax, as in the training step)
+if FP8 and kind in ("down", "up"):
+    src = Lt if kind == "down" else S
+    xq = ops.quantize_fp8(src.abs(), float(src.abs().max()) / 448.0)
+    wq = ops.pack_weight_fp8(w, 3, kind == "up", float(w.abs().max()) / 448.0)
+    amax = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+    plain = "--plain" in sys.argv      # no second output, no amax
+    fn = lambda: ops.conv_fp8(kind == "up", xq, wq, None, Cs if kind == "down" else Cl, 3, "relu", acc_scale=1e-3, out8_scale=None if plain else 1.0, amax=None if plain else amax)
+elif kind == "down":
     wp = ops.pack_weight(w, 3, False, dt); fn = lambda: ops._conv_down(Lt, wp, None, S, Cs, 3, None)
 elif kind == "up":
     wp = ops.pack_weight(w, 3, True, dt); fn = lambda: ops._conv_up(S, wp, None, Lt, Cl, 3, None)
