@@ -727,11 +727,14 @@ def test_fp8_and_bf16_sweep_decode_close_to_fp32_decode():
     zd, md = z.to(DEV), m.to(DEV)
     ref = batched_counterfactual(model, zd, md, feats, vals)
     assert ref.shape == (4, 12, 5, 1, 64, 64, 64)
-    for b, fi, vi in ((3, 11, 4), (2, 6, 1), (0, 0, 0)):
-        m1 = m[b:b + 1].clone(); m1[0, feats[fi]] = vals[vi]
-        torch.testing.assert_close(ref[b, fi, vi].cpu(), ofn.bio_decode(sd, z[b:b + 1], m1, nd=3)[0], rtol=1e-4, atol=1e-5)
+    zr_c, mc_c = sweep_inputs(z, m, feats, vals)
+    ref_rows = ref.reshape(240, 1, 64, 64, 64).cpu()
+    for r0 in range(0, 240, 60):                                   # EVERY row of the fp32 sweep against the oracle's decode of that row
+        torch.testing.assert_close(ref_rows[r0:r0 + 60], ofn.bio_decode(sd, zr_c[r0:r0 + 60], mc_c[r0:r0 + 60], nd=3), rtol=1e-4, atol=1e-5)
+    del ref_rows
     model.set_compute_dtype(torch.bfloat16)
-    b16 = batched_counterfactual(model, zd, md, feats, vals)
+    b16 = batched_counterfactual(model, zd, md, feats, vals, precision="bf16")
+    assert model.dec_conv.compute_dtype == torch.bfloat16
     z_rep, m_cf = sweep_inputs(zd, md, feats, vals)
     plan = model.calibrate_fp8_decoder(z_rep[:60], m_cf[:60])
     assert [e["sx"] is not None for e in plan] == [True, True, True, False]       # the single-channel output layer stays bf16
@@ -751,6 +754,41 @@ def test_fp8_and_bf16_sweep_decode_close_to_fp32_decode():
     assert up.shape == (1, 1, 2, 1, 96, 80, 72)
     one = model.decode(z_rep[77:78], m_cf[77:78], fp8_plan=plan)
     torch.testing.assert_close(one[0], f8.reshape(240, 1, 64, 64, 64)[77], rtol=0, atol=0)
+
+
+def test_counterfactual_effect_is_preserved():
+    """What a counterfactual sweep is FOR is the intervention effect decode(z, m') - decode(z, m) (generate_counterfactual.py:77-99 plots exactly these
+    differences).  Against the CPU oracle's effect, on weights where the effect is >= 1 % of the output norm (dec_input's m-columns scaled by 10: 4.2 %;
+    at random init it is 0.5 %, below bf16 / fp8 resolution — tools/effect_probe.py): the default (fp32) sweep holds 1e-4, bf16 8e-2, fp8 2.5e-1
+    (measured 3.6e-6 / 5.2e-2 / 1.7e-1).  The error of a low-precision sweep relative to an effect of relative size f is eps_decode / f — hence fp32 is
+    batched_counterfactual's default, and it must hold 1e-4 at the untrained model's 0.5 % too."""
+    from causal_vae_amd.counterfactual import batched_counterfactual, sweep_inputs
+    g = torch.Generator().manual_seed(8)
+    z, m = torch.randn(2, 64, generator=g), torch.rand(2, 12, generator=g)
+    feats, vals = [0, 5, 11], [0.0, 1.0]
+    z_rep, m_cf = sweep_inputs(z, m, feats, vals)
+    eff = lambda o: o.reshape(2, len(feats), 2, -1)[:, :, 1] - o.reshape(2, len(feats), 2, -1)[:, :, 0]
+    for gain, bounds in ((10.0, {"fp32": 1e-4, "bf16": 8e-2, "fp8": 2.5e-1}), (1.0, {"fp32": 1e-4})):
+        sd = oracle.init_state_dict("bio3d", seed=42)
+        sd["dec_input.weight"][:, 64:] *= gain
+        ref = ofn.bio_decode(sd, z_rep, m_cf, nd=3)
+        e_ref = eff(ref)
+        frac = float(e_ref.norm() / ref.norm()) * 2 ** 0.5          # effect rows against one decode's rows
+        assert (frac >= 0.01) == (gain == 10.0), frac
+        torch.manual_seed(42)
+        model = CausalBioVAE3D().to(DEV).eval()
+        model.load_state_dict({k: v.to(DEV) for k, v in sd.items()})
+        zd, md = z.to(DEV), m.to(DEV)
+        got = {"fp32": batched_counterfactual(model, zd, md, feats, vals).cpu()}                     # the default IS the exact one
+        if "bf16" in bounds:
+            got["bf16"] = batched_counterfactual(model, zd, md, feats, vals, precision="bf16").cpu()
+            assert model.dec_conv.compute_dtype == torch.float32                                          # restored
+            model.set_compute_dtype(torch.bfloat16)
+            plan = model.calibrate_fp8_decoder(z_rep.to(DEV), m_cf.to(DEV))
+            got["fp8"] = batched_counterfactual(model, zd, md, feats, vals, fp8_plan=plan).cpu()
+        for name, o in got.items():
+            err = float((eff(o) - e_ref).norm() / e_ref.norm())
+            assert err < bounds[name], (gain, name, err, "effect / output", frac)
 
 
 def test_gaussian_head_adversarial_step_matches_oracle():
