@@ -53,7 +53,7 @@ SIGNATURES = {
     "cvae_quantize_fp8_dev": [_p, _i, _p, _i64, _p, _p, _p],
     "cvae_absmax": [_p, _i, _i64, _p, _p],
     "cvae_conv_pack_weights_fp8": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
-    "cvae_conv_fp8": [_i, _p, _p, _p, _p, _i, _p, _p, _f, _f, _p] + [_i64] * 9 + [_i, _i, _p, _sz, _p],
+    "cvae_conv_fp8": [_i, _p, _p, _p, _p, _i, _p, _p, _f, _f, _p] + [_i64] * 9 + [_i, _i, _p, _sz, _i, _p],
     "cvae_fp8_scale_update": [_p, _p, _p, _i, _f, _p, _p, _p, _i, _p, _p, _p],
     "cvae_conv_pack_weight_pairs_f8": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "cvae_conv_down_image_f8": [_p, _i, _p, _p, _p, _p, _p, _p] + [_i64] * 8 + [_i, _i, _p],
@@ -75,9 +75,7 @@ SIGNATURES = {
     "cvae_linear_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
     "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
     "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
-    "cvae_tune_upfull_min_grid": [_i64],
-    "cvae_tune_c1u_walk_min_units": [_i64],
-    "cvae_tune_xpair_min_wgs": [_i64],
+    "cvae_conv_up_variant": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _i, _i, _i64, _p],
     "cvae_linear_fwd_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
     "cvae_linear_bwd_data_bf16": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
     "cvae_linear_bwd_weight_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
@@ -135,7 +133,7 @@ SIGNATURES = {
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
-            "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64, "cvae_tune_upfull_min_grid": _i64, "cvae_tune_c1u_walk_min_units": _i64, "cvae_tune_xpair_min_wgs": _i64, "cvae_channel_sum_workspace_bytes": _sz,
+            "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64, "cvae_channel_sum_workspace_bytes": _sz,
             "cvae_linear_workspace_bytes": _sz, "cvae_reduce_workspace_bytes": _sz, "cvae_bn2d_workspace_bytes": _sz}
 
 for _name, _args in SIGNATURES.items():

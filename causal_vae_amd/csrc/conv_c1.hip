@@ -947,7 +947,6 @@ __global__ __launch_bounds__(256) void wgrad_c1_finish_kernel(const float* __res
     }
 }
 
-static int g_c1u_walk_min_units = CVAE_C1U_WALK_MIN_UNITS;
 
 }  // namespace
 
@@ -1004,14 +1003,9 @@ int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* b
     return CVAE_OK;
 }
 
-int64_t cvae_tune_c1u_walk_min_units(int64_t min_units) {
-    const int64_t prev = g_c1u_walk_min_units;
-    if (min_units > 0 && min_units < ((int64_t)1 << 30)) g_c1u_walk_min_units = (int)min_units;
-    return prev;
-}
-
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
-                    int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream) {
+                    int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, long long walk_units_arg) {
+    const long long walk_min_units = walk_units_arg > 0 ? walk_units_arg : CVAE_C1U_WALK_MIN_UNITS;     // per call (cvae_conv_up_variant), no process-wide state
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
     const int64_t n = B * sd * sh * sw;                     // one thread per (source voxel, channel half)
     if (n >= ((int64_t)1 << 30) || (nd == 3 && ld != 2 * sd) || lh != 2 * sh || lw != 2 * sw) return CVAE_E_UNSUPPORTED;   // exact 2x only (depth counts in 3D)
@@ -1024,8 +1018,8 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
         dim3 mgrid((unsigned)(ntiles < CVAE_C1_MAX_WG ? ntiles : CVAE_C1_MAX_WG), 1, 1);      // a workgroup walks ntiles / grid tiles with one set of weight fragments
         const int epi = CVAE_EPI_OF(act);
 #if CVAE_C1U_WALK
-        if (nd == 3 && ntiles >= 2 * g_c1u_walk_min_units && tiles_d > 1) {   // long z columns: walk them, the shared halo planes stay in LDS
-            int walk = ntiles / g_c1u_walk_min_units;
+        if (nd == 3 && ntiles >= 2 * walk_min_units && tiles_d > 1) {   // long z columns: walk them, the shared halo planes stay in LDS
+            int walk = (int)(ntiles / walk_min_units);
             if (walk > tiles_d) walk = tiles_d;
             const int segs = (tiles_d + walk - 1) / walk;
             const int nunits = (int)B * segs * tiles_h * tiles_w;

@@ -737,8 +737,13 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
 #ifndef CVAE_XPAIR_MIN_WGS
 #define CVAE_XPAIR_MIN_WGS 2048
 #endif
-static long long g_xpair_min_wgs = CVAE_XPAIR_MIN_WGS;
-static long long g_upfull_min_grid = CVAE_UPFULL_MIN_GRID;
+// Kernel-form selection of one `up` launch.  The library picks by launch size (-1 / 0 = automatic); cvae_conv_up_variant and cvae_conv_fp8 let a caller
+// force a form for ONE call — the tests run every narrow case through both forms that way.  No process-wide state.
+struct UpVariant {
+    int upfull = -1;            // conv_up_full_kernel: -1 by grid size (CVAE_UPFULL_MIN_GRID), 0 never, 1 whenever the shape fits it
+    int xpair = -1;             // two samples per tile for layers at most half a tile wide: -1 by grid size (CVAE_XPAIR_MIN_WGS), 0 never, 1 always
+    long long walk_units = 0;   // single-channel output layer: 0 = by launch size (CVAE_C1U_WALK_MIN_UNITS), > 0 = that many units
+};
 
 // Split-K factor for a launch of `nwg` workgroups over `nchunks` channel chunks: the layers with 8^3 / 4^3 grids fill a fraction
 // of the 256 CUs with one long serial K loop each; slicing K puts ~2 workgroups on every CU.  Largest divisor of nchunks <= target.
@@ -757,7 +762,8 @@ static int pick_ksplit(bool up, long long nwg, int nchunks) {
 
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int EPI, int KH = 1, typename TO = T, bool BD = (CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2), int TS = 1, int XB = 1>
 int launch_data_epi(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* workspace,
-                    size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f, F8Side f8 = F8Side{nullptr, nullptr, nullptr}) {
+                    size_t workspace_bytes, hipStream_t stream, float acc_scale = 1.f, float out_scale = 1.f, F8Side f8 = F8Side{nullptr, nullptr, nullptr},
+                    UpVariant var = UpVariant{}) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     using TL = Tile<ND, BM>;
     constexpr int ID = (ND == 3) ? (UP ? TL::TD + 1 : 2 * TL::TD + 2) : 1;
@@ -772,8 +778,8 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     if constexpr (CVAE_XPAIR && XB == 1 && UP && ND == 3 && (TS == 2 || IsF8<T>::value)) {
         // a layer at most half a tile wide, on a launch that fills the chip several times over (the decode sweep's 4^3 -> 8^3 layer): two samples per tile
         const long long wgs = (long long)((md + TL::TD - 1) / TL::TD) * ((mh + TL::TH - 1) / TL::TH) * ((UP ? g.Cl : g.Cs) / BN) * 8 * g.B;
-        if (mw <= TL::TW / 2 && g.B >= 2 && wgs >= g_xpair_min_wgs)
-            return launch_data_epi<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, 2>(in, wp, bias, mask, out, g, act, workspace, workspace_bytes, stream, acc_scale, out_scale, f8);
+        if (mw <= TL::TW / 2 && g.B >= 2 && (var.xpair == 1 || (var.xpair < 0 && wgs >= CVAE_XPAIR_MIN_WGS)))
+            return launch_data_epi<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, 2>(in, wp, bias, mask, out, g, act, workspace, workspace_bytes, stream, acc_scale, out_scale, f8, var);
     }
     auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, XB>;
     static bool attr_set = false;
@@ -805,18 +811,18 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
 }
 
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int TS = 1>
-int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* ws, size_t wsb, hipStream_t stream) {
+int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* ws, size_t wsb, hipStream_t stream, UpVariant var = UpVariant{}) {
     constexpr bool BDX = CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2;
     // 32-channel stages pay where the K loop is long and the grid small (measured: Cin 256: -12 %, 128: -5 %, 64: +2 %)
     if (UP && sizeof(T) == 2 && g.Cs >= 128 && (g.Cs % 32) == 0) {
         constexpr int KH2 = (UP && sizeof(T) == 2) ? 2 : 1;
-        if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-        if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-        return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+        if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
+        if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
+        return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
     }
-    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
-    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream);
+    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
+    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
+    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
 }
 
 // Workspace the split-K path of launch_data would use for this geometry (0: the launch fills the chip without it).
@@ -1097,7 +1103,7 @@ template <typename T, int ND, int WM, int WN, int MI, int NI, int KCH> constexpr
 // Launch of conv_up_full_kernel; CVAE_E_UNSUPPORTED when this (tile, channel count) pair does not fit the LDS (the caller falls back to launch_data<UP>).
 template <typename T, int ND, int WM, int WN, int MI, int NI, int KCH, typename TO = T>
 int launch_up_full(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, hipStream_t stream,
-                   float acc_scale = 1.f, float out_scale = 1.f) {
+                   UpVariant var, float acc_scale = 1.f, float out_scale = 1.f) {
     constexpr size_t LDS = up_full_lds_bytes<T, ND, WM, WN, MI, NI, KCH>();
     if constexpr (LDS > 160 * 1024 || (KCH * 2 * WN * NI * 32) % (WM * WN * 64) != 0) {
         return CVAE_E_UNSUPPORTED;
@@ -1108,7 +1114,7 @@ int launch_up_full(const void* in, const void* wp, const float* bias, const void
         g.tiles_d = (md + TL::TD - 1) / TL::TD; g.tiles_h = (mh + TL::TH - 1) / TL::TH; g.tiles_w = (mw + TL::TW - 1) / TL::TW;
         const long long tiles = (long long)g.tiles_d * g.tiles_h * g.tiles_w;
         const int npar = (ND == 3) ? 8 : 4, nblocks = g.Cl / BN;
-        if (tiles * nblocks * g.B < g_upfull_min_grid) return CVAE_E_UNSUPPORTED;
+        if (var.upfull == 0 || (var.upfull < 0 && tiles * nblocks * g.B < CVAE_UPFULL_MIN_GRID)) return CVAE_E_UNSUPPORTED;
         // parity classes per workgroup: all of them (one halo stage per tile) once the grid has ~2 workgroups per CU without splitting them
         int psplit = 1;
         while (psplit < npar && tiles * nblocks * g.B * psplit < CVAE_UPFULL_MIN_WG) psplit *= 2;
@@ -1137,13 +1143,13 @@ int launch_up_full(const void* in, const void* wp, const float* bias, const void
 // `up` through the whole-K kernel when the input channel count is one it is built for (64 / 128 / 256 where the halo fits): CVAE_E_UNSUPPORTED otherwise.
 template <typename T, int ND, int WM, int WN, int MI, int NI, typename TO = T>
 int try_up_full(const void* in, const void* wp, const float* bias, const void* mask, void* out, const ConvGeom& g, int act, hipStream_t stream,
-                float acc_scale = 1.f, float out_scale = 1.f) {
+                UpVariant var, float acc_scale = 1.f, float out_scale = 1.f) {
     if constexpr (!CVAE_UPFULL || (WN * NI > 1 && !CVAE_UPFULL_WIDE)) {      // the 64-channel-tile form measured slower than conv_data_kernel<UP> with BD: not instantiated
         return CVAE_E_UNSUPPORTED;
     } else {
-        if (g.Cs == 64) return launch_up_full<T, ND, WM, WN, MI, NI, 4, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
-        if (g.Cs == 128) return launch_up_full<T, ND, WM, WN, MI, NI, 8, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
-        if (g.Cs == 256) return launch_up_full<T, ND, WM, WN, MI, NI, 16, TO>(in, wp, bias, mask, out, g, act, stream, acc_scale, out_scale);
+        if (g.Cs == 64) return launch_up_full<T, ND, WM, WN, MI, NI, 4, TO>(in, wp, bias, mask, out, g, act, stream, var, acc_scale, out_scale);
+        if (g.Cs == 128) return launch_up_full<T, ND, WM, WN, MI, NI, 8, TO>(in, wp, bias, mask, out, g, act, stream, var, acc_scale, out_scale);
+        if (g.Cs == 256) return launch_up_full<T, ND, WM, WN, MI, NI, 16, TO>(in, wp, bias, mask, out, g, act, stream, var, acc_scale, out_scale);
     }
     return CVAE_E_UNSUPPORTED;
 }
@@ -1784,7 +1790,7 @@ bool geom_ok(int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t 
 int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* bias, const void* mask, void* S, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                       int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, F8Side f8 = F8Side{nullptr, nullptr, nullptr});
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
-                    int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream);
+                    int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, long long walk_units = 0);
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd);
 int cvae_conv_wgrad_c1(const void* S, const void* L, int l_dtype, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
                        int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
@@ -1795,18 +1801,6 @@ extern "C" int cvae_debug_stamps(unsigned long long* host, size_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), count * sizeof(unsigned long long)) == hipSuccess ? CVAE_OK : CVAE_E_LAUNCH;
 }
 #endif
-
-extern "C" int64_t cvae_tune_xpair_min_wgs(int64_t min_wgs) {
-    const long long prev = g_xpair_min_wgs;
-    if (min_wgs >= 0) g_xpair_min_wgs = min_wgs;
-    return prev;
-}
-
-extern "C" int64_t cvae_tune_upfull_min_grid(int64_t min_grid) {      // < 0: query only.  Returns the previous threshold.  Tests set 0 to run every `up` case through both kernels.
-    const long long prev = g_upfull_min_grid;
-    if (min_grid >= 0) g_upfull_min_grid = min_grid;
-    return prev;
-}
 
 extern "C" size_t cvae_conv_packed_weight_bytes(int64_t Cs, int64_t Cl, int nd, int dtype) {
     const int64_t taps = (nd == 3) ? 64 : 16;
@@ -1986,33 +1980,49 @@ extern "C" int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, 
     return cvae_conv_wgrad_c1(S, L, l_dtype, dW, dbias, nullptr, workspace, workspace_bytes, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, (hipStream_t)stream);
 }
 
-extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
-                            int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                            int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+static int conv_up_impl(const void* S, const void* w, const float* bias, const void* mask, void* L,
+                        int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                        int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                        void* workspace, size_t workspace_bytes, void* stream, UpVariant var) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (B == 0) return CVAE_OK;
     if (!S || !w || !L) return CVAE_E_NULLPTR;
     hipStream_t st = (hipStream_t)stream;
-    if (Cl == 1) return cvae_conv_up_c1(S, (const float*)w, bias, mask, L, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
+    if (Cl == 1) return cvae_conv_up_c1(S, (const float*)w, bias, mask, L, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st, var.walk_units);
     if (Cs % 16 || Cl % 32) return CVAE_E_UNSUPPORTED;
     GEOM_INIT();
     const bool wide = (Cl % 64) == 0;     // N tile 64 (2x2 waves, 128 rows) else N tile 32 (4x1 waves, 256 rows)
     if (dtype == CVAE_BF16) {
         int rc;
-        if (nd == 3) rc = wide ? try_up_full<bf16, 3, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : try_up_full<bf16, 3, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
-        else rc = wide ? try_up_full<bf16, 2, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st) : try_up_full<bf16, 2, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st);
+        if (nd == 3) rc = wide ? try_up_full<bf16, 3, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st, var) : try_up_full<bf16, 3, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st, var);
+        else rc = wide ? try_up_full<bf16, 2, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st, var) : try_up_full<bf16, 2, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st, var);
         if (rc != CVAE_E_UNSUPPORTED) return rc;
 #if CVAE_KSPLIT_WAVES
-        if (wide) return nd == 3 ? launch_data<bf16, 3, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st)
-                                 : launch_data<bf16, 2, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
+        if (wide) return nd == 3 ? launch_data<bf16, 3, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var)
+                                 : launch_data<bf16, 2, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
 #endif
-        if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
-        return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
+        if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
+        return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
     }
-    if (nd == 3) return wide ? launch_data<float, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<float, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
-    return wide ? launch_data<float, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st) : launch_data<float, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st);
+    if (nd == 3) return wide ? launch_data<float, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<float, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
+    return wide ? launch_data<float, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<float, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
+}
+
+extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
+                            int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                            int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_up_impl(S, w, bias, mask, L, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, UpVariant{});
+}
+extern "C" int cvae_conv_up_variant(const void* S, const void* w, const float* bias, const void* mask, void* L,
+                                    int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                                    int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                                    void* workspace, size_t workspace_bytes, int upfull, int xpair, int64_t c1_walk_units, void* stream) {
+    if (upfull < -1 || upfull > 1 || xpair < -1 || xpair > 1 || c1_walk_units < 0 || c1_walk_units >= ((int64_t)1 << 30)) return CVAE_E_BADSHAPE;
+    UpVariant var;
+    var.upfull = upfull; var.xpair = xpair; var.walk_units = c1_walk_units;
+    return conv_up_impl(S, w, bias, mask, L, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, var);
 }
 
 extern "C" size_t cvae_conv_wgrad_workspace_bytes(int64_t Cs, int64_t Cl, int nd) {
@@ -2234,14 +2244,15 @@ extern "C" int cvae_fp8_scale_update(void* amax_slots, float* scale, float* inv_
 // codes) or CVAE_FP8 (codes only).  Scales: by value (acc_scale = s_in * s_w, out8_inv_scale = 1 / s_out8), or, when `dscale` is not null,
 // read from the device pair {acc_scale, out8_inv_scale} at run time.
 template <int ND, bool UP, typename TO>
-static int conv_fp8_t(const void* in, const void* w, const float* bias, void* out, ConvGeom g, int act, float acc_scale, float out_scale, F8Side f8, void* ws, size_t wsb, hipStream_t st) {
+static int conv_fp8_t(const void* in, const void* w, const float* bias, void* out, ConvGeom g, int act, float acc_scale, float out_scale, F8Side f8, void* ws, size_t wsb, hipStream_t st,
+                      UpVariant var) {
     const int Cout = UP ? g.Cl : g.Cs;
     const bool wide = (Cout % 64) == 0;
     // the bf16 launches' tile shapes: 64-channel tiles as (K split) x (N sub-tile) waves with the per-wave weight fetch, 32-channel tiles as 4 x 1 waves on LDS panels
 #ifndef CVAE_F8_FORM
 #define CVAE_F8_FORM 0      // 64-channel tiles: 0 = (K split) x (N sub-tile) waves with the per-wave weight fetch (the bf16 form), 1 = 2 x 2 waves on LDS weight panels,
 #endif                      // 2 = 2 x 2 waves with the per-wave fetch
-#define F8L(WM, WN, MI, TS, BDX, EPI) launch_data_epi<f8x2, ND, UP, WM, WN, MI, 1, EPI, 1, TO, BDX, TS>(in, w, bias, nullptr, out, g, act, ws, wsb, st, acc_scale, out_scale, f8)
+#define F8L(WM, WN, MI, TS, BDX, EPI) launch_data_epi<f8x2, ND, UP, WM, WN, MI, 1, EPI, 1, TO, BDX, TS>(in, w, bias, nullptr, out, g, act, ws, wsb, st, acc_scale, out_scale, f8, var)
 #define F8E(WM, WN, MI, TS, BDX) (act == CVAE_ACT_NONE ? F8L(WM, WN, MI, TS, BDX, 0) : (act == CVAE_ACT_RELU ? F8L(WM, WN, MI, TS, BDX, 1) : F8L(WM, WN, MI, TS, BDX, 2)))
     if (wide) {
         // measured (rocprofv3 device durations, 4 x 128^3 shapes, profiles/r03_fp8_forms.txt): the `down` products want their weights on LDS panels — the
@@ -2257,8 +2268,8 @@ static int conv_fp8_t(const void* in, const void* w, const float* bias, void* ou
 }
 extern "C" int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, void* out, int out_dtype, void* out8, const float* dscale, float acc_scale,
                              float out8_inv_scale, void* amax_slots, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl,
-                             int nd, int act, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || (up != 0 && up != 1)) return CVAE_E_BADSHAPE;
+                             int nd, int act, void* workspace, size_t workspace_bytes, int xpair, void* stream) {
+    if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || (up != 0 && up != 1) || xpair < -1 || xpair > 1) return CVAE_E_BADSHAPE;
     if (out_dtype != CVAE_FP8 && out_dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (!dscale && (!(acc_scale > 0.f) || ((out_dtype == CVAE_FP8 || out8) && !(out8_inv_scale > 0.f)))) return CVAE_E_BADSHAPE;
     if (out_dtype == CVAE_FP8 && out8) return CVAE_E_BADSHAPE;        // codes-only output: there is no second copy to ask for
@@ -2269,8 +2280,10 @@ extern "C" int cvae_conv_fp8(int up, const void* in8, const void* w8, const floa
     GEOM_INIT();
     hipStream_t st = (hipStream_t)stream;
     const F8Side f8{dscale, (fp8*)out8, (unsigned*)amax_slots};
-#define F8D(ND_, UP_) (out_dtype == CVAE_FP8 ? conv_fp8_t<ND_, UP_, fp8>(in8, w8, bias, out, g, act, acc_scale, out8_inv_scale, f8, nullptr, 0, st) \
-                                             : conv_fp8_t<ND_, UP_, bf16>(in8, w8, bias, out, g, act, acc_scale, out8_inv_scale, f8, workspace, workspace_bytes, st))
+    UpVariant var;
+    var.xpair = xpair;
+#define F8D(ND_, UP_) (out_dtype == CVAE_FP8 ? conv_fp8_t<ND_, UP_, fp8>(in8, w8, bias, out, g, act, acc_scale, out8_inv_scale, f8, nullptr, 0, st, var) \
+                                             : conv_fp8_t<ND_, UP_, bf16>(in8, w8, bias, out, g, act, acc_scale, out8_inv_scale, f8, workspace, workspace_bytes, st, var))
     if (nd == 3) return up ? F8D(3, true) : F8D(3, false);
     return up ? F8D(2, true) : F8D(2, false);
 #undef F8D
@@ -2280,5 +2293,5 @@ extern "C" int cvae_conv_up_fp8(const void* S, const void* w, const float* bias,
                                 int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                                 void* stream) {
     return cvae_conv_fp8(1, S, w, bias, L, out_dtype, nullptr, nullptr, acc_scale, out_dtype == CVAE_FP8 ? out_inv_scale : 1.f, nullptr, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, act,
-                         nullptr, 0, stream);
+                         nullptr, 0, -1, stream);
 }

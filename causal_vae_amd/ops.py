@@ -401,12 +401,19 @@ def _conv_down(Lt, wp, bias, mask, Cs, nd, act, out_dtype=None):
     return S
 
 
+UP_VARIANT = None    # test hook: (upfull, xpair, c1_walk_units) for cvae_conv_up_variant / the xpair of cvae_conv_fp8; None = the library's automatic choice
+
+
 def _conv_up(St, wp, bias, mask, Cl, nd, act, l_dims=None):
     """l_dims: spatial extent (ld, lh, lw) of the result when it is not 2 s — the data gradient of a conv over an odd extent (l = 2 s + 1)."""
     B, sd, sh, sw, Cs = _cl_dims(St)
     ld, lh, lw = ((2 * sd if nd == 3 else 1), 2 * sh, 2 * sw) if l_dims is None else tuple(int(v) for v in l_dims)
     Lt = _empty((B, ld, lh, lw, Cl), St.dtype, St)
     ws, nbytes = _conv_data_workspace(St.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, 1)
+    if UP_VARIANT is not None:
+        check(lib.cvae_conv_up_variant(ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), L.act_code(act),
+                                       ptr(ws), nbytes, int(UP_VARIANT[0]), int(UP_VARIANT[1]), int(UP_VARIANT[2]), stream()), "conv_up_variant")
+        return Lt
     check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up, ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt),
                   B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), L.act_code(act), ptr(ws), nbytes, stream()), "conv_up")
     return Lt
@@ -711,7 +718,7 @@ def conv_fp8(up, xq, wq, bias, Cout, nd, act, acc_scale=None, out8_scale=None, c
     label = (f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}" if up else f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}")
     check(L.timed(label, lib.cvae_conv_fp8, int(bool(up)), ptr(xq), ptr(wq), ptr(bias), ptr(out), L.FP8 if codes_only else L.BF16, ptr(out8), ptr(dscale),
                   float(acc_scale if acc_scale is not None else 1.0), (1.0 / float(out8_scale)) if out8_scale is not None else 1.0, ptr(amax),
-                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.act_code(act), ptr(ws), nbytes, stream()), "conv_fp8")
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.act_code(act), ptr(ws), nbytes, -1 if UP_VARIANT is None else int(UP_VARIANT[1]), stream()), "conv_fp8")
     return (out, out8) if pair else out
 
 

@@ -133,7 +133,7 @@ int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, 
  *                               the next fp8 layer; out_dtype CVAE_FP8: `out` holds the codes only.  dscale (optional, device): {acc_scale,
  *                               out8_inv_scale} read at run time instead of the two by-value arguments (delayed scaling under graph replay).
  *                               amax_slots (optional): records max |out|.  workspace: cvae_conv_data_workspace_bytes of the same geometry (split-K
- *                               of the small `down` grids; NULL = unsplit).
+ *                               of the small `down` grids; NULL = unsplit).  xpair: as in cvae_conv_up_variant (-1 = automatic).
  *   cvae_conv_up_fp8            = cvae_conv_fp8(up = 1) with by-value scales and no side outputs (round-2 entry point, kept)
  *   cvae_fp8_scale_update       once per step: for each of n tracked tensors, scale[i] = headroom * amax_i / 448 (amax_i = the largest value
  *                               recorded in its CVAE_AMAX_SLOTS words since the last call; the words are cleared; nothing recorded = scale kept),
@@ -151,7 +151,7 @@ int cvae_conv_pack_weights_fp8(const float* const* w, void* const* packed, const
                                const float* const* inv_scale_dev, void* const* amax_slots, int count, int nd, void* stream);
 int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, void* out, int out_dtype, void* out8, const float* dscale, float acc_scale,
                   float out8_inv_scale, void* amax_slots, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl,
-                  int nd, int act, void* workspace, size_t workspace_bytes, void* stream);
+                  int nd, int act, void* workspace, size_t workspace_bytes, int xpair, void* stream);
 int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                      void* stream);
@@ -390,18 +390,15 @@ int cvae_linear_bwd_data_bf16(const float* dy, const float* W, float* dx, int64_
 int cvae_linear_bwd_weight_bf16(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N, int64_t dy_stride,
                                 int64_t x_stride, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Tuning / test hook (process-wide, not thread-safe; call between launches): the grid size (tiles x channel blocks x batch) from which the bf16
- * cvae_conv_up of a 32-channel output with 64 input channels switches to the whole-K kernel (default 2048).  min_grid < 0 only queries.
- * Returns the previous value.  Both kernels compute the same product; the tests run every case through each. */
-int64_t cvae_tune_upfull_min_grid(int64_t min_grid);
-/* Same kind of hook for the bf16 3D cvae_conv_up_c1: a launch with at least 2 x min_units tiles (2 x 8 x 16 source voxels each) lets a workgroup
- * walk ntiles / min_units consecutive tiles along z with the shared halo planes kept in LDS (default 1024).  min_units <= 0 only queries.
- * Returns the previous value.  Same arithmetic per output voxel either way (bit-identical results). */
-int64_t cvae_tune_c1u_walk_min_units(int64_t min_units);
-/* And for the 3D cvae_conv_up / cvae_conv_up_fp8 of a layer at most 4 source voxels wide (the decoder's 4^3 input): from min_wgs workgroups on,
- * a tile carries two samples side by side instead of one sample and an empty half (default 2048; 0 = always, < 0 only queries).  Returns the
- * previous value.  Same products and the same summation order per output element (bit-identical results). */
-int64_t cvae_tune_xpair_min_wgs(int64_t min_wgs);
+/* cvae_conv_up with the kernel form chosen by the CALLER for this one call instead of by launch size (the library keeps no process-wide tuning state):
+ *   upfull        -1 automatic; 0 / 1: never / whenever it fits — the whole-K `up` kernel (bf16, 64 / 128 / 256 input channels, 32 output channels);
+ *   xpair         -1 automatic; 0 / 1: one sample per tile / two side by side — 3D layers at most 4 source voxels wide (the decoder's 4^3 input);
+ *   c1_walk_units  0 automatic; > 0: the single-channel output layer (bf16, 3D) walks z columns when the launch has at least 2 x this many tiles.
+ * Every form computes the same products in the same order (bit-identical results; the tests run each narrow case through both). */
+int cvae_conv_up_variant(const void* S, const void* w, const float* bias, const void* mask, void* L,
+                         int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                         int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                         void* workspace, size_t workspace_bytes, int upfull, int xpair, int64_t c1_walk_units, void* stream);
 
 /* ---- optimiser ---------------------------------------------------------------------------------------------- */
 /* torch.optim.Adam (no weight decay / amsgrad) on flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t

@@ -76,10 +76,10 @@ def split_k(request):
     threshold of the whole-K `up` kernel to 0, so the narrow bf16 cases (64 -> 32 channels) run through conv_up_full_kernel there and through
     conv_data_kernel<UP> in the other arm."""
     old, ops.SPLIT_K = ops.SPLIT_K, request.param
-    prev = L.lib.cvae_tune_upfull_min_grid(-1 if request.param else 0)
+    prev, ops.UP_VARIANT = ops.UP_VARIANT, (None if request.param else (1, -1, 0))        # cvae_conv_up_variant(upfull = 1): per call, no library state
     yield request.param
     ops.SPLIT_K = old
-    L.lib.cvae_tune_upfull_min_grid(prev)
+    ops.UP_VARIANT = prev
 
 
 # odd input extents (l = 2 s + 1: the conv floors, its data gradient must come back with the odd extent): the 7 -> 3 layer of ConditionalVAE
@@ -159,14 +159,14 @@ def test_conv_up_c1_walking_z_columns_is_bit_identical(B, ssize, act):
     tiles_d = (ssize[0] + 1) // 2
     ntiles = B * tiles_d * ((ssize[1] + 7) // 8) * ((ssize[2] + 15) // 16)
     outs = {}
-    prev = L.lib.cvae_tune_c1u_walk_min_units(-1)
+    prev = ops.UP_VARIANT
     try:
         for name, units in [("none", 1 << 29), ("whole", 1), ("ragged", max(1, ntiles // 3)), ("pairs", max(1, ntiles // 2))]:
-            L.lib.cvae_tune_c1u_walk_min_units(units)
+            ops.UP_VARIANT = (-1, -1, units)                       # cvae_conv_up_variant(c1_walk_units)
             with torch.no_grad():
                 outs[name] = ops.ConvUp.apply(xg, wg, bg, 3, act, False, False).clone()
     finally:
-        L.lib.cvae_tune_c1u_walk_min_units(prev)
+        ops.UP_VARIANT = prev
     close(from_cl(outs["none"], 3), y_ref, torch.bfloat16, "y")
     for name in ("whole", "ragged", "pairs"):
         assert torch.equal(outs[name], outs["none"]), name
@@ -192,13 +192,13 @@ def test_conv_up_two_samples_per_tile_is_bit_identical(B, Cs, Cl, ssize, act, ma
     wp = ops.pack_weight(w.to(DEV), 3, True, torch.bfloat16)
     mg = to_cl(mask, torch.bfloat16) if masked else None
     outs = {}
-    prev = L.lib.cvae_tune_xpair_min_wgs(-1)
+    prev = ops.UP_VARIANT
     try:
-        for name, wgs in [("single", 1 << 40), ("paired", 0)]:
-            L.lib.cvae_tune_xpair_min_wgs(wgs)
+        for name, xp in [("single", 0), ("paired", 1)]:
+            ops.UP_VARIANT = (-1, xp, 0)                           # cvae_conv_up_variant(xpair)
             outs[name] = ops._conv_up(xg, wp, bg, mg, Cl, 3, act).clone()
     finally:
-        L.lib.cvae_tune_xpair_min_wgs(prev)
+        ops.UP_VARIANT = prev
     close(from_cl(outs["single"], 3), y_ref, torch.bfloat16, "y")
     assert torch.equal(outs["paired"], outs["single"])
 
@@ -227,9 +227,9 @@ def test_quantize_fp8_codes_bit_exact(dtype):
 @pytest.fixture(params=[False, True], ids=["single", "paired"])
 def xpair(request):
     """Narrow 3D `up` layers (at most 4 source voxels wide) with one sample per tile, and with two side by side (the large-launch form)."""
-    prev = L.lib.cvae_tune_xpair_min_wgs(0 if request.param else 1 << 40)
+    prev, ops.UP_VARIANT = ops.UP_VARIANT, (-1, 1 if request.param else 0, 0)
     yield request.param
-    L.lib.cvae_tune_xpair_min_wgs(prev)
+    ops.UP_VARIANT = prev
 
 
 @pytest.mark.parametrize("nd,B,Cl,Cs,ssize,act,q_out", [(3, 2, 128, 256, (4, 4, 4), "relu", True), (3, 3, 64, 128, (8, 8, 8), "relu", False), (3, 1, 32, 64, (5, 6, 9), None, True),
