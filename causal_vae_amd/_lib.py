@@ -119,7 +119,7 @@ SIGNATURES = {
     "cvae_up2x_supported": [_i64] * 7,
     "cvae_up2x_fwd": [_p, _p] + [_i64] * 7 + [_i, _p],
     "cvae_elbo_up2x_partials": [_i64] * 4,
-    "cvae_elbo_up2x_fwd": [_p] * 6 + [_f, _p, _p, _p] + [_i64] * 9 + [_i, _p],
+    "cvae_elbo_up2x_fwd": [_p] * 6 + [_f, _p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _p],
     "cvae_elbo_up2x_bwd": [_p] * 5 + [_f] + [_p] * 5 + [_i64] * 9 + [_i, _p],
     "cvae_conv3_to_k4": [_p, _p, _i64, _i64, _p],
     "cvae_k4_to_conv3_grad": [_p, _p, _i64, _i64, _p],

@@ -182,15 +182,18 @@ class CausalBioVAE(nn.Module):
         out_cl, m_hat, mu, logvar = self._forward_cl(x, m, t, eps)
         return self._resize_to(out_cl, x), m_hat, mu, logvar
 
-    def forward_elbo(self, x, m, t, eps=None, gamma=2000.0):
+    def forward_elbo(self, x, m, t, eps=None, gamma=2000.0, bump=None):
         """forward + loss_function(recon_x, x, m_hat, m, mu, logvar, gamma) -> (loss, recon_loss, m_loss) in one call.  When the resize
         is the exact 2x of the benchmark shape the reconstruction term is computed from the decoder output directly
         (ops.ElboUp2x): the resized volume is never written; otherwise this is literally forward() followed by the ELBO node."""
         out_cl, m_hat, mu, logvar = self._forward_cl(x, m, t, eps)
+        # bump: a device step counter (FusedAdam.claim_step_counter) that this step's launches must advance by one; the ELBO launch takes it along
         if self.fuse_recon_loss and ops.ElboUp2x.supported(out_cl, x):
-            loss, recon, m_loss, _ = ops.ElboUp2x.apply(out_cl, x, m_hat, m, mu, logvar, gamma)
+            loss, recon, m_loss, _ = ops.ElboUp2x.apply(out_cl, x, m_hat, m, mu, logvar, gamma, bump)
         else:
             loss, recon, m_loss, _ = ops.Elbo.apply(self._resize_to(out_cl, x), x, m_hat, m, mu, logvar, gamma)
+            if bump is not None:
+                ops.check(ops.lib.cvae_counter_add(ops.ptr(bump), 1, ops.stream()), "counter_add")
         return loss, recon, m_loss
 
     fuse_recon_loss = True

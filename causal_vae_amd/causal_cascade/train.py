@@ -21,7 +21,9 @@ def train_step(model, optimizer, x, m, t, eps=None, gamma=2000.0, grad_hook=None
     Returns (loss, recon_loss, m_loss) as 0-dim device tensors (no host sync)."""
     optimizer.zero_grad(set_to_none=True)
     if hasattr(model, "forward_elbo"):      # same numbers; skips materialising recon_x when the resize is an exact 2x (models.py)
-        loss, l_recon, l_m = model.forward_elbo(x, m, t, eps=eps, gamma=gamma)
+        # FusedAdam's device step counter rides on the ELBO launch (no launch of its own); claimed only once gradients are sure to follow
+        bump = optimizer.claim_step_counter(x.device) if (hasattr(optimizer, "claim_step_counter") and not getattr(optimizer, "_early", None)) else None
+        loss, l_recon, l_m = model.forward_elbo(x, m, t, eps=eps, gamma=gamma, bump=bump)
     else:
         recon_x, m_hat, mu, logvar = model(x, m, t) if eps is None else model(x, m, t, eps=eps)
         loss, l_recon, l_m = loss_function(recon_x, x, m_hat, m, mu, logvar, gamma)

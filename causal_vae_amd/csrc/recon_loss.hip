@@ -71,6 +71,22 @@ __device__ __forceinline__ float2 even_w(int o) { return o == 0 ? make_float2(0.
 
 // MODE 0 / 4: dst = up(src).  MODE 1: acc_out[block] = sum (up(src) - xin)^2.  MODE 3: MODE 1 and dst = t1[b][od][oh][x] = sum_ow Ww(ow -> x) (up(src) - xin).
 // D == d (2D tensors) leaves the depth axis untouched.
+// The ELBO's finish inside the forward launch (round 3; it was a launch of its own: ~4.7 us of cold misses in series for a 1-block kernel,
+// profiles/r03_launch_gap.txt).  Every workgroup leaves its partial sum and counts itself in on `ticket`; the workgroup whose add came LAST sums the
+// partials — in index order, as elbo_finish_kernel does, so the loss keeps its bits — adds the small terms and writes out4.  Hand-off per
+// MI355X_MICROARCH.md ("Valid forms", first table row): the partial is ONE 4-byte agent-scope (sc1) atomic store by the lane that then drains it
+// (s_waitcnt vmcnt(0)) and makes the agent-scope ticket add; the last arriver — told by the value its add returned — passes a workgroup barrier and
+// reads every partial with agent-scope (sc1) atomic loads, never through its L1.  The last arriver resets the ticket (a replayed graph finds it zero)
+// and, when asked, bumps a device step counter (the optimizer's: one more single-block launch gone).
+#define CVAE_ELBO_TICKET_GROUPS 32
+struct ElboFinish {
+    unsigned* ticket;                                        // CVAE_ELBO_TICKET_WORDS words; null: no in-launch finish (the caller runs elbo_finish_kernel)
+    const float *m_hat, *m, *mu, *logvar;
+    float* out4;
+    int* bump;
+    float gamma;
+    int n_m, n_z;
+};
 struct SmallBwd {                                            // the ELBO's small terms, ridden along the backward launch
     const float *m_hat, *m, *mu, *logvar;
     float *d_mhat, *dmu, *dlv;
@@ -80,7 +96,7 @@ struct SmallBwd {                                            // the ELBO's small
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ src, const float* __restrict__ xin, float* __restrict__ dst,
                                                          float* __restrict__ acc_out, const float* __restrict__ gout, float gscale,
-                                                         int B, int d, int h, int w, int D, int H, int W, SmallBwd sb) {
+                                                         int B, int d, int h, int w, int D, int H, int W, SmallBwd sb, ElboFinish fin) {
     constexpr int J0 = (MODE == 3) ? -1 : 0, NJ = (MODE == 3) ? 10 : 8;     // outputs along w per row: local j <-> ow = ow0 + J0 + j
     const bool sdz = D != d;
     const float sw = (float)w / (float)W;
@@ -186,10 +202,51 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
     }
     if (MODE == 1 || MODE == 3) {
         __shared__ float red[4];
+        __shared__ unsigned is_last;
         sse = wave_sum(sse);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sse;
         __syncthreads();
-        if (threadIdx.x == 0) acc_out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];     // per-block partial: summed in a fixed order by elbo_finish_kernel
+        if (!fin.ticket) {
+            if (threadIdx.x == 0) acc_out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];     // per-block partial: summed in a fixed order by elbo_finish_kernel
+            return;
+        }
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(acc_out + blockIdx.x, red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has left this CU before the ticket says so
+            // Two-level ticket: the ~1000 workgroups of this one-round grid finish nearly together, and that many RETURNING adds on ONE word serialise at
+            // the memory side (measured: the step 18 us LONGER than with the finish launch).  Workgroup b counts in on word b % 32 of 32 (each on a line
+            // of its own); the last arriver of a word counts in on the top word; the last arriver there has, transitively, every partial behind it.
+            constexpr unsigned G = CVAE_ELBO_TICKET_GROUPS;
+            const unsigned grp = blockIdx.x % G, pop = gridDim.x / G + (grp < gridDim.x % G ? 1u : 0u), ngrp = gridDim.x < G ? gridDim.x : G;
+            unsigned last = 0u;
+            if (__hip_atomic_fetch_add(fin.ticket + 32 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pop - 1)
+                last = __hip_atomic_fetch_add(fin.ticket + 32 * G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1 ? 1u : 0u;
+            is_last = last;
+        }
+        __syncthreads();
+        if (!is_last) return;
+        // ---- the last arriver: elbo_finish_kernel's sums, thread for thread ----
+        __shared__ float fr[3][4];
+        float sr = 0.f, sm = 0.f, sk = 0.f;
+        for (int i0 = threadIdx.x; i0 < (int)gridDim.x; i0 += 256 * 8) {      // 8 sc1 loads in flight per lane, then added in index order (elbo_finish_kernel's order)
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = (i0 + 256 * u < (int)gridDim.x) ? __hip_atomic_load(acc_out + i0 + 256 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + 256 * u < (int)gridDim.x) sr += pv[u];
+        }
+        for (int i = threadIdx.x; i < fin.n_m; i += 256) { const float df = fin.m_hat[i] - fin.m[i]; sm += df * df; }
+        for (int i = threadIdx.x; i < fin.n_z; i += 256) sk += 1.f + fin.logvar[i] - fin.mu[i] * fin.mu[i] - expf(fin.logvar[i]);
+        sr = wave_sum(sr); sm = wave_sum(sm); sk = wave_sum(sk);
+        if ((threadIdx.x & 63) == 0) { fr[0][threadIdx.x >> 6] = sr; fr[1][threadIdx.x >> 6] = sm; fr[2][threadIdx.x >> 6] = sk; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float recon = fr[0][0] + fr[0][1] + fr[0][2] + fr[0][3], ml = fr[1][0] + fr[1][1] + fr[1][2] + fr[1][3];
+            const float kld = -0.5f * (fr[2][0] + fr[2][1] + fr[2][2] + fr[2][3]);
+            fin.out4[0] = recon + fin.gamma * ml + kld; fin.out4[1] = recon; fin.out4[2] = ml; fin.out4[3] = kld;
+            if (fin.bump) *fin.bump += 1;
+        }
+        if (threadIdx.x <= CVAE_ELBO_TICKET_GROUPS) __hip_atomic_store(fin.ticket + 32 * threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every word back to zero
     }
 }
 
@@ -363,7 +420,7 @@ extern "C" int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, 
         return CVAE_OK;
     }
 #endif
-#define UP2X_FWD(T, MODE) hipLaunchKernelGGL((up2x_block_kernel<T, MODE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{})
+#define UP2X_FWD(T, MODE) hipLaunchKernelGGL((up2x_block_kernel<T, MODE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, nullptr, dst, nullptr, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{}, ElboFinish{})
     if (dtype == CVAE_BF16) { if (stream_out) UP2X_FWD(bf16, 4); else UP2X_FWD(bf16, 0); }
     else if (dtype == CVAE_F32) { if (stream_out) UP2X_FWD(float, 4); else UP2X_FWD(float, 0); }
 #undef UP2X_FWD
@@ -375,20 +432,24 @@ extern "C" int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, 
 extern "C" int64_t cvae_elbo_up2x_partials(int64_t B, int64_t d, int64_t h, int64_t w) { return (B * d * h * (w / 4) + 255) / 256; }
 
 extern "C" int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                                  float* out4, float* partial, float* t1, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
-                                  int64_t n_z, int dtype, void* stream) {
+                                  float* out4, float* partial, float* t1, void* ticket, int* bump, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W,
+                                  int64_t n_m, int64_t n_z, int dtype, void* stream) {
     if (!up2x_ok(B, d, h, w, D, H, W) || n_m < 0 || n_z < 0 || n_m > (1 << 24) || n_z > (1 << 24)) return CVAE_E_UNSUPPORTED;
     if (!src || !x || !m_hat || !m || !mu || !logvar || !out4 || !partial) return CVAE_E_NULLPTR;
     if (dtype != CVAE_BF16 && dtype != CVAE_F32) return CVAE_E_DTYPE;
+    if (bump && !ticket) return CVAE_E_NULLPTR;              // the counter rides on the in-launch finish
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)cvae_elbo_up2x_partials(B, d, h, w);
-#define ELBO_FWD(T, MODE) hipLaunchKernelGGL((up2x_block_kernel<T, MODE>), dim3(grid), dim3(256), 0, st, (const T*)src, x, t1, partial, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{})
+    const ElboFinish fin{(unsigned*)ticket, m_hat, m, mu, logvar, out4, bump, gamma, (int)n_m, (int)n_z};
+#define ELBO_FWD(T, MODE) hipLaunchKernelGGL((up2x_block_kernel<T, MODE>), dim3(grid), dim3(256), 0, st, (const T*)src, x, t1, partial, nullptr, 0.f, (int)B, (int)d, (int)h, (int)w, (int)D, (int)H, (int)W, SmallBwd{}, fin)
     if (dtype == CVAE_BF16) { if (t1) ELBO_FWD(bf16, 3); else ELBO_FWD(bf16, 1); }
     else { if (t1) ELBO_FWD(float, 3); else ELBO_FWD(float, 1); }
 #undef ELBO_FWD
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(elbo_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, (int)grid, m_hat, m, mu, logvar, gamma, out4, (int)n_m, (int)n_z);
-    CVAE_CHECK_LAUNCH();
+    if (!ticket) {
+        hipLaunchKernelGGL(elbo_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, (int)grid, m_hat, m, mu, logvar, gamma, out4, (int)n_m, (int)n_z);
+        CVAE_CHECK_LAUNCH();
+    }
     return CVAE_OK;
 }
 

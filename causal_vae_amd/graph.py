@@ -65,7 +65,8 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         self.opt.zero_grad(set_to_none=True)
         if self.loss_fn is None:
-            res = self.model.forward_elbo(self.x, self.m, self.t)
+            bump = self.opt.claim_step_counter(self.x.device) if not getattr(self.opt, "_early", None) else None
+            res = self.model.forward_elbo(self.x, self.m, self.t, bump=bump)
         else:
             res = self.loss_fn(self.model(self.x, self.m, self.t), self.x, self.m)
         ops.backward_from(res[0])
@@ -88,7 +89,7 @@ class GraphedTrainStep:
         cap = torch.cuda.Stream()                            # ONE capture stream: the autograd nodes built in A1 run again in A2
         with _capture(self.g1, stream=cap):
             self.opt.zero_grad(set_to_none=True)
-            res = self.model.forward_elbo(self.x, self.m, self.t)
+            res = self.model.forward_elbo(self.x, self.m, self.t, bump=self.opt.claim_step_counter(self.x.device))
             h = self.model._enc_out
             if h is None or not h.requires_grad:
                 raise CvaeError("overlap_exchange: the model did not take the fused path that exposes its encoder output")

@@ -1295,8 +1295,12 @@ class ElboUp2x(torch.autograd.Function):
         B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
         return (Cc == 1 and x.shape[0] == B and x.shape[1] == 1 and x.dtype == torch.float32 and bool(lib.cvae_up2x_supported(B, d, h, w, D, H, W)))
 
+    _tickets = {}                  # device -> the zero-initialised arrival word of the in-launch finish (the kernel leaves it zero)
+    IN_LAUNCH_FINISH = __import__("os").environ.get("CVAE_ELBO_TWO_LAUNCH") != "1"        # False: the two-launch form (tests compare the two bit for bit; the env switch is for A/B runs)
+
     @staticmethod
-    def forward(ctx, src, x, m_hat, m, mu, logvar, gamma):
+    def forward(ctx, src, x, m_hat, m, mu, logvar, gamma, bump=None):
+        """bump: optional device int32 tensor incremented by the launch (the optimizer's device step counter, FusedAdam.claim_step_counter)."""
         L.require_gpu(src, x, m_hat, m, mu, logvar)
         src = src.contiguous()
         x, m_hat, m, mu, logvar = (t.contiguous().float() for t in (x, m_hat, m, mu, logvar))
@@ -1306,8 +1310,15 @@ class ElboUp2x(torch.autograd.Function):
         buf = torch.empty(4 + lib.cvae_elbo_up2x_partials(B, d, h, w), dtype=torch.float32, device=x.device)
         # a backward will follow: the forward launch also leaves t1 = U_w^T (up(src) - x), so the step reads x (33.5 MB at 128^3, B = 4) once
         t1 = torch.empty(B * D * H * w, dtype=torch.float32, device=x.device) if any(ctx.needs_input_grad[i] for i in (0, 2, 4, 5)) else None
-        check(lib.cvae_elbo_up2x_fwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), float(gamma), ptr(buf), buf.data_ptr() + 16, ptr(t1), B, d, h, w, D, H, W,
-                                     m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_fwd")
+        ticket = None
+        if ElboUp2x.IN_LAUNCH_FINISH:
+            ticket = ElboUp2x._tickets.get(x.device)
+            if ticket is None:
+                ticket = ElboUp2x._tickets[x.device] = torch.zeros(33 * 32, dtype=torch.int32, device=x.device)      # CVAE_ELBO_TICKET_WORDS
+        check(lib.cvae_elbo_up2x_fwd(ptr(src), ptr(x), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), float(gamma), ptr(buf), buf.data_ptr() + 16, ptr(t1), ptr(ticket),
+                                     ptr(bump) if ticket is not None else None, B, d, h, w, D, H, W, m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_fwd")
+        if bump is not None and ticket is None:
+            check(lib.cvae_counter_add(ptr(bump), 1, stream()), "counter_add")
         ctx.save_for_backward(src, x, m_hat, m, mu, logvar, t1)
         ctx.gamma = float(gamma)
         ctx.set_materialize_grads(False)
@@ -1319,12 +1330,12 @@ class ElboUp2x(torch.autograd.Function):
         if g_recon is not None or g_m is not None or g_kld is not None:
             raise L.CvaeError("ElboUp2x back-propagates the total loss only; for a single term use loss_function on the model's recon_x")
         if g_loss is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         B, d, h, w, Cc, D, H, W = ElboUp2x.dims(src, x)
         dsrc, d_mhat, dmu, dlv = torch.empty_like(src), torch.empty_like(m_hat), torch.empty_like(mu), torch.empty_like(mu)
         check(lib.cvae_elbo_up2x_bwd(ptr(t1), ptr(m_hat), ptr(m), ptr(mu), ptr(logvar), ctx.gamma, ptr(g_loss.contiguous()), ptr(dsrc),
                                      ptr(d_mhat), ptr(dmu), ptr(dlv), B, d, h, w, D, H, W, m.numel(), mu.numel(), L.dtype_code(src.dtype), stream()), "elbo_up2x_bwd")
-        return dsrc, None, d_mhat, None, dmu, dlv, None
+        return dsrc, None, d_mhat, None, dmu, dlv, None, None
 
 
 class WeightedSum(torch.autograd.Function):

@@ -61,6 +61,16 @@ class FusedAdam(torch.optim.Optimizer):
         self._early_left, self._early_ran = len(self._early), False
         return super().zero_grad(set_to_none=set_to_none)
 
+    def claim_step_counter(self, device):
+        """The device step counter, for a caller that promises to advance it by exactly one before this step's step() (the flagship model's ELBO launch
+        does: one single-block launch fewer).  step() then does not count again.  None when the counter lives on the host."""
+        if not self.device_step:
+            return None
+        if self._step_dev is None:
+            self._step_dev = torch.zeros((), dtype=torch.int32, device=device)
+        self._counted = True
+        return self._step_dev
+
     def _count_step(self, device):
         if self.device_step and not self._counted:
             if self._step_dev is None:

@@ -176,10 +176,15 @@ int cvae_up2x_fwd(const void* src, float* dst, int64_t B, int64_t d, int64_t h, 
 /* out4 = {loss, recon, m_loss, kld}: recon = sum (up(src) - x)^2, m_loss = sum (m_hat - m)^2 (n_m elements),
  * kld = -0.5 sum (1 + logvar - mu^2 - exp(logvar)) (n_z elements), loss = recon + gamma * m_loss + kld.
  * partial: scratch of cvae_elbo_up2x_partials(B, d, h, w) floats (per-workgroup sums, added in a fixed order: no atomics). */
+#define CVAE_ELBO_TICKET_WORDS (33 * 32)
 int64_t cvae_elbo_up2x_partials(int64_t B, int64_t d, int64_t h, int64_t w);
 int cvae_elbo_up2x_fwd(const void* src, const float* x, const float* m_hat, const float* m, const float* mu, const float* logvar, float gamma,
-                       float* out4, float* partial, float* t1, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W, int64_t n_m,
-                       int64_t n_z, int dtype, void* stream);
+                       float* out4, float* partial, float* t1, void* ticket, int* bump, int64_t B, int64_t d, int64_t h, int64_t w, int64_t D, int64_t H, int64_t W,
+                       int64_t n_m, int64_t n_z, int dtype, void* stream);
+/* ticket (optional): CVAE_ELBO_TICKET_WORDS device words, zero before the first call — the launch then finishes the sums itself (the workgroup that arrives
+ * last, found by a two-level arrival count, adds the partials in index order: same bits as the two-launch form, one dependent launch fewer; the words are
+ * zero again when the launch ends).  bump (optional,
+ * needs ticket): a device int incremented once by that last workgroup — the optimizer's device step counter rides along (cvae_adam_multi's step_dev). */
 /* t1 (B*D*H*w floats, or NULL when no backward follows): the same launch also leaves U_w^T (up(src) - x), the part of the backward that needs x,
  * so that a training step reads x once.  cvae_elbo_up2x_bwd turns it into the gradients of `loss` scaled by the device scalar *g_loss (NULL = 1):
  * dsrc (dtype), d_mhat, dmu, dlv. */

@@ -633,6 +633,36 @@ def test_fp8_forward_train_step_close_to_bf16_step(B, size):
     assert float(ratio.max()) < 2.0 and float(ratio.min()) > 0.5, ratio
 
 
+def test_elbo_in_launch_finish_equals_the_two_launch_form():
+    """cvae_elbo_up2x_fwd with a ticket: the workgroup that arrives last sums the partials inside the forward launch (sc1 stores, drained, agent-scope ticket
+    add; sc1 loads by the last arriver — MI355X_MICROARCH.md, valid forms) instead of a finish launch.  Same sums in the same order: all four outputs are
+    bit-identical to the two-launch form, on every one of 40 back-to-back launches interleaved with a bandwidth-heavy kernel (uneven load: a stale or
+    early read of a partial would show as a different bit pattern), the ticket is left at zero, and the step counter that rides along advances once per call."""
+    g = torch.Generator().manual_seed(55)
+    B = 4
+    src = (torch.randn(B, 64, 64, 64, 1, generator=g) * 0.3).to(DEV).to(torch.bfloat16)
+    x = torch.randn(B, 1, 128, 128, 128, generator=g).to(DEV)
+    m_hat, m = torch.rand(B, 12, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
+    mu, logvar = torch.randn(B, 64, generator=g).to(DEV), (torch.randn(B, 64, generator=g) * 0.1).to(DEV)
+    junk = torch.empty(64 << 20, device=DEV)
+    old = ops_mod.ElboUp2x.IN_LAUNCH_FINISH
+    try:
+        ops_mod.ElboUp2x.IN_LAUNCH_FINISH = False
+        ref = [v.clone() for v in ops_mod.ElboUp2x.apply(src, x, m_hat, m, mu, logvar, 2000.0)]
+        ops_mod.ElboUp2x.IN_LAUNCH_FINISH = True
+        bump = torch.zeros((), dtype=torch.int32, device=DEV)
+        for it in range(40):
+            if it % 3:
+                junk.mul_(1.0001)                                   # a streaming kernel right in front: the forward's workgroups start under load
+            out = ops_mod.ElboUp2x.apply(src.requires_grad_(it % 2 == 0), x, m_hat, m, mu, logvar, 2000.0, bump)       # with and without the t1 side output
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b), (it, float(a), float(b))
+        assert int(bump) == 40
+        assert int(ops_mod.ElboUp2x._tickets[src.device].abs().sum()) == 0
+    finally:
+        ops_mod.ElboUp2x.IN_LAUNCH_FINISH = old
+
+
 def test_split_backward_capture_matches_eager_steps():
     """GraphedTrainStep(overlap_exchange=True): the backward captured in two graphs around the encoder output (the multi-GPU exchange
     overlap; no process group here, so no exchange happens) == the eager step: losses and weights after 3 + 3 steps, every gradient

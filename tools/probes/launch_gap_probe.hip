@@ -31,6 +31,22 @@ __global__ void reader(const float4* p, size_t n4, float* out) {
     if (s == 12345.f) out[0] = s;
 }
 
+// 32 DISTINCT kernels of ~1.5 KB of code each (a chain in the real step never launches the same kernel twice in a row: every launch starts with cold
+// instruction-cache lines and a cold kernel descriptor); I selects a different unrolled body so the code objects do not fold into one.
+template <int I> __global__ void distinct_tiny(int* p, int n) {
+    int v = p[threadIdx.x & 63];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) v = v * (I + 3 + k) + ((v >> (k & 7)) ^ (I * 7919 + k));
+    if (n == 123456789) p[threadIdx.x & 63] = v;      // never true: the body stays, nothing is written
+    if (threadIdx.x == 0) p[64 + I] += 1;
+}
+template <int I> static void launch_distinct(int which, hipStream_t st, int* p) {
+    if constexpr (I < 32) {
+        if (which == I) { hipLaunchKernelGGL(distinct_tiny<I>, dim3(1), dim3(64), 0, st, p, 0); return; }
+        launch_distinct<I + 1>(which, st, p);
+    }
+}
+
 template <typename F> static float time_chain(hipStream_t st, int K, int reps, bool graph, F enqueue) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
@@ -57,13 +73,18 @@ template <typename F> static float time_chain(hipStream_t st, int K, int reps, b
 int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
     const size_t MAXB = 64ull << 20;
-    float* buf; CK(hipMalloc(&buf, MAXB)); int* cnt; CK(hipMalloc(&cnt, 256)); CK(hipMemset(cnt, 0, 256));
+    float* buf; CK(hipMalloc(&buf, MAXB)); int* cnt; CK(hipMalloc(&cnt, 1024)); CK(hipMemset(cnt, 0, 1024));
     float* tb; CK(hipMalloc(&tb, 256 * 256 * 4));
     const int K = 64, reps = 20;
     for (int graph = 0; graph < 2; ++graph) {
         const char* mode = graph ? "graph" : "eager";
         printf("%s trivial 256x256       : %.2f us/launch\n", mode, time_chain(st, K, reps, graph, [&](int) { hipLaunchKernelGGL(trivial, dim3(256), dim3(256), 0, st, tb); }));
         printf("%s tiny 1x64             : %.2f us/launch\n", mode, time_chain(st, K, reps, graph, [&](int) { hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, st, cnt); }));
+        printf("%s 32 distinct tiny 1x64 : %.2f us/launch\n", mode, time_chain(st, K, reps, graph, [&](int i) { launch_distinct<0>(i & 31, st, cnt); }));
+        // the same with 64 MB rewritten between two passes over the chain, so the kernels' code has left the caches (one step of the model moves > 2 GB)
+        printf("%s 32 distinct tiny, cold: %.2f us/launch (chain of 32 + one 64 MB writer; the writer alone %.2f us)\n", mode,
+               33.f / 32.f * time_chain(st, 33, reps, graph, [&](int i) { if (i == 32) hipLaunchKernelGGL(writer, dim3(2048), dim3(256), 0, st, (float4*)buf, MAXB / 16); else launch_distinct<0>(i, st, cnt); }),
+               time_chain(st, 4, reps, graph, [&](int) { hipLaunchKernelGGL(writer, dim3(2048), dim3(256), 0, st, (float4*)buf, MAXB / 16); }));
         for (size_t mb : {1, 4, 16, 64}) {
             const size_t n4 = (mb << 20) / 16;
             const float w = time_chain(st, K, reps, graph, [&](int) { hipLaunchKernelGGL(writer, dim3(2048), dim3(256), 0, st, (float4*)buf, n4); });
@@ -76,6 +97,22 @@ int main() {
                 if (i & 1) hipLaunchKernelGGL(reader, dim3(2048), dim3(256), 0, st, (const float4*)buf, n4, tb); else hipLaunchKernelGGL(writer, dim3(2048), dim3(256), 0, st, (float4*)buf, n4); });
             printf("%s writer %3zu MB         : plain %.2f us/launch (%.2f TB/s)  sc1 %.2f;  writer+tiny pair: plain %.2f sc1 %.2f us/pair;  writer+reader pair %.2f\n", mode, mb, w, mb * 1.048576 / w, ws, 2 * wt, 2 * wst, 2 * wr);
         }
+    }
+    // What a tiny kernel costs when everything it needs is cold — the situation inside the train step, where > 2 GB move between two launches of the same
+    // small kernel: a 1 GB rewrite (far beyond the 256 MB Infinity Cache and every TLB) in front of EACH tiny launch; the boundary is the pair minus the writer.
+    {
+        float* huge; CK(hipMalloc(&huge, 1ull << 30));
+        const size_t n4 = (1ull << 30) / 16;
+        for (int graph = 0; graph < 2; ++graph) {
+            const float w = time_chain(st, 8, 6, graph, [&](int) { hipLaunchKernelGGL(writer, dim3(4096), dim3(256), 0, st, (float4*)huge, n4); });
+            const float p_same = time_chain(st, 16, 6, graph, [&](int i) {
+                if (i & 1) hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, st, cnt); else hipLaunchKernelGGL(writer, dim3(4096), dim3(256), 0, st, (float4*)huge, n4); });
+            const float p_dist = time_chain(st, 64, 4, graph, [&](int i) {
+                if (i & 1) launch_distinct<0>((i >> 1) & 31, st, cnt); else hipLaunchKernelGGL(writer, dim3(4096), dim3(256), 0, st, (float4*)huge, n4); });
+            printf("%s 1 GB writer %.1f us; writer + tiny pair %.1f (tiny behind it: %.2f us); writer + one of 32 distinct tiny kernels %.1f (%.2f us)\n", graph ? "graph" : "eager", w,
+                   2 * p_same, 2 * p_same - w, 2 * p_dist, 2 * p_dist - w);
+        }
+        hipFree(huge);
     }
     // a kernel with a large by-value argument block (the WgradTable / AdamTable launches pass ~4 KB of kernargs)
     return 0;
