@@ -201,8 +201,9 @@ def test_bio2d_odd_intermediate_extents_match_oracle(H, W):
             adam_close(p, sd1[k], k)
 
 
-# Stated bf16 bounds (conv GEMM inputs rounded to bf16 = 2^-9 relative, fp32 accumulate, fp32 heads / losses / master weights), measured on
-# MI355X at 4 x 128^3 and held with ~1.5x margin.  rel-L2 = ||got - ref||_2 / ||ref||_2 against the fp32 CPU oracle.
+# Stated bf16 bounds (conv GEMM inputs rounded to bf16 = 2^-9 relative, fp32 accumulate, fp32 heads / losses / master weights): static CAPS per layer.
+# The operative bound in test_bio3d_bf16_elbo_vs_fp32_oracle is derived per batch from the oracle alone (fp32 oracle vs bf16-rounding oracle, both CPU).
+# rel-L2 = ||got - ref||_2 / ||ref||_2 against the fp32 CPU oracle.
 BF16_RECON_REL_L2 = 2e-2                 # the decoder output resized to the input grid
 BF16_GRAD_REL_L2 = {                     # per-layer weight gradients: the error grows along the bf16 backward chain (decoder -> bottleneck -> encoder).
     # Large in relative terms because at the initial weights on N(0,1) volumes d(recon) ~ -2x is noise, and every weight gradient is a
@@ -247,24 +248,33 @@ def test_bio3d_bf16_elbo_vs_fp32_oracle(B, size):
           f"m_loss {rel(l_m, st['m_loss']):.3e}")
     assert err < 1e-4                                                       # BASELINE.md target
     assert rel(l_recon, st["recon"]) < 1e-4 and rel(l_m, st["m_loss"]) < 1e-5
+    # What may bf16 cost?  Not what the HIP build happens to produce: the gap between the fp32 oracle and the SAME oracle with its conv operands,
+    # activations and activation gradients rounded to bf16 (pure CPU fp32 arithmetic, conv_dtype=bfloat16) is what bf16 STORAGE costs on this batch.
+    # The build's own distance from the fp32 oracle must stay within 1.5x that gap (+ 0.01: two bf16 computations that sum in different orders also
+    # differ from each other, test_bio3d_bf16_matches_bf16_rounding_oracle) — and under the static table above, which only caps it.
+    sd_r = oracle.init_state_dict("bio3d", seed=42)
+    st_r = oracle.cascade_train_step(sd_r, x, m, t, eps, nd=3, apply_update=False, conv_dtype=torch.bfloat16)
     for k, p in model.named_parameters():
         if k.endswith(".weight") and p.dim() > 1:
             a, b = p.grad.cpu().double().flatten(), st["grads"][k].double().flatten()
+            r_ = st_r["grads"][k].double().flatten()
             cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
             l2 = float((a - b).norm() / b.norm())
-            print(f"  {k}: rel-L2 {l2:.4f}  cos {cos:.5f}")
+            gap = float((r_ - b).norm() / b.norm())
+            print(f"  {k}: rel-L2 {l2:.4f} (bf16-rounding oracle vs fp32 oracle: {gap:.4f})  cos {cos:.5f}")
+            assert l2 < 1.5 * gap + 0.01, (k, l2, gap)
             assert l2 < BF16_GRAD_REL_L2[k], (k, l2)
             assert cos > (0.98 if k == "enc_conv.0.weight" else 0.99), (k, cos)
 
 
-def test_bio3d_bf16_matches_bf16_rounding_oracle():
+@pytest.mark.parametrize("B,size", [(2, 64), (4, 128)], ids=["2x64", "4x128"])          # (4, 128): the bench workload itself
+def test_bio3d_bf16_matches_bf16_rounding_oracle(B, size):
     """The same bf16 step against the oracle run with conv_dtype=bfloat16 (fp32 CPU arithmetic that rounds exactly where the bf16 build stores
     bf16: conv operands, conv activations and their gradients).  Against THAT every weight gradient agrees 3-5x tighter than against the pure-fp32
     oracle (bound 5e-2 here, 0.09-0.22 there): the several-percent gaps of test_bio3d_bf16_elbo_vs_fp32_oracle are bf16 storage on noise-like
     gradients, not kernel error.  It is not tighter still because two bf16 implementations that sum in different orders flip different ReLU
     masks and diverge chaotically to 2-3 % in the first-layer gradients; kernel by kernel they match the rounded reference at 1e-5
-    (tools/debug_bf16_chain.py)."""
-    B, size = 2, 64
+    (tests/test_hip_ops.py::test_bench_shape_launches_match_rounded_operand_reference)."""
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, 1, size, size, size, generator=g)
     m, t, eps = torch.rand(B, 12, generator=g), torch.randint(0, 19, (B,), generator=g), torch.randn(B, 64, generator=g)
