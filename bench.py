@@ -279,7 +279,11 @@ def run_volume(args, rank, world, dev):
     opt = FusedAdam(model.parameters(), lr=args.lr, device_step=True)   # main.py:50
     if world == 1 and args.overlap_adam:
         opt.overlap_backward(model.early_gradient_parameters())        # measured: -4 % (the streaming update slows the co-running conv kernels more than it hides)
-    reducer = GradAllReducer(model.parameters()) if world > 1 else None
+    comm = None
+    if world > 1 and args.exchange == "abi":                        # the exchange through include/cvae_dp.h (reduce-scatter + all-gather on RCCL directly)
+        from causal_vae_amd.parallel import RcclComm
+        comm = RcclComm()
+    reducer = GradAllReducer(model.parameters(), comm=comm) if world > 1 else None
     x, m, t, eps = make_batch(args.batch, args.size, 1234 + rank, dev, binary=vessel)
 
     if vessel:
@@ -367,6 +371,7 @@ def run_volume(args, rank, world, dev):
     res["config"] = {"workload": f"3D vessel CausalVAE train step, {args.size}^3 {'bf16 volumes, fp8 (e4m3) forward convs (C_in >= 32), bf16 backward' if fp8 else args.dtype + ' volumes'} ({'binary ~10 % density' if vessel else 'z-scored N(0,1)'}), "
                                  f"batch {args.batch}/GPU, Adam lr {args.lr:g}, {loss_name}",
                      "global_batch": world * args.batch, "per_gpu_batch": args.batch, "volume": [args.size] * 3, "parallelism": f"dp{world}", "params": n_params}
+    res["exchange_backend"] = "cvae_dp C ABI (RCCL reduce-scatter + all-gather)" if comm is not None else ("torch.distributed all_reduce (RCCL)" if world > 1 else None)
     res["exchange"] = ("split backward: decoder + bottleneck bucket all-reduced under the encoder backward" if (use_graph and want_split) else
                        ("one all-reduce after the backward" if world > 1 else "none (1 rank)"))
     if capture_fallback:
@@ -611,6 +616,8 @@ def main():
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: one all-reduce after the whole backward instead of the split backward")
     ap.add_argument("--force-overlap-exchange", action="store_true", help="take the split-backward capture also at N = 1 (no exchange happens)")
     ap.add_argument("--roofline-steps", type=int, default=5, help="eager steps with per-launch HIP events after the timed region")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "abi"], help="N > 1: gradient exchange through torch.distributed's all_reduce on RCCL (default) or through "
+                    "the C ABI of include/cvae_dp.h (libcvae_dp.so: reduce-scatter + all-gather on RCCL directly)")
     ap.add_argument("--no-secondary", action="store_true", help="default vol128 run at N = 1: skip the compact lines of the other BASELINE.json configurations")
     ap.add_argument("--decode-native", action="store_true", help="decode workload: stop at the decoder's native 64^3 (no resize)")
     args = ap.parse_args()

@@ -1,0 +1,110 @@
+// dp.cpp — libcvae_dp.so: the gradient exchange of the data-parallel train step over RCCL (include/cvae_dp.h).  Host code only: RCCL brings its own kernels.
+#include "../../include/cvae_dp.h"
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <cstring>
+#include <new>
+
+namespace {
+struct Comm {
+    ncclComm_t comm;
+    int rank, world;
+};
+thread_local char g_err[256] = "";
+int fail(ncclResult_t r) {
+    std::strncpy(g_err, ncclGetErrorString(r), sizeof(g_err) - 1);
+    return CVAE_DP_E_RCCL;
+}
+bool dtype_of(int code, ncclDataType_t* t, size_t* esz) {
+    if (code == CVAE_DP_F32) { *t = ncclFloat32; *esz = 4; return true; }
+    if (code == CVAE_DP_BF16) { *t = ncclBfloat16; *esz = 2; return true; }
+    return false;
+}
+}  // namespace
+
+extern "C" int cvae_dp_version(void) { return 100; }
+extern "C" const char* cvae_dp_strerror(int code) {
+    switch (code) {
+        case CVAE_DP_OK: return "ok";
+        case CVAE_DP_E_BADARG: return "bad argument";
+        case CVAE_DP_E_NULLPTR: return "null pointer";
+        case CVAE_DP_E_DTYPE: return "unsupported dtype";
+        case CVAE_DP_E_RCCL: return "RCCL call failed (cvae_dp_last_rccl_error)";
+        default: return "unknown error";
+    }
+}
+extern "C" const char* cvae_dp_last_rccl_error(void) { return g_err; }
+
+extern "C" int cvae_dp_unique_id(void* id128) {
+    if (!id128) return CVAE_DP_E_NULLPTR;
+    static_assert(sizeof(ncclUniqueId) == CVAE_DP_UNIQUE_ID_BYTES, "RCCL's unique id is 128 bytes");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(r);
+    std::memcpy(id128, &id, sizeof(id));
+    return CVAE_DP_OK;
+}
+extern "C" int cvae_dp_init(int rank, int world, const void* id128, void** comm) {
+    if (!id128 || !comm) return CVAE_DP_E_NULLPTR;
+    if (world < 1 || rank < 0 || rank >= world) return CVAE_DP_E_BADARG;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    Comm* c = new (std::nothrow) Comm{nullptr, rank, world};
+    if (!c) return CVAE_DP_E_BADARG;
+    const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(r); }
+    *comm = c;
+    return CVAE_DP_OK;
+}
+extern "C" int cvae_dp_world(const void* comm) { return comm ? ((const Comm*)comm)->world : CVAE_DP_E_NULLPTR; }
+extern "C" int cvae_dp_rank(const void* comm) { return comm ? ((const Comm*)comm)->rank : CVAE_DP_E_NULLPTR; }
+
+extern "C" int cvae_dp_reduce_scatter_sum(void* comm, void* flat, size_t n, int dtype, void* stream) {
+    if (!comm || (!flat && n)) return CVAE_DP_E_NULLPTR;
+    Comm* c = (Comm*)comm;
+    ncclDataType_t t; size_t esz;
+    if (!dtype_of(dtype, &t, &esz)) return CVAE_DP_E_DTYPE;
+    if (n % (size_t)c->world) return CVAE_DP_E_BADARG;
+    if (n == 0 || c->world == 1) return CVAE_DP_OK;
+    const size_t per = n / (size_t)c->world;
+    const ncclResult_t r = ncclReduceScatter(flat, (char*)flat + (size_t)c->rank * per * esz, per, t, ncclSum, c->comm, (hipStream_t)stream);
+    return r == ncclSuccess ? CVAE_DP_OK : fail(r);
+}
+extern "C" int cvae_dp_all_gather(void* comm, void* flat, size_t n, int dtype, void* stream) {
+    if (!comm || (!flat && n)) return CVAE_DP_E_NULLPTR;
+    Comm* c = (Comm*)comm;
+    ncclDataType_t t; size_t esz;
+    if (!dtype_of(dtype, &t, &esz)) return CVAE_DP_E_DTYPE;
+    if (n % (size_t)c->world) return CVAE_DP_E_BADARG;
+    if (n == 0 || c->world == 1) return CVAE_DP_OK;
+    const size_t per = n / (size_t)c->world;
+    const ncclResult_t r = ncclAllGather((const char*)flat + (size_t)c->rank * per * esz, flat, per, t, c->comm, (hipStream_t)stream);
+    return r == ncclSuccess ? CVAE_DP_OK : fail(r);
+}
+extern "C" int cvae_dp_allreduce_sum(void* comm, void* flat, size_t n, int dtype, void* stream) {
+    if (!comm || (!flat && n)) return CVAE_DP_E_NULLPTR;
+    Comm* c = (Comm*)comm;
+    ncclDataType_t t; size_t esz;
+    if (!dtype_of(dtype, &t, &esz)) return CVAE_DP_E_DTYPE;
+    if (n == 0 || c->world == 1) return CVAE_DP_OK;
+    const size_t body = n - n % (size_t)c->world;           // reduce-scatter + all-gather over equal slices; the < world-element tail as one small all-reduce
+    if (body) {
+        int rc = cvae_dp_reduce_scatter_sum(comm, flat, body, dtype, stream);
+        if (rc != CVAE_DP_OK) return rc;
+        rc = cvae_dp_all_gather(comm, flat, body, dtype, stream);
+        if (rc != CVAE_DP_OK) return rc;
+    }
+    if (n != body) {
+        void* tail = (char*)flat + body * esz;
+        const ncclResult_t r = ncclAllReduce(tail, tail, n - body, t, ncclSum, c->comm, (hipStream_t)stream);
+        if (r != ncclSuccess) return fail(r);
+    }
+    return CVAE_DP_OK;
+}
+extern "C" int cvae_dp_destroy(void* comm) {
+    if (!comm) return CVAE_DP_E_NULLPTR;
+    Comm* c = (Comm*)comm;
+    const ncclResult_t r = ncclCommDestroy(c->comm);
+    delete c;
+    return r == ncclSuccess ? CVAE_DP_OK : fail(r);
+}

@@ -81,7 +81,8 @@ class GraphedTrainStep:
         params_b = [p for p in self.model.parameters() if p.requires_grad and id(p) not in ids_a]
         group = self.reducer.group if self.reducer is not None else None
         always = self.reducer.always_exchange if self.reducer is not None else False
-        self.red_a, self.red_b = GradAllReducer(params_a, group, always), GradAllReducer(params_b, group, always)
+        comm = self.reducer.comm if self.reducer is not None else None
+        self.red_a, self.red_b = GradAllReducer(params_a, group, always, comm), GradAllReducer(params_b, group, always, comm)
         self.red_a.pack(); self.red_b.pack()                 # the warm-up left every .grad in place: the flat buckets are allocated here,
         torch.cuda.synchronize()                             # in the ordinary pool, because RCCL touches them outside the graphs
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):

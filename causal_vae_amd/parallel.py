@@ -34,24 +34,117 @@ def init_distributed(backend=None):
     return rank, world, local_rank
 
 
+class RcclComm:
+    """This rank's RCCL communicator behind the C ABI of include/cvae_dp.h (libcvae_dp.so): cvae_dp_init / cvae_dp_allreduce_sum, the
+    exchange SURVEY.md §8(b) names, with no torch.distributed call on the data path.  The 128-byte unique id is created by rank 0 and
+    handed round once, through the process group the launcher set up (any backend) — bootstrap only.
+
+    all_reduce_sum(flat) reduces a flat fp32 / bf16 bucket in place as reduce-scatter + all-gather (both use every xGMI link of the fully
+    connected node), enqueued on the current HIP stream; `async_on_side_stream` runs it on the communicator's own stream instead, ordered
+    after what the current stream holds, and returns a handle whose wait() orders the current stream after the exchange."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes as C
+            here = os.path.dirname(os.path.abspath(__file__))
+            path = os.path.join(here, "libcvae_dp.so")
+            if not os.path.exists(path):
+                raise ImportError(f"{path} is missing: build it with `make -C causal_vae_amd/csrc` (the RCCL exchange has no fallback)")
+            try:                                             # one RCCL per process: let the loader see the one torch already brought
+                C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            L = C.CDLL(path)
+            L.cvae_dp_strerror.restype = C.c_char_p
+            L.cvae_dp_last_rccl_error.restype = C.c_char_p
+            L.cvae_dp_unique_id.argtypes = [C.c_void_p]
+            L.cvae_dp_init.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+            for name in ("cvae_dp_allreduce_sum", "cvae_dp_reduce_scatter_sum", "cvae_dp_all_gather"):
+                getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+            L.cvae_dp_destroy.argtypes = [C.c_void_p]
+            L.cvae_dp_world.argtypes = [C.c_void_p]
+            L.cvae_dp_rank.argtypes = [C.c_void_p]
+            cls._lib = L
+        return cls._lib
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            L = RcclComm.lib()
+            raise RuntimeError(f"{what}: {L.cvae_dp_strerror(rc).decode()} ({L.cvae_dp_last_rccl_error().decode()})")
+
+    def __init__(self, rank=None, world=None, group=None, device=None):
+        import ctypes as C
+        L = self.lib()
+        have_pg = dist.is_initialized()
+        self.rank = (dist.get_rank(group) if have_pg else 0) if rank is None else int(rank)
+        self.world = (dist.get_world_size(group) if have_pg else 1) if world is None else int(world)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idbuf = (C.c_char * 128)()
+        if self.rank == 0:
+            self._check(L.cvae_dp_unique_id(idbuf), "cvae_dp_unique_id")
+        if self.world > 1:
+            if not have_pg:
+                raise RuntimeError("RcclComm: world > 1 needs an initialised torch.distributed group to hand the unique id round")
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=self.device if on_gpu else "cpu")
+            dist.broadcast(t, src=(dist.get_global_rank(group, 0) if group is not None else 0), group=group)
+            idbuf = (C.c_char * 128)(*bytes(t.cpu().tolist()))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(L.cvae_dp_init(self.rank, self.world, idbuf, C.byref(self._h)), "cvae_dp_init")
+        self._side = None
+
+    def all_reduce_sum(self, flat):
+        if flat.dtype not in (torch.float32, torch.bfloat16) or not flat.is_contiguous() or not flat.is_cuda:
+            raise RuntimeError("RcclComm.all_reduce_sum: a contiguous fp32 / bf16 GPU tensor expected")
+        code = 0 if flat.dtype == torch.float32 else 1
+        self._check(self.lib().cvae_dp_allreduce_sum(self._h, flat.data_ptr(), flat.numel(), code, torch.cuda.current_stream(flat.device).cuda_stream), "cvae_dp_allreduce_sum")
+
+    def async_on_side_stream(self, flat):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=flat.device)
+        self._side.wait_stream(torch.cuda.current_stream(flat.device))
+        with torch.cuda.stream(self._side):
+            self.all_reduce_sum(flat)
+        side = self._side
+
+        class _Work:
+            def wait(self_inner):
+                torch.cuda.current_stream(flat.device).wait_stream(side)
+        return _Work()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib().cvae_dp_destroy(self._h)
+            self._h = None
+
+
 class GradAllReducer:
     """Sums `.grad` of `params` across ranks through one flat bucket.  Call it between backward and optimizer.step
     (the `grad_hook` of causal_cascade.train.train_step)."""
 
-    def __init__(self, params, group=None, always_exchange=False):
+    def __init__(self, params, group=None, always_exchange=False, comm=None):
         """always_exchange: issue the collective even in a one-rank group (a one-rank RCCL all-reduce is the identity; used to run the
-        capture / async-exchange machinery against RCCL on a single card)."""
+        capture / async-exchange machinery against RCCL on a single card).
+        comm: an RcclComm — the exchange then goes through the C ABI of include/cvae_dp.h (reduce-scatter + all-gather on RCCL directly)
+        instead of torch.distributed.all_reduce; same sums."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.always_exchange = bool(always_exchange)
+        self.comm = comm
         self._flat = None
 
     def world_size(self):
+        if self.comm is not None:
+            return self.comm.world
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def active(self):
         """True when a step has to exchange gradients: more than one rank, or always_exchange inside an initialised group."""
-        return self.world_size() > 1 or (self.always_exchange and dist.is_initialized())
+        return self.world_size() > 1 or (self.always_exchange and (dist.is_initialized() or self.comm is not None))
 
     def _grads(self):
         return [p.grad for p in self.params if p.grad is not None]
@@ -91,6 +184,9 @@ class GradAllReducer:
         self._copy(True)
 
     def all_reduce(self):
+        if self.comm is not None:
+            self.comm.all_reduce_sum(self._flat)
+            return
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce_async(self):
@@ -98,6 +194,8 @@ class GradAllReducer:
         communicator's stream, ordered after what the current stream holds so far, and `.wait()` orders the current stream after it."""
         if not self.active() or self._flat is None:
             return None
+        if self.comm is not None:
+            return self.comm.async_on_side_stream(self._flat)
         return dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def unpack(self):

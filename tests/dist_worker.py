@@ -198,7 +198,7 @@ def mode_nccl1(rank, world, dev):
         torch.manual_seed(42)
         model = CausalBioVAE3D().to(dev).train().set_compute_dtype(torch.bfloat16)
         opt = FusedAdam(model.parameters(), lr=1e-4, device_step=True)
-        red = GradAllReducer(model.parameters(), always_exchange=True)
+        red = GradAllReducer(model.parameters(), always_exchange=True, comm=COMM[0])
         assert red.active()
         if mode == "eager":
             losses = [float(train_step(model, opt, x, m, t, grad_hook=red)[0]) for _ in range(6)][3:]
@@ -215,14 +215,35 @@ def mode_nccl1(rank, world, dev):
     assert len(set(runs[0][0])) == 3
 
 
-MODES = dict(dp_step=mode_dp_step, sync_bn=mode_sync_bn, pos_weight=mode_pos_weight, eps=mode_eps, nccl1=mode_nccl1)
+COMM = [None]
+
+
+def mode_dp_abi1(rank, world, dev):
+    """The same three-way check with the exchange behind the C ABI of include/cvae_dp.h (libcvae_dp.so: cvae_dp_init on a fresh unique id, the bucket through
+    cvae_dp_allreduce_sum, the asynchronous exchange on the communicator's own stream) instead of torch.distributed — a one-rank communicator, so the sums
+    are the identity; what runs is the bootstrap, the handle's life cycle and the stream ordering around graph replays."""
+    from causal_vae_amd.parallel import RcclComm
+    COMM[0] = RcclComm()
+    assert COMM[0].world == 1 and COMM[0].rank == 0
+    flat = torch.arange(1000, dtype=torch.float32, device=dev)
+    COMM[0].all_reduce_sum(flat)
+    COMM[0].async_on_side_stream(flat).wait()
+    assert torch.equal(flat.cpu(), torch.arange(1000, dtype=torch.float32))
+    try:
+        mode_nccl1(rank, world, dev)
+    finally:
+        COMM[0].close()
+        COMM[0] = None
+
+
+MODES = dict(dp_step=mode_dp_step, sync_bn=mode_sync_bn, pos_weight=mode_pos_weight, eps=mode_eps, nccl1=mode_nccl1, dp_abi1=mode_dp_abi1)
 
 
 def main():
     mode = sys.argv[1]
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    backend = "nccl" if mode == "nccl1" else "gloo"
+    backend = "nccl" if mode in ("nccl1", "dp_abi1") else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(0)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)      # before any other GPU work of this process

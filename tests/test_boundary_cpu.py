@@ -38,6 +38,24 @@ def test_library_exports_every_header_symbol(built_lib):
     assert built_lib.cvae_strerror(0) == b"ok" and b"shape" in built_lib.cvae_strerror(-1)
 
 
+def test_dp_library_exports_every_header_symbol(built_lib):
+    """include/cvae_dp.h <-> libcvae_dp.so (the RCCL gradient exchange): every declared entry point is exported; argument checks that need no GPU and
+    no communicator answer with the documented codes (nothing here talks to RCCL)."""
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cvae_dp.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(cvae_dp_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) == 11, names
+    dp = ctypes.CDLL(os.path.join(ROOT, "causal_vae_amd", "libcvae_dp.so"))
+    for n in names:
+        assert hasattr(dp, n), f"{n} declared in include/cvae_dp.h but not exported by libcvae_dp.so"
+    dp.cvae_dp_strerror.restype = ctypes.c_char_p
+    assert dp.cvae_dp_version() >= 100 and dp.cvae_dp_strerror(0) == b"ok"
+    assert dp.cvae_dp_unique_id(None) == -2 and dp.cvae_dp_init(0, 1, None, None) == -2 and dp.cvae_dp_destroy(None) == -2
+    idbuf = (ctypes.c_char * 128)()
+    h = ctypes.c_void_p()
+    assert dp.cvae_dp_init(3, 2, idbuf, ctypes.byref(h)) == -1          # rank outside the world
+    assert dp.cvae_dp_allreduce_sum(None, None, ctypes.c_size_t(4), 0, None) == -2
+
+
 def test_ctypes_table_matches_header(built_lib):
     from causal_vae_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_functions()

@@ -35,3 +35,10 @@ def test_two_ranks_on_one_card_gloo(mode):
 def test_one_rank_rccl_group_with_graph_replay_and_async_exchange():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     _run([sys.executable, WORKER, "nccl1"], env, "nccl1")
+
+
+def test_one_rank_exchange_through_the_rccl_c_abi():
+    """include/cvae_dp.h: cvae_dp_init / cvae_dp_allreduce_sum behind GradAllReducer(comm=RcclComm()) — eager step, whole-step graph and split-backward capture
+    with the asynchronous exchange give the same training (one-rank communicator: bootstrap, handle life cycle and stream ordering, not wire traffic)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    _run([sys.executable, WORKER, "dp_abi1"], env, "dp_abi1")
