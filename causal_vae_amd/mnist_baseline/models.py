@@ -41,11 +41,12 @@ class CausalMorphVAE12(nn.Module):
         """Encoder half: enc_conv -> cat[x_feat, m, t] -> enc_fc; returns the [B, 2 z] head (mu | logvar) (models.py:55-60 of the reference)."""
         return self.enc_fc(self.enc_conv.forward_cat(x, [m, t]))
 
-    def forward_train(self, x, m, t, eps_vae=None, eps_adv=None):
+    def forward_train(self, x, m, t, eps_vae=None, eps_adv=None, h=None):
         """forward() plus what the adversarial step takes from the same latent head (train.py:65-81 of the reference): the KLD sum and the second
         sample z' = reparameterize(mu, logvar) that feeds the discriminator — mu | logvar are consumed where the encoder leaves them (ops.LatentHead),
         both noise draws are one Philox launch.  Returns (recon_x, m_hat, mu, logvar, kld, z_adv)."""
-        h = self.encode(x, m, t)
+        if h is None:                                        # h: the encoder head of THIS x, m, t at THESE weights, computed by the caller (train_step shares it with the D step)
+            h = self.encode(x, m, t)
         B, Z = h.shape[0], self.z_dim
         if eps_vae is None or eps_adv is None:
             e = self._eps.draw(h.new_empty(2 * B, Z))

@@ -26,24 +26,25 @@ def train_step(vae, discriminator, opt_vae, opt_d, x, m, t, eps=None, beta=None,
 
 def _train_step(vae, discriminator, opt_vae, opt_d, x, m, t, t_indices, eps_d, eps_vae, eps_adv, beta, lambda_adv):
     # ---- 1. discriminator ----
-    # the reference runs the whole VAE here (:47) and keeps mu, logvar: the decoder half of that no-grad forward reaches no result, so only
-    # the encoder half runs (same mu, logvar, bit for bit)
+    # The reference runs the whole VAE under no_grad here (:47) and keeps mu, logvar; the VAE step then runs the same encoder on the same x, m, t at the
+    # same weights (opt_d.step() in between touches the discriminator only, :57-59) — the two encoder passes compute the same numbers.  ONE encoder pass,
+    # with its autograd graph, serves both: the D step reads its values (detached), the VAE step continues from it (round 3: 9 launches fewer).
     opt_d.zero_grad(set_to_none=True)
+    opt_vae.zero_grad(set_to_none=True)
+    h = vae.encode(x, m, t)
     with torch.no_grad():
-        h = vae.encode(x, m, t)
-        z, _, _ = ops.LatentHead.apply(h, eps_d if eps_d is not None else vae._eps.draw(h.new_empty(h.shape[0], vae.z_dim)), None, False)
+        z, _, _ = ops.LatentHead.apply(h.detach(), eps_d if eps_d is not None else vae._eps.draw(h.new_empty(h.shape[0], vae.z_dim)), None, False)
     loss_d = ops.SoftmaxCE.apply(discriminator(z), t_indices)
     ops.backward_from(loss_d)
     opt_d.step()
     # ---- 2. VAE ----
-    # the adversarial term back-propagates THROUGH the discriminator; its own parameter gradients from this pass are dead in the reference too
+    # the adversarial term back-propagates THROUGH the (updated) discriminator; its own parameter gradients from this pass are dead in the reference too
     # (opt_d.zero_grad() drops them before the next D step reads anything), so they are not computed
-    opt_vae.zero_grad(set_to_none=True)
     d_params = [p for p in discriminator.parameters() if p.requires_grad]
     for p in d_params:
         p.requires_grad_(False)
     try:
-        recon_x, m_hat, mu, logvar, kld, z_sample = vae.forward_train(x, m, t, eps_vae, eps_adv)
+        recon_x, m_hat, mu, logvar, kld, z_sample = vae.forward_train(x, m, t, eps_vae, eps_adv, h=h)
         loss_recon = ops.bce_sum(recon_x.view(-1, 784), x.view(-1, 784))
         # loss = recon + BETA * kld + 100 * morph + LAMBDA_ADV * 100 * adv: one launch for the sum and the four logged terms, one for their gradients
         loss, parts = ops.weighted_sum([loss_recon, kld, ops.sse(m_hat, m), ops.UniformKL.apply(discriminator(z_sample))],
