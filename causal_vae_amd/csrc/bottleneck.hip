@@ -536,6 +536,25 @@ __device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n, i
         }
         return;                                              // the caller's next __syncthreads() publishes dzs
     }
+    if ((n & 3) == 0) {
+        // more 4-element groups than threads (M = 16: 16 x 76 floats = 304 groups): every thread takes several groups, 16 slot loads in flight each, slots
+        // added in index order.  (The element-wise loop below issued one DEPENDENT 4-byte load per slot: 256 slots = 256 round trips, 299 us for
+        // mulv_bwd at B = 16 — the other half of the 64^3 configuration's round-2 slowdown.)
+        for (int i4 = threadIdx.x; i4 < n4; i4 += nt) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int q = 0;
+            for (; q + 16 <= nslots; q += 16) {
+                float4 u[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) u[j] = *(const float4*)(dzm_acc + (size_t)(q + j) * n + 4 * i4);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
+            }
+            for (; q < nslots; ++q) { const float4 u = *(const float4*)(dzm_acc + (size_t)q * n + 4 * i4); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            *(float4*)(dzs + 4 * i4) = v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += nt) {
         float v = 0.f;
         for (int q = 0; q < nslots; ++q) v += dzm_acc[(size_t)q * n + i];
@@ -747,6 +766,9 @@ __global__ __launch_bounds__(256) void fc2_bwd_kernel(TailDims d, TailParams p, 
 // enc_fc.0 backward in one pass over W: thread owns column k; for its slice of rows n it writes dW[n][k] = sum_m g[m][n] x[m][k]
 // and accumulates dx[m][k] += g[m][n] W[n][k].  grid (ceil(K / 256), NS).  The partial dx of feature column f = c * S + s is
 // stored cell-major, dxp[ns][m][s][c], so pool_bwd reads it coalesced along c (columns >= F — m and t — need no gradient).
+struct __attribute__((packed, aligned(4))) F2U { float x, y; };                // float2 at dword alignment
+template <int MT> struct SkinnyBwdCols { static constexpr int value = 4; using vec = F4U; };
+template <> struct SkinnyBwdCols<16> { static constexpr int value = 2; using vec = F2U; };
 template <int MT>
 __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ Wt,
                                                                  float* __restrict__ dW, float* __restrict__ dxp, int M, int K, int N, int nslice, int F, int S,
@@ -757,16 +779,20 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
         return;
     }
     __shared__ float gs[MT][64];
-    // thread owns columns k0 .. k0 + 3: 16-byte loads of W and stores of dW at 4-byte alignment (rows of odd length K are not
-    // 16-byte aligned; global_load/store_dwordx4 take dword-aligned addresses), a quarter of the memory instructions of the scalar form
-    const int k0 = (blockIdx.x * 256 + threadIdx.x) * 4, ns = blockIdx.y;
+    // thread owns columns k0 .. k0 + CPT - 1: 16-byte (8-byte) loads of W and stores of dW at 4-byte alignment (rows of odd length K are not
+    // 16-byte aligned; global_load/store_dwordx4 take dword-aligned addresses), a quarter of the memory instructions of the scalar form.
+    // CPT = 4 up to 8 rows; 16 rows (the 64^3 fp32 configuration, B = 16) keep 2 columns per thread: x and the dx accumulators are 2 x MT x CPT registers,
+    // and with 4 columns the MT = 16 instance needed > 256 VGPRs (528 bytes of scratch per lane, one wave per SIMD: 494 us for this launch — 14 % of the
+    // whole 64^3 step, the "3.09 -> 3.5 ms" of round 2's record; with 2 columns it fits in 150).
+    constexpr int CPT = SkinnyBwdCols<MT>::value;
+    const int k0 = (blockIdx.x * 256 + threadIdx.x) * CPT, ns = blockIdx.y;
     const int n0 = ns * nslice, n1 = min(N, n0 + nslice);
-    const int nk = min(4, K - k0);                           // live columns of this thread (<= 0: none)
-    float xv[MT][4], acc[MT][4];
+    const int nk = min(CPT, K - k0);                         // live columns of this thread (<= 0: none)
+    float xv[MT][CPT], acc[MT][CPT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { xv[m][c] = (m < M && c < nk) ? x[(size_t)m * K + k0 + c] : 0.f; acc[m][c] = 0.f; }
+        for (int c = 0; c < CPT; ++c) { xv[m][c] = (m < M && c < nk) ? x[(size_t)m * K + k0 + c] : 0.f; acc[m][c] = 0.f; }
     for (int nb = n0; nb < n1; nb += 64) {
         const int cnt = min(64, n1 - nb);
         __syncthreads();
@@ -775,20 +801,24 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
             gs[m][j] = (m < M && j < cnt) ? g[(size_t)m * N + nb + j] : 0.f;
         }
         __syncthreads();
-        if (nk == 4) {
-#pragma unroll CVAE_BN_BWD_UNROLL
+        if (nk == CPT) {
+            constexpr int UNR = MT >= 16 ? 2 : CVAE_BN_BWD_UNROLL;      // an unrolled row holds MT values of g: 8 rows of 16 are 128 registers by themselves
+#pragma unroll UNR
             for (int j = 0; j < cnt; ++j) {
-                const F4U w = *(const F4U*)(Wt + (size_t)(nb + j) * K + k0);
-                F4U dw = {0.f, 0.f, 0.f, 0.f};
+                typename SkinnyBwdCols<MT>::vec w = *(const typename SkinnyBwdCols<MT>::vec*)(Wt + (size_t)(nb + j) * K + k0), dw;
+                const float* wf = (const float*)&w;
+                float* dwf = (float*)&dw;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) dwf[c] = 0.f;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const float gv = gs[m][j];
-                    dw.x += gv * xv[m][0]; dw.y += gv * xv[m][1]; dw.z += gv * xv[m][2]; dw.w += gv * xv[m][3];
-                    acc[m][0] += gv * w.x; acc[m][1] += gv * w.y; acc[m][2] += gv * w.z; acc[m][3] += gv * w.w;
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) { dwf[c] += gv * xv[m][c]; acc[m][c] += gv * wf[c]; }
                 }
-                *(F4U*)(dW + (size_t)(nb + j) * K + k0) = dw;
+                *(typename SkinnyBwdCols<MT>::vec*)(dW + (size_t)(nb + j) * K + k0) = dw;
             }
-        } else if (nk > 0) {                                 // the row tail (K % 4 columns)
+        } else if (nk > 0) {                                 // the row tail (K % CPT columns)
             for (int j = 0; j < cnt; ++j)
                 for (int c = 0; c < nk; ++c) {
                     const float w = Wt[(size_t)(nb + j) * K + k0 + c];
@@ -800,7 +830,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CPT; ++c) {
         const int k = k0 + c;
         if (k < F) {
             const int ch = k / S, sp = k - ch * S, C = F / S;
@@ -912,7 +942,7 @@ template <int MT>
 static void launch_bwd_colwise(const float* g, const float* x, const float* W1, float* dW, float* dxp, int M, int K, int N, int NS, int F, int S, const TailDims& d,
                                const TailParams& p, const TailGrads& tg, const TailSaved& sv, const MechBwdArgs& mb, hipStream_t st) {
     const int nslice = (N + NS - 1) / NS;
-    hipLaunchKernelGGL(skinny_bwd_colwise_kernel<MT>, dim3((unsigned)((K + 1023) / 1024), (unsigned)(NS + 1)), dim3(256), mech_bwd_lds(d), st, g, x, W1, dW, dxp, M, K, N,
+    hipLaunchKernelGGL(skinny_bwd_colwise_kernel<MT>, dim3((unsigned)((K + 256 * SkinnyBwdCols<MT>::value - 1) / (256 * SkinnyBwdCols<MT>::value)), (unsigned)(NS + 1)), dim3(256), mech_bwd_lds(d), st, g, x, W1, dW, dxp, M, K, N,
                        nslice, F, S, NS, d, p, tg, sv, mb);
 }
 
