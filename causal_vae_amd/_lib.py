@@ -53,10 +53,12 @@ SIGNATURES = {
     "cvae_quantize_fp8_dev": [_p, _i, _p, _i64, _p, _p, _p],
     "cvae_absmax": [_p, _i, _i64, _p, _p],
     "cvae_conv_pack_weights_fp8": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
-    "cvae_conv_fp8": [_i, _p, _p, _p, _p, _i, _p, _p, _f, _f, _p] + [_i64] * 9 + [_i, _i, _p, _sz, _i, _p],
+    "cvae_conv_fp8": [_i, _p, _p, _p, _p, _i, _p, _p, _f, _f, _p] + [_i64] * 9 + [_i, _i, _p, _sz, _i, _p, _p],
+    "cvae_conv_down_bits": [_p, _p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
+    "cvae_conv_up_bits": [_p, _p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _p],
     "cvae_fp8_scale_update": [_p, _p, _p, _i, _f, _p, _p, _p, _i, _p, _p, _p],
     "cvae_conv_pack_weight_pairs_f8": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "cvae_conv_down_image_f8": [_p, _i, _p, _p, _p, _p, _p, _p] + [_i64] * 8 + [_i, _i, _p],
+    "cvae_conv_down_image_f8": [_p, _i, _p, _p, _p, _p, _p, _p, _p] + [_i64] * 8 + [_i, _i, _p],
     "cvae_conv_image_supported": [_p, _i64, _i, _i],
     "cvae_conv_down_image": [_p, _i, _p, _p, _p, _p] + [_i64] * 8 + [_i, _i, _i, _p],
     "cvae_conv_wgrad_image": [_p, _p, _i, _p, _p, _p, _sz] + [_i64] * 8 + [_i, _i, _p],

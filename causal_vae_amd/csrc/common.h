@@ -76,7 +76,25 @@ struct F8Side {
     const float* dscale;
     fp8* out8;
     unsigned* amax;
+    // ReLU masks as bits (round 3): one bit per element of the result, in element order — dword i covers elements 32 i .. 32 i + 31 (channel counts are
+    // multiples of 32: a dword is one position's 32-channel block), bit set <=> element > 0.  `bits_out`: the producing launch leaves the mask of ITS result
+    // (1/16 of the bf16 bytes) so that the backward launch that applies this ReLU reads `mask_bits` instead of the whole saved activation.
+    const unsigned* mask_bits;
+    unsigned* bits_out;
 };
+// this lane's two mask bytes (channels 8h..8h+7 -> `b0`, 16+8h..23+8h -> `b1` of its position's 32-channel block) -> the block's dword, in the lanes with
+// h = 0 (one v_permlane32_swap; every lane must take part)
+__device__ __forceinline__ unsigned mask_bytes_to_dword(unsigned b0, unsigned b1) {
+    const unsigned a = b0 | (b1 << 16);
+    const auto x = __builtin_amdgcn_permlane32_swap(a, a, false, false);       // lanes 0-31: (own, the partner lane's)
+    return (x[0] & 0xffu) | ((x[1] & 0xffu) << 8) | (((x[0] >> 16) & 0xffu) << 16) | ((x[1] >> 16) << 24);
+}
+__device__ __forceinline__ unsigned mask_byte_of(const float (&v)[8]) {
+    unsigned b = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b |= (v[q] > 0.f ? 1u : 0u) << q;
+    return b;
+}
 // max |.| of the workgroup (`red`: one float per wave, in LDS), then ONE atomicMax per WORKGROUP on the slot of its linear index: with
 // CVAE_AMAX_SLOTS = 4096 the workgroups of a launch rarely share a word.  (One atomic per wave on 64 slots cost the 64 -> 32 channel layer 14 of
 // its 23 us: same-address atomics serialise at the memory side at ~100 ns each.)  Every thread of the workgroup must call this.

@@ -295,16 +295,27 @@ __global__ __launch_bounds__(256) void down_c1_vec_kernel(const TL* __restrict__
                 for (int j = 0; j < 2; ++j) {
                     const int c = 16 * j + 8 * h;
                     if constexpr (MASKED) {
-                        __attribute__((aligned(16))) bf16 mv[8];
-                        *(uint4*)mv = *(const uint4*)(mask + tile_org + loff + c);
+                        if (f8.mask_bits) {                  // the position's 32-channel dword (F8Side, common.h) instead of 16 bytes of the saved activation
+                            const unsigned mb = f8.mask_bits[(tile_org + loff) >> 5] >> c;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
+                            for (int q = 0; q < 8; ++q)
+                                if (!((mb >> q) & 1u)) v[j][q] = 0.f;
+                        } else {
+                            __attribute__((aligned(16))) bf16 mv[8];
+                            *(uint4*)mv = *(const uint4*)(mask + tile_org + loff + c);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
+                        }
                     }
                     *(uint4*)(S + tile_org + loff + c) = make_uint4(pack2_bf16(v[j][0], v[j][1]), pack2_bf16(v[j][2], v[j][3]), pack2_bf16(v[j][4], v[j][5]), pack2_bf16(v[j][6], v[j][7]));
                 }
             }
             if constexpr (SIDE8) {
+                if (f8.bits_out) {                            // every lane takes part in the lane swap; lanes h = 0 store the position's dword
+                    const unsigned dw = mask_bytes_to_dword(mask_byte_of(v[0]), mask_byte_of(v[1]));
+                    if (ok && h == 0) f8.bits_out[(tile_org + loff) >> 5] = dw;
+                }
                 if (ok && f8.amax) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) amx = fmaxf(amx, fmaxf(fabsf(v[0][q]), fabsf(v[1][q])));
@@ -959,8 +970,9 @@ int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* b
                       int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, F8Side f8) {
     if (Cs != 32) return CVAE_E_UNSUPPORTED;
     const int epi = CVAE_EPI_OF(act);
-    const bool side8 = f8.out8 || f8.amax;
-    if (side8 && !(dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype) && !mask)) return CVAE_E_UNSUPPORTED;
+    const bool side8 = f8.out8 || f8.amax || f8.bits_out;
+    if (side8 && !(dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype) && !mask && !f8.mask_bits)) return CVAE_E_UNSUPPORTED;
+    if (f8.mask_bits && !(dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype))) return CVAE_E_UNSUPPORTED;
     if (dtype == CVAE_BF16 && image_vec_ok(L, lw, l_dtype)) {          // bf16 output: the 16-byte-load form, image in its own dtype
         // 512 positions per workgroup once that still leaves ~4 workgroups per CU, else 256
         const bool big = B * ((sd + 1) / 2) * ((sh + 7) / 8) * ((sw + 31) / 32) >= 1024 || nd == 2;
@@ -974,7 +986,7 @@ int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* b
 #define LAUNCH_DOWN_VEC__(TLT, ND, EPI, MASKED, MS, SIDE)                                                                                              \
     hipLaunchKernelGGL((down_c1_vec_kernel<TLT, ND, EPI, MASKED, MS, SIDE>), grid, dim3(256), 0, stream, (const TLT*)L, w, bias, (const bf16*)mask, (bf16*)S, (int)sd, (int)sh, \
                        (int)sw, (int)ld, (int)lh, (int)lw, tiles_d, tiles_h, tiles_w, ntiles, act, f8)
-#define LAUNCH_DOWN_VEC_(TLT, ND, EPI, MS) do { if (mask) LAUNCH_DOWN_VEC__(TLT, ND, EPI, true, MS, false); else if (side8) LAUNCH_DOWN_VEC__(TLT, ND, EPI, false, MS, true); \
+#define LAUNCH_DOWN_VEC_(TLT, ND, EPI, MS) do { if (mask || f8.mask_bits) LAUNCH_DOWN_VEC__(TLT, ND, EPI, true, MS, false); else if (side8) LAUNCH_DOWN_VEC__(TLT, ND, EPI, false, MS, true); \
                                                 else LAUNCH_DOWN_VEC__(TLT, ND, EPI, false, MS, false); } while (0)
 #define LAUNCH_DOWN_VEC(TLT, ND, MS)                                                                                                      \
     do { if (epi == 0) LAUNCH_DOWN_VEC_(TLT, ND, 0, MS); else if (epi == 1) LAUNCH_DOWN_VEC_(TLT, ND, 1, MS); else LAUNCH_DOWN_VEC_(TLT, ND, 2, MS); } while (0)

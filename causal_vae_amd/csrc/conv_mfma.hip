@@ -407,7 +407,8 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
     constexpr int MO = MI / TS;                               // M sub-tiles this wave finishes (TS = 2: the other half goes to its partner wave)
     const int mi0 = ts * MO;
     float bpre[NI][2][8];
-    Piece<TO> mpre[MO][NI][2];
+    unsigned mbw[MO][NI];                                    // ReLU mask of this lane's channels, as bits of the position's 32-channel block dword
+    const bool masked = !F8 && (mask || f8.mask_bits);
     const int out_d = UP ? g.ld : g.sd, out_h = UP ? g.lh : g.sh, out_w = UP ? g.lw : g.sw;
     if (ksplit == 1) {
 #pragma unroll
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
 #pragma unroll
                 for (int q = 0; q < 8; ++q) bpre[ni][j][q] = bias ? bias[c + q] : 0.f;
             }
-        if (!F8 && mask) {                                   // fp8 products are forward products: no mask, and no registers held for one
+        if (masked) {                                        // fp8 products are forward products: no mask
 #pragma unroll
             for (int mo = 0; mo < MO; ++mo) {
                 const int mi = mi0 + mo, ms = wm * MI + mi;
@@ -430,9 +431,22 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
                 const bool ok = od < out_d && oh < out_h && ow < out_w && b + sx < g.B;
                 const size_t pidx = ok ? ((((size_t)(b + sx) * out_d + od) * out_h + oh) * out_w + ow) * Cout : 0;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (f8.mask_bits) {                      // one dword per (position, 32-channel block) instead of two 16-byte pieces of the saved activation
+                        mbw[mo][ni] = f8.mask_bits[(pidx + n0 + (wn * NI + ni) * 32) >> 5];
+                    } else {                                 // the activation itself as the mask (callers without the bit form): turned into bits here
+                        unsigned wbits = 0;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) piece_load_raw<TO>(mpre[mo][ni][j], mask + pidx + n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h);
+                        for (int j = 0; j < 2; ++j) {
+                            Piece<TO> mp;
+                            piece_load_raw<TO>(mp, mask + pidx + n0 + (wn * NI + ni) * 32 + 16 * j + 8 * h);
+                            const TO* mv = (const TO*)&mp;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) wbits |= (to_f32(mv[q]) > 0.f ? 1u : 0u) << (16 * j + 8 * h + q);
+                        }
+                        mbw[mo][ni] = wbits;
+                    }
+                }
             }
         }
     }
@@ -642,11 +656,11 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
                     v[j][q] = x;
                 }
                 if (!ok) continue;
-                if (!F8 && mask) {
-                    const TO* mv = (const TO*)&mpre[mo][ni][j];
+                if (masked) {
+                    const unsigned mb = mbw[mo][ni] >> (16 * j + 8 * h);
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        if (!(to_f32(mv[q]) > 0.f)) v[j][q] = 0.f;
+                        if (!((mb >> q) & 1u)) v[j][q] = 0.f;
                 }
                 if constexpr (F8) {
                     if (f8.amax) {
@@ -664,6 +678,10 @@ __global__ __launch_bounds__(WM * WN * TS * 64, BD ? 2 : 1) void conv_data_kerne
                     for (int q = 0; q < 8; ++q) ov[q] = from_f32<TO>(v[j][q]);
                     piece_store<TO>(op, (char*)(out + pidx + c));
                 }
+            }
+            if (f8.bits_out) {                               // uniform: every lane takes part in the lane swap; lanes h = 0 store the block's dword
+                const unsigned dw = mask_bytes_to_dword(mask_byte_of(v[0]), mask_byte_of(v[1]));
+                if (ok && h == 0) f8.bits_out[(pidx + n0 + (wn * NI + ni) * 32) >> 5] = dw;
             }
             if constexpr (F8) {
                 // the fp8 copy of this 32-channel block: 16 bytes per lane (all lanes take part in the lane swap; `ok` only guards the store)
@@ -712,19 +730,27 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
         const float accs = f8.dscale ? f8.dscale[0] : acc_scale;
         const int c = (int)(i8 % Cout);
         Piece<T> mp, op;
-        if (mask) piece_load_raw<T>(mp, mask + i8);
-        const T* mv = (const T*)&mp;
+        unsigned mb = 0xffu;
+        if (f8.mask_bits) mb = ((const unsigned char*)f8.mask_bits)[i8 >> 3];
+        else if (mask) {
+            piece_load_raw<T>(mp, mask + i8);
+            const T* mv = (const T*)&mp;
+            mb = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mb |= (to_f32(mv[q]) > 0.f ? 1u : 0u) << q;
+        }
         T* ov = (T*)&op;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             float x = v[q] * accs + (bias ? bias[c + q] : 0.f);
             x = apply_act_t<EPI>(x, act);
-            if (mask && !(to_f32(mv[q]) > 0.f)) x = 0.f;
+            if (!((mb >> q) & 1u)) x = 0.f;
             v[q] = x;
             ov[q] = from_f32<T>(x);
             amx = fmaxf(amx, fabsf(x));
         }
         piece_store<T>(op, (char*)(out + i8));
+        if (f8.bits_out) ((unsigned char*)f8.bits_out)[i8 >> 3] = (unsigned char)mask_byte_of(v);
         if (f8.out8) *(uint2*)(f8.out8 + i8) = pack8_fp8(v, f8.dscale ? f8.dscale[1] : 1.f);
     }
     __shared__ float red[4];
@@ -811,18 +837,18 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
 }
 
 template <typename T, int ND, bool UP, int WM, int WN, int MI, int NI, int TS = 1>
-int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* ws, size_t wsb, hipStream_t stream, UpVariant var = UpVariant{}) {
+int launch_data(const void* in, const void* wp, const float* bias, const void* mask, void* out, ConvGeom g, int act, void* ws, size_t wsb, hipStream_t stream, UpVariant var = UpVariant{}, F8Side side = F8Side{nullptr, nullptr, nullptr}) {
     constexpr bool BDX = CVAE_BDIRECT && sizeof(T) == 2 && WM <= 2;
     // 32-channel stages pay where the K loop is long and the grid small (measured: Cin 256: -12 %, 128: -5 %, 64: +2 %)
     if (UP && sizeof(T) == 2 && g.Cs >= 128 && (g.Cs % 32) == 0) {
         constexpr int KH2 = (UP && sizeof(T) == 2) ? 2 : 1;
-        if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
-        if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
-        return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
+        if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, side, var);
+        if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, side, var);
+        return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, KH2, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, side, var);
     }
-    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
-    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
-    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, F8Side{nullptr, nullptr, nullptr}, var);
+    if (act == CVAE_ACT_NONE) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 0, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, side, var);
+    if (act == CVAE_ACT_RELU) return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 1, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, side, var);
+    return launch_data_epi<T, ND, UP, WM, WN, MI, NI, 2, 1, T, BDX, TS>(in, wp, bias, mask, out, g, act, ws, wsb, stream, 1.f, 1.f, side, var);
 }
 
 // Workspace the split-K path of launch_data would use for this geometry (0: the launch fills the chip without it).
@@ -1920,28 +1946,47 @@ extern "C" size_t cvae_conv_data_workspace_bytes(int64_t B, int64_t sd, int64_t 
     return nd == 3 ? data_workspace_bytes<3, true, 256, 32>(g) : data_workspace_bytes<2, true, 256, 32>(g);
 }
 
-extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
-                              int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
-                              int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+static int conv_down_impl(const void* L, const void* w, const float* bias, const void* mask, void* S,
+                          int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                          int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                          void* workspace, size_t workspace_bytes, void* stream, F8Side side) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (B == 0) return CVAE_OK;
     if (!L || !w || !S) return CVAE_E_NULLPTR;
     hipStream_t st = (hipStream_t)stream;
-    if (Cl == 1) return cvae_conv_down_c1(L, dtype, (const float*)w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st);
+    if (Cl == 1) return cvae_conv_down_c1(L, dtype, (const float*)w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, st, side);
     if (Cl % 16 || Cs % 64) return CVAE_E_UNSUPPORTED;
     GEOM_INIT();
 #if CVAE_KSPLIT_WAVES
-    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
-                                           : launch_data<bf16, 2, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side)
+                                           : launch_data<bf16, 2, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side);
 #endif
-    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
-                                           : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
-    return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st)
-                   : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st);
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side)
+                                           : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side);
+    return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side)
+                   : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side);
 }
 
+extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
+                              int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                              int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_down_impl(L, w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, F8Side{nullptr, nullptr, nullptr});
+}
+// cvae_conv_down / cvae_conv_up with ReLU masks as BITS (F8Side, common.h): mask_bits replaces `mask` (1 bit per element of the result instead of the saved
+// activation: 1/16 of the bytes the backward launch reads for it), relu_bits_out receives the mask of THIS launch's result for the backward pass to come.
+static bool bits_ok(int64_t Cout) { return Cout % 32 == 0; }
+extern "C" int cvae_conv_down_bits(const void* L, const void* w, const float* bias, const void* mask_bits, void* S, void* relu_bits_out,
+                                   int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                                   int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if ((mask_bits || relu_bits_out) && !bits_ok(Cs)) return CVAE_E_UNSUPPORTED;
+    if (Cl == 1 && mask_bits && !(dtype == CVAE_BF16)) return CVAE_E_UNSUPPORTED;
+    F8Side side{nullptr, nullptr, nullptr};
+    side.mask_bits = (const unsigned*)mask_bits; side.bits_out = (unsigned*)relu_bits_out;
+    return conv_down_impl(L, w, bias, nullptr, S, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, side);
+}
 // ---- the single-channel image end of the network, image read in the dtype it is stored in (no cast pass in front of the first conv) ----
 extern "C" int cvae_conv_image_supported(const void* L, int64_t lw, int l_dtype, int dtype) {
     if (l_dtype == dtype) return 1;
@@ -1958,13 +2003,16 @@ extern "C" int cvae_conv_down_image(const void* L, int l_dtype, const float* w, 
     return cvae_conv_down_c1(L, l_dtype, w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, dtype, act, (hipStream_t)stream);
 }
 extern "C" int cvae_conv_down_image_f8(const void* L, int l_dtype, const float* w, const float* bias, void* S, void* S8, const float* inv_scale_dev, void* amax_slots,
-                                       int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int act, void* stream) {
+                                       void* relu_bits_out, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int act,
+                                       void* stream) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, 1, nd)) return CVAE_E_BADSHAPE;
     if (l_dtype != CVAE_F32 && l_dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (B == 0) return CVAE_OK;
     if (!L || !w || !S || (S8 && !inv_scale_dev)) return CVAE_E_NULLPTR;
     if (!cvae_conv_image_supported(L, lw, l_dtype, CVAE_BF16) && l_dtype != CVAE_BF16) return CVAE_E_UNSUPPORTED;
-    return cvae_conv_down_c1(L, l_dtype, w, bias, nullptr, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, CVAE_BF16, act, (hipStream_t)stream, F8Side{inv_scale_dev, (fp8*)S8, (unsigned*)amax_slots});
+    F8Side side{inv_scale_dev, (fp8*)S8, (unsigned*)amax_slots};
+    side.bits_out = (unsigned*)relu_bits_out;
+    return cvae_conv_down_c1(L, l_dtype, w, bias, nullptr, S, B, sd, sh, sw, Cs, ld, lh, lw, nd, CVAE_BF16, act, (hipStream_t)stream, side);
 }
 extern "C" int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, void* stream) {
@@ -1983,7 +2031,7 @@ extern "C" int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, 
 static int conv_up_impl(const void* S, const void* w, const float* bias, const void* mask, void* L,
                         int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                         int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
-                        void* workspace, size_t workspace_bytes, void* stream, UpVariant var) {
+                        void* workspace, size_t workspace_bytes, void* stream, UpVariant var, F8Side side = F8Side{nullptr, nullptr, nullptr}) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (B == 0) return CVAE_OK;
@@ -1994,19 +2042,20 @@ static int conv_up_impl(const void* S, const void* w, const float* bias, const v
     GEOM_INIT();
     const bool wide = (Cl % 64) == 0;     // N tile 64 (2x2 waves, 128 rows) else N tile 32 (4x1 waves, 256 rows)
     if (dtype == CVAE_BF16) {
-        int rc;
-        if (nd == 3) rc = wide ? try_up_full<bf16, 3, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st, var) : try_up_full<bf16, 3, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st, var);
+        int rc = CVAE_E_UNSUPPORTED;
+        if (side.mask_bits || side.bits_out) {}      // the whole-K kernel knows the tensor form of the mask only (inference sweeps: no mask at all)
+        else if (nd == 3) rc = wide ? try_up_full<bf16, 3, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st, var) : try_up_full<bf16, 3, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st, var);
         else rc = wide ? try_up_full<bf16, 2, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, st, var) : try_up_full<bf16, 2, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, st, var);
         if (rc != CVAE_E_UNSUPPORTED) return rc;
 #if CVAE_KSPLIT_WAVES
-        if (wide) return nd == 3 ? launch_data<bf16, 3, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var)
-                                 : launch_data<bf16, 2, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
+        if (wide) return nd == 3 ? launch_data<bf16, 3, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side)
+                                 : launch_data<bf16, 2, true, 1, 2, 4, 1, 2>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side);
 #endif
-        if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
-        return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
+        if (nd == 3) return wide ? launch_data<bf16, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side) : launch_data<bf16, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side);
+        return wide ? launch_data<bf16, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side) : launch_data<bf16, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side);
     }
-    if (nd == 3) return wide ? launch_data<float, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<float, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
-    return wide ? launch_data<float, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var) : launch_data<float, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var);
+    if (nd == 3) return wide ? launch_data<float, 3, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side) : launch_data<float, 3, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side);
+    return wide ? launch_data<float, 2, true, 2, 2, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side) : launch_data<float, 2, true, 4, 1, 2, 1>(S, w, bias, mask, L, g, act, workspace, workspace_bytes, st, var, side);
 }
 
 extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, const void* mask, void* L,
@@ -2014,6 +2063,15 @@ extern "C" int cvae_conv_up(const void* S, const void* w, const float* bias, con
                             int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
                             void* workspace, size_t workspace_bytes, void* stream) {
     return conv_up_impl(S, w, bias, mask, L, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, UpVariant{});
+}
+extern "C" int cvae_conv_up_bits(const void* S, const void* w, const float* bias, const void* mask_bits, void* L, void* relu_bits_out,
+                                 int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                                 int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if ((mask_bits || relu_bits_out) && (!bits_ok(Cl) || Cl == 1)) return CVAE_E_UNSUPPORTED;
+    F8Side side{nullptr, nullptr, nullptr};
+    side.mask_bits = (const unsigned*)mask_bits; side.bits_out = (unsigned*)relu_bits_out;
+    return conv_up_impl(S, w, bias, nullptr, L, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, UpVariant{}, side);
 }
 extern "C" int cvae_conv_up_variant(const void* S, const void* w, const float* bias, const void* mask, void* L,
                                     int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
@@ -2268,7 +2326,7 @@ static int conv_fp8_t(const void* in, const void* w, const float* bias, void* ou
 }
 extern "C" int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, void* out, int out_dtype, void* out8, const float* dscale, float acc_scale,
                              float out8_inv_scale, void* amax_slots, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl,
-                             int nd, int act, void* workspace, size_t workspace_bytes, int xpair, void* stream) {
+                             int nd, int act, void* workspace, size_t workspace_bytes, int xpair, void* relu_bits_out, void* stream) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd) || (up != 0 && up != 1) || xpair < -1 || xpair > 1) return CVAE_E_BADSHAPE;
     if (out_dtype != CVAE_FP8 && out_dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (!dscale && (!(acc_scale > 0.f) || ((out_dtype == CVAE_FP8 || out8) && !(out8_inv_scale > 0.f)))) return CVAE_E_BADSHAPE;
@@ -2279,7 +2337,8 @@ extern "C" int cvae_conv_fp8(int up, const void* in8, const void* w8, const floa
     if (up ? (lh != 2 * sh || lw != 2 * sw || (nd == 3 && ld != 2 * sd)) : false) return CVAE_E_UNSUPPORTED;   // forward products only: exact 2x extents
     GEOM_INIT();
     hipStream_t st = (hipStream_t)stream;
-    const F8Side f8{dscale, (fp8*)out8, (unsigned*)amax_slots};
+    F8Side f8{dscale, (fp8*)out8, (unsigned*)amax_slots};
+    f8.bits_out = (unsigned*)relu_bits_out;
     UpVariant var;
     var.xpair = xpair;
 #define F8D(ND_, UP_) (out_dtype == CVAE_FP8 ? conv_fp8_t<ND_, UP_, fp8>(in8, w8, bias, out, g, act, acc_scale, out8_inv_scale, f8, nullptr, 0, st, var) \
@@ -2293,5 +2352,5 @@ extern "C" int cvae_conv_up_fp8(const void* S, const void* w, const float* bias,
                                 int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                                 void* stream) {
     return cvae_conv_fp8(1, S, w, bias, L, out_dtype, nullptr, nullptr, acc_scale, out_dtype == CVAE_FP8 ? out_inv_scale : 1.f, nullptr, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, act,
-                         nullptr, 0, -1, stream);
+                         nullptr, 0, -1, nullptr, stream);
 }

@@ -384,28 +384,58 @@ def image_direct_ok(x, dtype):
                                                                                         L.dtype_code(x.dtype), L.dtype_code(dtype)))
 
 
-def _conv_down(Lt, wp, bias, mask, Cs, nd, act, out_dtype=None):
+MASK_BITS = __import__("os").environ.get("CVAE_MASK_BITS", "1") != "0"     # (env switch: A/B runs) ReLU masks travel as bits (1/16 of the saved activation's bytes) wherever producer and consumer are this library's conv launches
+BITS_STATS = {"produced": 0, "consumed": 0}      # launches that left / read a mask in bit form (tests check that the model really takes the path)
+
+
+def _bits_for(t):
+    """int32 tensor for the ReLU mask bits of channels-last tensor `t` (one dword per 32 consecutive elements), or None when the channel count does not allow it."""
+    return torch.empty(t.numel() // 32, dtype=torch.int32, device=t.device) if (t.shape[-1] % 32 == 0 and t.numel() % 32 == 0) else None
+
+
+def _conv_down(Lt, wp, bias, mask, Cs, nd, act, out_dtype=None, mask_bits=None, want_bits=None):
+    """mask_bits: the ReLU mask as bits (replaces `mask`).  want_bits (True / False; None = plain return): return (S, bits) — the ReLU mask bits of the result
+    when asked for and supported, else None."""
     B, ld, lh, lw, Cl = _cl_dims(Lt)
     sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
     if out_dtype is not None and out_dtype != Lt.dtype:      # single-channel image read in its own dtype, S in the compute dtype
         if Cl != 1:
             raise L.CvaeError("a mixed-dtype conv is available for the single-channel image layer only")
         S = _empty((B, sd, sh, sw, Cs), out_dtype, Lt)
-        check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down_image, ptr(Lt), L.dtype_code(Lt.dtype), ptr(wp), ptr(bias), ptr(mask), ptr(S),
-                      B, sd, sh, sw, Cs, ld, lh, lw, nd, L.dtype_code(out_dtype), L.act_code(act), stream()), "conv_down_image")
-        return S
+        bits = _bits_for(S) if (want_bits and out_dtype == torch.bfloat16 and mask is None) else None
+        if bits is not None:
+            check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down_image_f8, ptr(Lt), L.dtype_code(Lt.dtype), ptr(wp), ptr(bias), ptr(S), None, None,
+                          None, ptr(bits), B, sd, sh, sw, Cs, ld, lh, lw, nd, L.act_code(act), stream()), "conv_down_image_f8")
+        else:
+            check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down_image, ptr(Lt), L.dtype_code(Lt.dtype), ptr(wp), ptr(bias), ptr(mask), ptr(S),
+                          B, sd, sh, sw, Cs, ld, lh, lw, nd, L.dtype_code(out_dtype), L.act_code(act), stream()), "conv_down_image")
+        return (S, bits) if want_bits is not None else S
     S = _empty((B, sd, sh, sw, Cs), Lt.dtype, Lt)
     ws, nbytes = _conv_data_workspace(Lt.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, 0)
-    check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down, ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S),
+    label = f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}"
+    # the bit forms: MFMA layers in any dtype; the single-channel end (dec4's data gradient applies d3's mask) in its bf16 16-byte-row form only
+    c1_ok = Cl != 1 or (Lt.dtype == torch.bfloat16 and lw % 8 == 0)
+    bits = _bits_for(S) if (want_bits and Cl != 1 and Cs % 64 == 0 and Cl % 16 == 0) else None
+    use_mb = mask_bits if (mask_bits is not None and c1_ok) else None      # the bit form of the mask wins over the tensor form when the launch can read it
+    if use_mb is None and mask is not None:
+        bits = None                                          # a tensor mask: the plain entry point (backward launches want no bits of their own anyway)
+    if use_mb is not None or bits is not None:
+        check(L.timed(label, lib.cvae_conv_down_bits, ptr(Lt), ptr(wp), ptr(bias), ptr(use_mb), ptr(S), ptr(bits), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(Lt.dtype),
+                      L.act_code(act), ptr(ws), nbytes, stream()), "conv_down_bits")
+        BITS_STATS["produced"] += bits is not None
+        BITS_STATS["consumed"] += use_mb is not None
+        return (S, bits) if want_bits is not None else S
+    check(L.timed(label, lib.cvae_conv_down, ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S),
                   B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(Lt.dtype), L.act_code(act), ptr(ws), nbytes, stream()), "conv_down")
-    return S
+    return (S, None) if want_bits is not None else S
 
 
 UP_VARIANT = None    # test hook: (upfull, xpair, c1_walk_units) for cvae_conv_up_variant / the xpair of cvae_conv_fp8; None = the library's automatic choice
 
 
-def _conv_up(St, wp, bias, mask, Cl, nd, act, l_dims=None):
-    """l_dims: spatial extent (ld, lh, lw) of the result when it is not 2 s — the data gradient of a conv over an odd extent (l = 2 s + 1)."""
+def _conv_up(St, wp, bias, mask, Cl, nd, act, l_dims=None, mask_bits=None, want_bits=None):
+    """l_dims: spatial extent (ld, lh, lw) of the result when it is not 2 s — the data gradient of a conv over an odd extent (l = 2 s + 1).
+    mask_bits / want_bits: as in _conv_down."""
     B, sd, sh, sw, Cs = _cl_dims(St)
     ld, lh, lw = ((2 * sd if nd == 3 else 1), 2 * sh, 2 * sw) if l_dims is None else tuple(int(v) for v in l_dims)
     Lt = _empty((B, ld, lh, lw, Cl), St.dtype, St)
@@ -413,10 +443,20 @@ def _conv_up(St, wp, bias, mask, Cl, nd, act, l_dims=None):
     if UP_VARIANT is not None:
         check(lib.cvae_conv_up_variant(ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), L.act_code(act),
                                        ptr(ws), nbytes, int(UP_VARIANT[0]), int(UP_VARIANT[1]), int(UP_VARIANT[2]), stream()), "conv_up_variant")
-        return Lt
-    check(L.timed(f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}", lib.cvae_conv_up, ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt),
+        return (Lt, None) if want_bits is not None else Lt
+    label = f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}"
+    bits_ok = Cl != 1 and Cl % 32 == 0 and Cs % 16 == 0
+    use_mb = mask_bits if (mask_bits is not None and bits_ok) else None
+    bits = _bits_for(Lt) if (want_bits and bits_ok and (mask is None or use_mb is not None)) else None
+    if use_mb is not None or bits is not None:
+        check(L.timed(label, lib.cvae_conv_up_bits, ptr(St), ptr(wp), ptr(bias), ptr(use_mb), ptr(Lt), ptr(bits), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype),
+                      L.act_code(act), ptr(ws), nbytes, stream()), "conv_up_bits")
+        BITS_STATS["produced"] += bits is not None
+        BITS_STATS["consumed"] += use_mb is not None
+        return (Lt, bits) if want_bits is not None else Lt
+    check(L.timed(label, lib.cvae_conv_up, ptr(St), ptr(wp), ptr(bias), ptr(mask), ptr(Lt),
                   B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(St.dtype), L.act_code(act), ptr(ws), nbytes, stream()), "conv_up")
-    return Lt
+    return (Lt, None) if want_bits is not None else Lt
 
 
 DEFER_WGRAD = True     # weight gradients of the MFMA conv layers are queued during a backward pass and computed by ONE grouped launch (+ one
@@ -569,15 +609,21 @@ class ConvDown(torch.autograd.Function):
             sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
             y = _empty((B, sd, sh, sw, Cs), torch.bfloat16, x)
             y8 = torch.empty((B, sd, sh, sw, Cs), dtype=torch.uint8, device=x.device)
+            f8["bits"] = _bits_for(y) if (MASK_BITS and act == "relu") else None
             check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down_image_f8, ptr(x), L.dtype_code(x.dtype), ptr(weight.contiguous()), ptr(bias),
-                          ptr(y), ptr(y8), ptr(f8["inv_scale"]), ptr(f8.get("amax")), B, sd, sh, sw, Cs, ld, lh, lw, nd, L.act_code(act), stream()), "conv_down_image_f8")
+                          ptr(y), ptr(y8), ptr(f8["inv_scale"]), ptr(f8.get("amax")), ptr(f8["bits"]), B, sd, sh, sw, Cs, ld, lh, lw, nd, L.act_code(act), stream()), "conv_down_image_f8")
             f8["y8"] = y8
+            bits = f8.get("bits")
         elif f8 is not None:
-            res = conv_fp8(False, f8["xq"], f8["wq"], bias, Cs, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"))
-            y, f8["y8"] = res if isinstance(res, tuple) else (res, None)
+            want_bits = MASK_BITS and act == "relu"
+            res = conv_fp8(False, f8["xq"], f8["wq"], bias, Cs, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"), want_bits=want_bits)
+            y, f8["y8"], bits = res
         else:
             wp = packed[0] if packed is not None else pack_weight(weight, nd, False, out_dtype or x.dtype)
-            y = _conv_down(x, wp, bias, None, Cs, nd, act, out_dtype)
+            y, bits = _conv_down(x, wp, bias, None, Cs, nd, act, out_dtype, want_bits=MASK_BITS and act == "relu")
+        if bits is not None:
+            y._relu_bits = bits                              # travels with the activation to the layer whose backward applies this ReLU
+        ctx.x_bits = getattr(x, "_relu_bits", None) if (MASK_BITS and in_is_relu_out) else None
         ctx.save_for_backward(x, weight, y)
         ctx.bias_ref = bias
         ctx.packed_bwd = packed[1] if packed is not None else None
@@ -607,7 +653,7 @@ class ConvDown(torch.autograd.Function):
             wp_up = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, True, g.dtype)
             if x.dtype != g.dtype:
                 raise L.CvaeError("the image read in its own dtype carries no gradient (cast it first if it needs one)")
-            dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None, l_dims=x.shape[1:4])
+            dx = _conv_up(g, wp_up, None, x if in_relu else None, weight.shape[1], nd, None, l_dims=x.shape[1:4], mask_bits=ctx.x_bits if in_relu else None)
         fork.join(dw, db)
         return dx, dw, db, None, None, None, None, None, None, None
 
@@ -620,11 +666,15 @@ class ConvUp(torch.autograd.Function):
         L.require_gpu(x, weight, bias)
         Cl = weight.shape[1]
         if f8 is not None:                                   # forward product on fp8 operands (see ConvDown.forward)
-            res = conv_fp8(True, f8["xq"], f8["wq"], bias, Cl, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"))
-            y, f8["y8"] = res if isinstance(res, tuple) else (res, None)
+            res = conv_fp8(True, f8["xq"], f8["wq"], bias, Cl, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"),
+                           want_bits=MASK_BITS and act == "relu")
+            y, f8["y8"], bits = res
         else:
             wp = packed[1] if packed is not None else pack_weight(weight, nd, True, x.dtype)
-            y = _conv_up(x, wp, bias, None, Cl, nd, act)
+            y, bits = _conv_up(x, wp, bias, None, Cl, nd, act, want_bits=MASK_BITS and act == "relu")
+        if bits is not None:
+            y._relu_bits = bits
+        ctx.x_bits = getattr(x, "_relu_bits", None) if (MASK_BITS and in_is_relu_out) else None
         ctx.save_for_backward(x, weight, y)
         ctx.bias_ref = bias
         ctx.packed_bwd = packed[0] if packed is not None else None
@@ -652,7 +702,7 @@ class ConvUp(torch.autograd.Function):
                 db = _channel_sum(g)
         if ctx.needs_input_grad[0]:
             wp_dn = ctx.packed_bwd if ctx.packed_bwd is not None else pack_weight(weight, nd, False, g.dtype)
-            dx = _conv_down(g, wp_dn, None, x if in_relu else None, weight.shape[0], nd, None)
+            dx = _conv_down(g, wp_dn, None, x if in_relu else None, weight.shape[0], nd, None, mask_bits=ctx.x_bits if in_relu else None)
         fork.join(dw, db)
         return dx, dw, db, None, None, None, None, None, None
 
@@ -687,12 +737,13 @@ def conv_up_fp8(Sq, wq, bias, Cl, nd, act, acc_scale, out_scale=None):
 AMAX_SLOTS = 4096        # CVAE_AMAX_SLOTS
 
 
-def conv_fp8(up, xq, wq, bias, Cout, nd, act, acc_scale=None, out8_scale=None, codes_only=False, dscale=None, want_out8=False, amax=None):
+def conv_fp8(up, xq, wq, bias, Cout, nd, act, acc_scale=None, out8_scale=None, codes_only=False, dscale=None, want_out8=False, amax=None, want_bits=None):
     """One fp8 (e4m3) product on the block-scaled MFMA (cvae_conv_fp8; forward only).  up False: nn.Conv (k4, s2, p1) of xq [B, ld, lh, lw, Cin];
     up True: nn.ConvTranspose of xq [B, sd, sh, sw, Cin].  xq, wq: uint8 codes (quantize_fp8 / pack_weight_fp8 panels).
     Scales by value (acc_scale = s_x * s_w; out8_scale = the scale of the fp8 copy of the result) or on the device (dscale: float32 tensor
     {acc_scale, 1 / out8_scale}, re-read by every launch — the training step's delayed scaling).
-    Returns the bf16 result; with codes_only the fp8 codes instead; with want_out8 (or out8_scale and not codes_only) the pair (bf16, codes).
+    Returns the bf16 result; with codes_only the fp8 codes instead; with want_out8 (or out8_scale and not codes_only) the pair (bf16, codes); with
+    want_bits given (True / False) always the triple (bf16, codes or None, ReLU mask bits of the result or None).
     amax: optional uint32 tensor of AMAX_SLOTS words that records max |result|."""
     L.require_gpu(xq)
     if xq.dtype != torch.uint8 or wq.dtype != torch.uint8:
@@ -716,9 +767,12 @@ def conv_fp8(up, xq, wq, bias, Cout, nd, act, acc_scale=None, out8_scale=None, c
     out8 = torch.empty(oshape, dtype=torch.uint8, device=xq.device) if pair else None
     ws, nbytes = (None, 0) if codes_only else _conv_data_workspace(xq.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, int(bool(up)))
     label = (f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}" if up else f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}")
+    bits = _bits_for(out) if (want_bits and not codes_only and Cout % 32 == 0) else None
     check(L.timed(label, lib.cvae_conv_fp8, int(bool(up)), ptr(xq), ptr(wq), ptr(bias), ptr(out), L.FP8 if codes_only else L.BF16, ptr(out8), ptr(dscale),
                   float(acc_scale if acc_scale is not None else 1.0), (1.0 / float(out8_scale)) if out8_scale is not None else 1.0, ptr(amax),
-                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.act_code(act), ptr(ws), nbytes, -1 if UP_VARIANT is None else int(UP_VARIANT[1]), stream()), "conv_fp8")
+                  B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.act_code(act), ptr(ws), nbytes, -1 if UP_VARIANT is None else int(UP_VARIANT[1]), ptr(bits), stream()), "conv_fp8")
+    if want_bits is not None:                                # the training forward's call: always the triple (result, codes or None, mask bits or None)
+        return out, out8, bits
     return (out, out8) if pair else out
 
 

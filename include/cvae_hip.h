@@ -106,6 +106,20 @@ int cvae_conv_up(const void* S, const void* w, const float* bias, const void* ma
                  int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                  int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* ReLU masks as BITS.  The backward-data launch of a layer whose input was a ReLU output zeroes its result where that activation was not positive
+ * (`mask` above = the saved activation, read in full: 67 MB for enc_conv[2]'s backward at 4 x 128^3).  In the bit form the PRODUCING forward launch leaves
+ * one bit per element of its result — dword i covers elements 32 i .. 32 i + 31 in memory order (a position's 32-channel block; channel counts % 32 == 0),
+ * bit set <=> element > 0 — and the backward launch reads those (1/16 of the bf16 bytes).
+ *   relu_bits_out (optional): numel / 32 dwords that receive the mask of THIS launch's result;  mask_bits (optional): the mask to apply (replaces `mask`).
+ * Same arithmetic as cvae_conv_down / cvae_conv_up otherwise. */
+int cvae_conv_down_bits(const void* L, const void* w, const float* bias, const void* mask_bits, void* S, void* relu_bits_out,
+                        int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                        int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int cvae_conv_up_bits(const void* S, const void* w, const float* bias, const void* mask_bits, void* L, void* relu_bits_out,
+                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                      int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                      void* workspace, size_t workspace_bytes, void* stream);
 /* The first conv of the encoder (Cl == 1) with the IMAGE read in the dtype it is stored in (l_dtype) while S is written in the compute
  * dtype (`dtype`): the fp32 input volume of a bf16 model feeds the kernels directly — no cast pass, no bf16 copy of the batch
  * (causal_cascade/models.py:13: nn.Conv2d(img_channels, 32, 4, 2, 1) on the fp32 batch).  cvae_conv_down_image = cvae_conv_down with
@@ -133,7 +147,8 @@ int cvae_conv_wgrad_image(const void* S, const void* L, int l_dtype, float* dW, 
  *                               the next fp8 layer; out_dtype CVAE_FP8: `out` holds the codes only.  dscale (optional, device): {acc_scale,
  *                               out8_inv_scale} read at run time instead of the two by-value arguments (delayed scaling under graph replay).
  *                               amax_slots (optional): records max |out|.  workspace: cvae_conv_data_workspace_bytes of the same geometry (split-K
- *                               of the small `down` grids; NULL = unsplit).  xpair: as in cvae_conv_up_variant (-1 = automatic).
+ *                               of the small `down` grids; NULL = unsplit).  xpair: as in cvae_conv_up_variant (-1 = automatic).  relu_bits_out
+ *                               (optional): the ReLU mask of `out` as bits (cvae_conv_down_bits).
  *   cvae_conv_up_fp8            = cvae_conv_fp8(up = 1) with by-value scales and no side outputs (round-2 entry point, kept)
  *   cvae_fp8_scale_update       once per step: for each of n tracked tensors, scale[i] = headroom * amax_i / 448 (amax_i = the largest value
  *                               recorded in its CVAE_AMAX_SLOTS words since the last call; the words are cleared; nothing recorded = scale kept),
@@ -151,14 +166,16 @@ int cvae_conv_pack_weights_fp8(const float* const* w, void* const* packed, const
                                const float* const* inv_scale_dev, void* const* amax_slots, int count, int nd, void* stream);
 int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, void* out, int out_dtype, void* out8, const float* dscale, float acc_scale,
                   float out8_inv_scale, void* amax_slots, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl,
-                  int nd, int act, void* workspace, size_t workspace_bytes, int xpair, void* stream);
+                  int nd, int act, void* workspace, size_t workspace_bytes, int xpair, void* relu_bits_out, void* stream);
 int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                      void* stream);
 /* cvae_conv_down_image with bf16 S and the fp8 side channel of a training forward whose next conv runs on fp8 operands: S8 (optional) = fp8(S * *inv_scale_dev),
- * amax_slots (optional) records max |S|.  Needs the 16-byte-row form (cvae_conv_image_supported). */
+ * amax_slots (optional) records max |S|, relu_bits_out (optional) receives the ReLU mask of S as bits (cvae_conv_down_bits; this entry point also serves a
+ * bf16 step that only wants the bits: S8 = NULL).  Needs the 16-byte-row form (cvae_conv_image_supported). */
 int cvae_conv_down_image_f8(const void* L, int l_dtype, const float* w, const float* bias, void* S, void* S8, const float* inv_scale_dev, void* amax_slots,
-                            int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int act, void* stream);
+                            void* relu_bits_out, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int act,
+                            void* stream);
 int cvae_fp8_scale_update(void* amax_slots, float* scale, float* inv_scale, int n, float headroom, const int* layer_in, const int* layer_w, const int* layer_out,
                           int n_layers, float* dscale, void* ticket, void* stream);
 /* cvae_conv_pack_weight_pairs for a training step with fp8 forward products: f8dir[i] = 1 / 2 writes the `down` / `up` panel of weight i as fp8 codes of

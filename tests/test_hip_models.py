@@ -673,6 +673,44 @@ def test_elbo_in_launch_finish_equals_the_two_launch_form():
         ops_mod.ElboUp2x.IN_LAUNCH_FINISH = old
 
 
+@pytest.mark.parametrize("cls,shape,dtype,fp8", [("3d", (2, 1, 64, 64, 64), torch.bfloat16, False), ("3d", (2, 1, 32, 32, 32), torch.float32, False),
+                                                 ("2d", (3, 1, 64, 96), torch.bfloat16, False), ("3d", (2, 1, 64, 64, 64), torch.bfloat16, True)])
+def test_relu_mask_bits_give_the_gradients_of_tensor_masks(cls, shape, dtype, fp8):
+    """ops.MASK_BITS: the forward launches leave their ReLU masks as bits and the backward-data launches read those instead of the saved activations
+    (67 MB -> 4 MB for enc_conv[2]'s data gradient at 4 x 128^3).  Same masks, same arithmetic: loss and every gradient are bit-identical to the
+    run with the activations as masks (causal_cascade/models.py:12-20, 50-55: every ReLU between two convolutions)."""
+    Model = CausalBioVAE3D if cls == "3d" else CausalBioVAE
+    g = torch.Generator().manual_seed(41)
+    B = shape[0]
+    x, m = torch.randn(*shape, generator=g).to(DEV), torch.rand(B, 12, generator=g).to(DEV)
+    t, eps = torch.randint(0, 19, (B,), generator=g).to(DEV), torch.randn(B, 64, generator=g).to(DEV)
+    runs = []
+    old = ops_mod.MASK_BITS
+    try:
+        for use_bits in (False, True):
+            ops_mod.MASK_BITS = use_bits
+            torch.manual_seed(42)
+            model = Model().to(DEV).train().set_compute_dtype(dtype)
+            if fp8:
+                model.set_fp8_forward(True)
+                model.forward_elbo(x, m, t, eps=eps) if hasattr(model, "forward_elbo") else None     # calibration step
+            for p in model.parameters():
+                p.grad = None
+            before = dict(ops_mod.BITS_STATS)
+            recon, m_hat, mu, logvar = model(x, m, t, eps=eps)
+            loss = ((recon - x) ** 2).sum() + 3.0 * ((m_hat - m) ** 2).sum() - 0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
+            loss.backward()
+            made, used = ops_mod.BITS_STATS["produced"] - before["produced"], ops_mod.BITS_STATS["consumed"] - before["consumed"]
+            # every conv ReLU: enc2..enc4 and dec1..dec3 leave bits through the counted entry points (the image layer and the fp8 forward's products through their own), and the six data gradients above them read bits (bf16: the two single-channel ends included; an fp32 model keeps the tensor form at both)
+            assert (made, used) == ((0, 0) if not use_bits else ((0 if fp8 else 6), 6 if dtype == torch.bfloat16 else 4)), (made, used)
+            runs.append((float(loss), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    finally:
+        ops_mod.MASK_BITS = old
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
 def test_split_backward_capture_matches_eager_steps():
     """GraphedTrainStep(overlap_exchange=True): the backward captured in two graphs around the encoder output (the multi-GPU exchange
     overlap; no process group here, so no exchange happens) == the eager step: losses and weights after 3 + 3 steps, every gradient

@@ -447,6 +447,56 @@ def test_conv_up_fp8_bad_arguments_fail_loudly():
         ops.conv_up_fp8(xq[..., :48].contiguous(), wq, None, 32, 3, None, 1.0)          # channel count does not match the panels
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("kind,nd,B,Cl,Cs,size", [("down", 3, 2, 32, 64, (16, 16, 16)), ("down", 3, 1, 128, 256, (8, 8, 8)), ("down", 2, 3, 32, 64, (30, 44)), ("down", 3, 2, 1, 32, (16, 24, 32)),
+                                                    ("up", 3, 2, 64, 128, (16, 16, 16)), ("up", 3, 3, 128, 256, (8, 8, 8)), ("up", 3, 1, 32, 64, (10, 12, 18)), ("up", 2, 2, 32, 64, (24, 40))])
+def test_relu_masks_as_bits(kind, nd, B, Cl, Cs, size, dtype, split_k):
+    """cvae_conv_down_bits / cvae_conv_up_bits / cvae_conv_down_image_f8: the producing launch leaves its ReLU mask as bits (bit i of the flat result <=> result[i] > 0),
+    and a launch that applies a mask given as bits returns exactly what it returns for the same mask given as the saved activation."""
+    g = torch.Generator().manual_seed(31)
+    if kind == "down":
+        x = to_cl(torch.randn(B, Cl, *size, generator=g), dtype if Cl > 1 else torch.float32)
+        w = (torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cl * 4 ** nd)).to(DEV)
+        b = torch.randn(Cs, generator=g).to(DEV)
+        wp = ops.pack_weight(w, nd, False, dtype)
+        if Cl == 1 and dtype != torch.bfloat16:
+            pytest.skip("the single-channel layer leaves bits in its bf16 form only")
+        y, bits = ops._conv_down(x, wp, b, None, Cs, nd, "relu", dtype if Cl == 1 else None, want_bits=True)
+    else:
+        ssize = tuple(s // 2 for s in size)
+        x = to_cl(torch.randn(B, Cs, *ssize, generator=g), dtype)
+        w = (torch.randn(Cs, Cl, *([4] * nd), generator=g) / math.sqrt(Cs * 2 ** nd)).to(DEV)
+        b = torch.randn(Cl, generator=g).to(DEV)
+        wp = ops.pack_weight(w, nd, True, dtype)
+        y, bits = ops._conv_up(x, wp, b, None, Cl, nd, "relu", want_bits=True)
+    if bits is None:                                               # the `unsplit` arm forces the whole-K `up` kernel (cvae_conv_up_variant), which has no bit form
+        assert kind == "up" and ops.UP_VARIANT is not None
+        return
+    assert bits.dtype == torch.int32 and bits.numel() * 32 == y.numel()
+    want = (y.float().flatten() > 0).view(-1, 32).to(torch.int64)
+    packed = (want << torch.arange(32, device=DEV)).sum(1)
+    assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, packed)
+    # the consumer: the data gradient of the layer ABOVE y applies y's mask — here simply the opposite product with y as the mask
+    ext = tuple(y.shape[1:4]) if nd == 3 else tuple(y.shape[2:4])
+    if kind == "down":       # y = an encoder activation (Cs channels): the NEXT conv's data gradient, an `up` product from half its extent, lands on it
+        small = to_cl(torch.randn(B, 64, *[e // 2 for e in ext], generator=g), dtype)
+        w2 = (torch.randn(64, Cs, *([4] * nd), generator=g) * 0.05).to(DEV)
+        wp2 = ops.pack_weight(w2, nd, True, dtype)
+        a = ops._conv_up(small, wp2, None, y, Cs, nd, None, l_dims=y.shape[1:4])
+        bq = ops._conv_up(small, wp2, None, y, Cs, nd, None, l_dims=y.shape[1:4], mask_bits=bits)
+    else:                    # y = a decoder activation (Cl channels): the NEXT ConvTranspose's data gradient, a `down` product from twice its extent, lands on it
+        c2 = 1 if Cl == 32 else 32                            # the 32-channel activation feeds the single-channel output layer
+        if c2 == 1 and dtype != torch.bfloat16:
+            pytest.skip("the single-channel layer reads mask bits in its bf16 form only")
+        big = to_cl(torch.randn(B, c2, *[2 * e for e in ext], generator=g), dtype)
+        w2 = (torch.randn(Cl, c2, *([4] * nd), generator=g) * 0.05).to(DEV)
+        wp2 = ops.pack_weight(w2, nd, False, dtype)
+        a = ops._conv_down(big, wp2, None, y, Cl, nd, None)
+        bq = ops._conv_down(big, wp2, None, y, Cl, nd, None, mask_bits=bits)
+    assert torch.equal(a, bq)
+    assert bool((a.float()[y.float() <= 0] == 0).all())
+
+
 def test_conv_relu_mask_fusion_matches_unfused():
     """in_is_relu_out / grad_premasked only move the ReLU mask into neighbouring kernels: gradients must not change."""
     g = torch.Generator().manual_seed(3)
