@@ -39,7 +39,7 @@ PEAK_FP8_FLOPS = 5.0e15      # dense fp8 on the block-scaled MFMA (same table)
 PEAK_F32_FLOPS = 157.3e12    # fp32 MFMA / vector peak
 PEAK_HBM = 8.0e12            # HBM3E spec (6.3 TB/s achievable)
 METRIC = "training samples/sec on 128^3 vessel volumes (3D CausalVAE train step)"
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def conv_flops(name):

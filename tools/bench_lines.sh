@@ -4,6 +4,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 python bench.py > $O/fin_vol128.json 2> $O/fin_vol128.err && echo vol128 done
+python bench.py --dtype fp8 --cpu-seconds 0 > $O/fin_vol128-fp8.json 2> $O/fin_vol128-fp8.err && echo vol128 fp8 done
 python bench.py --workload mnist > $O/fin_mnist.json 2> $O/fin_mnist.err && echo mnist done
 python bench.py --workload vol64-f32 > $O/fin_vol64-f32.json 2> $O/fin_vol64-f32.err && echo vol64-f32 done
 python bench.py --workload vol128-vessel --cpu-seconds 0 > $O/fin_vol128-vessel.json 2> $O/fin_vol128-vessel.err && echo vessel done

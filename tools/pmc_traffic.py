@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM traffic of one train step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, as MI355X_MICROARCH.md prescribes)
-of `bench.py --no-graph`:  tools/pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> [out.json]  ->  profiles/r02_pmc_traffic.json
+of `bench.py --no-graph`:  tools/pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> [out.json]  ->  profiles/r03_pmc_traffic.json
 
 Units / corrections (MI355X_MICROARCH.md "HBM"): both counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of wide
 (16 B/lane) coalesced reads, which is what these kernels issue, so the read side is doubled; WRITE_SIZE is exact for 16-B streaming stores.
@@ -11,7 +11,7 @@ family by its kind (kernel-name substring) and its occurrence number inside the 
 import collections, csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join("profiles", "r02_pmc_traffic.json")
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join("profiles", "r03_pmc_traffic.json")
 
 FAM_DOWN = "conv_data_kernel<DOWN> / down_c1 (conv forward, convT backward-data)"
 FAM_UP = "conv_data_kernel<UP> / up_c1 (convT forward, conv backward-data)"
@@ -19,23 +19,24 @@ FAM_WG = "conv_wgrad_kernel + wgrad_reduce_kernel (weight gradients: main + slab
 B, ESZ = 4, 2
 # the 12 conv_data_kernel dispatches of a step, in order: (label, family, algorithmic bytes = input + output (+ mask) activations + packed weights)
 def act(s, c): return B * s ** 3 * c * ESZ
+def bits(s, c): return B * s ** 3 * c // 8                  # a ReLU mask as bits (round 3): read by the backward-data launch, written by the forward launch
 def wts(ci, co): return ci * co * 64 * ESZ
 DATA_ORDER = [
-    ("conv_down nd3 B4 L64x64x64x32 -> S64", FAM_DOWN, act(64, 32) + act(32, 64) + wts(32, 64)),
-    ("conv_down nd3 B4 L32x32x32x64 -> S128", FAM_DOWN, act(32, 64) + act(16, 128) + wts(64, 128)),
-    ("conv_down nd3 B4 L16x16x16x128 -> S256", FAM_DOWN, act(16, 128) + act(8, 256) + wts(128, 256)),
-    ("conv_up nd3 B4 S4x4x4x256 -> L128", FAM_UP, act(4, 256) + act(8, 128) + wts(256, 128)),
-    ("conv_up nd3 B4 S8x8x8x128 -> L64", FAM_UP, act(8, 128) + act(16, 64) + wts(128, 64)),
-    ("conv_up nd3 B4 S16x16x16x64 -> L32", FAM_UP, act(16, 64) + act(32, 32) + wts(64, 32)),
-    ("conv_down nd3 B4 L32x32x32x32 -> S64", FAM_DOWN, act(32, 32) + 2 * act(16, 64) + wts(64, 32)),       # dec3 backward-data (+ ReLU mask of its output)
-    ("conv_down nd3 B4 L16x16x16x64 -> S128", FAM_DOWN, act(16, 64) + 2 * act(8, 128) + wts(128, 64)),
-    ("conv_down nd3 B4 L8x8x8x128 -> S256", FAM_DOWN, act(8, 128) + 2 * act(4, 256) + wts(256, 128)),
-    ("conv_up nd3 B4 S8x8x8x256 -> L128", FAM_UP, act(8, 256) + 2 * act(16, 128) + wts(128, 256)),          # enc4 backward-data
-    ("conv_up nd3 B4 S16x16x16x128 -> L64", FAM_UP, act(16, 128) + 2 * act(32, 64) + wts(64, 128)),
-    ("conv_up nd3 B4 S32x32x32x64 -> L32", FAM_UP, act(32, 64) + 2 * act(64, 32) + wts(32, 64)),
+    ("conv_down nd3 B4 L64x64x64x32 -> S64", FAM_DOWN, act(64, 32) + act(32, 64) + bits(32, 64) + wts(32, 64)),
+    ("conv_down nd3 B4 L32x32x32x64 -> S128", FAM_DOWN, act(32, 64) + act(16, 128) + bits(16, 128) + wts(64, 128)),
+    ("conv_down nd3 B4 L16x16x16x128 -> S256", FAM_DOWN, act(16, 128) + act(8, 256) + bits(8, 256) + wts(128, 256)),
+    ("conv_up nd3 B4 S4x4x4x256 -> L128", FAM_UP, act(4, 256) + act(8, 128) + bits(8, 128) + wts(256, 128)),
+    ("conv_up nd3 B4 S8x8x8x128 -> L64", FAM_UP, act(8, 128) + act(16, 64) + bits(16, 64) + wts(128, 64)),
+    ("conv_up nd3 B4 S16x16x16x64 -> L32", FAM_UP, act(16, 64) + act(32, 32) + bits(32, 32) + wts(64, 32)),
+    ("conv_down nd3 B4 L32x32x32x32 -> S64", FAM_DOWN, act(32, 32) + act(16, 64) + bits(16, 64) + wts(64, 32)),       # dec3 backward-data (+ the ReLU mask of its output, as bits)
+    ("conv_down nd3 B4 L16x16x16x64 -> S128", FAM_DOWN, act(16, 64) + act(8, 128) + bits(8, 128) + wts(128, 64)),
+    ("conv_down nd3 B4 L8x8x8x128 -> S256", FAM_DOWN, act(8, 128) + act(4, 256) + wts(256, 128)),                      # dec1 backward-data: dec_input's output is no ReLU output
+    ("conv_up nd3 B4 S8x8x8x256 -> L128", FAM_UP, act(8, 256) + act(16, 128) + bits(16, 128) + wts(128, 256)),          # enc4 backward-data
+    ("conv_up nd3 B4 S16x16x16x128 -> L64", FAM_UP, act(16, 128) + act(32, 64) + bits(32, 64) + wts(64, 128)),
+    ("conv_up nd3 B4 S32x32x32x64 -> L32", FAM_UP, act(32, 64) + act(64, 32) + bits(64, 32) + wts(32, 64)),
 ]
-C1_DOWN = [("conv_down nd3 B4 L128x128x128x1 -> S32", FAM_DOWN, B * 128 ** 3 * 4 + act(64, 32)),            # fp32 image in
-           ("conv_down nd3 B4 L64x64x64x1 -> S32", FAM_DOWN, B * 64 ** 3 * ESZ + 2 * act(32, 32))]          # dec4 backward-data
+C1_DOWN = [("conv_down nd3 B4 L128x128x128x1 -> S32", FAM_DOWN, B * 128 ** 3 * 4 + act(64, 32) + bits(64, 32)),            # fp32 image in
+           ("conv_down nd3 B4 L64x64x64x1 -> S32", FAM_DOWN, B * 64 ** 3 * ESZ + act(32, 32) + bits(32, 32))]          # dec4 backward-data
 C1_UP = [("conv_up nd3 B4 S32x32x32x32 -> L1", FAM_UP, act(32, 32) + B * 64 ** 3 * ESZ)]
 WG_LAYERS = [(32, 64, 32), (16, 128, 64), (8, 256, 128), (4, 256, 128), (8, 128, 64), (16, 64, 32)]         # (S extent, Cs, Cl)
 WG_ALG = sum(act(s, cs) + act(2 * s, cl) + cs * cl * 64 * 4 for s, cs, cl in WG_LAYERS)
