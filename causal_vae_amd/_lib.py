@@ -133,6 +133,10 @@ SIGNATURES = {
     "cvae_bottleneck_sizes": [_p, _p, _p, _p, _p, _p],
     "cvae_bottleneck_fwd": [_p] * 10 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p],
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
+    "cvae_bottleneck_bn_local_stats": [_p] * 5 + [_i64, _i64, _i64, _p],
+    "cvae_bottleneck_fwd_sync": [_p] * 10 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
+    "cvae_bottleneck_bwd_sync": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p, _p, _p],
+    "cvae_bottleneck_bn_bwd_finish": [_p] * 7 + [_i, _p],
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
             "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64, "cvae_channel_sum_workspace_bytes": _sz,

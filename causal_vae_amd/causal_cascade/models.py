@@ -126,6 +126,10 @@ class CausalBioVAE(nn.Module):
         if (not self.training or not torch.is_grad_enabled() or not (2 <= x.shape[0] <= 16) or any(s < 4 or s % 4 for s in sp)
                 or any(s % 16 for s in x.shape[2:]) or not bn.track_running_stats or bn.momentum is None):
             return None
+        sync = ()
+        if getattr(bn, "sync", False):
+            # SyncBatchNorm (parallel.convert_sync_batchnorm): mechanism_net.0 sees t only, so its per-rank statistics are gathered here, ahead of the encoder
+            sync = ((bn.sync_group, ops.bottleneck_bn_rank_stats(self.mechanism_net[0].weight, self.mechanism_net[0].bias, t, bn.sync_group)),)
         we, wd = self.enc_conv.conv_weights(), self.dec_conv.conv_weights()
         f8 = self._fp8_plan(x.device)
         if f8 is not None:
@@ -143,7 +147,7 @@ class CausalBioVAE(nn.Module):
         if t.dim() != 1 or t.dtype != torch.int64:          # BioBottleneck builds the one-hot itself from int64 labels (one_hot raises otherwise)
             t = ops.one_hot(t, self.t_dim)
         mu, logvar, m_hat, dec_cl = ops.BioBottleneck.apply(h, m, t, eps, *params, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                                            bn.momentum, bn.eps, out_size)
+                                                            bn.momentum, bn.eps, out_size, *sync)
         out_cl = self.dec_conv.forward_from_cl(dec_cl, packed=packed[len(we):], f8=f8)
         if f8 is not None:
             f8.end_step()

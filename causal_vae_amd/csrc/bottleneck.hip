@@ -36,8 +36,9 @@ struct TailGrads {
 };
 // saved activations (global), all [M][dim] row-major
 struct TailSaved { float *h1, *h2, *mu, *logvar, *xhat, *invstd, *a1n, *a2, *m_hat, *zm; };
-struct MechFwdArgs { const float* t_onehot; float *running_mean, *running_var; long long* num_batches_tracked; float momentum, bn_eps; int bn_training; };
-struct MechBwdArgs { const float *dzm_part, *g_mhat, *t_onehot; };
+struct MechFwdArgs { const float* t_onehot; float *running_mean, *running_var; long long* num_batches_tracked; float momentum, bn_eps; int bn_training;
+                     const float* sync_stats; int sync_ranks; };       // SyncBatchNorm: [ranks][2][HM] (sum, squared deviations from the rank's own mean) of every rank's batch
+struct MechBwdArgs { const float *dzm_part, *g_mhat, *t_onehot; float *sync_dy, *sync_local; };      // SyncBatchNorm: the backward stops at the BatchNorm (see mech_bwd)
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };       // float4 at dword alignment
 
 __device__ __forceinline__ int pool_lo(int o, int in, int out) { return (o * in) / out; }
@@ -84,9 +85,10 @@ __global__ __launch_bounds__(256) void pool_cat_fwd_kernel(const T* __restrict__
 // partial[ks][m][n] = sum_{k in slice ks} x[m][k] W[n][k].  grid (N / 4, KS), 256 threads: 4 weight rows per workgroup share one
 // pass over the x slice; rows are read with coalesced 4-byte loads (K is odd in the model: rows are not 16-byte aligned).
 __device__ void mech_fwd(const TailDims& d, const TailParams& p, const TailSaved& sv, const float* __restrict__ t_onehot, float* __restrict__ running_mean,
-                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked, float momentum, float bn_eps, int bn_training, float* lds);
+                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked, float momentum, float bn_eps, int bn_training, float* lds,
+                         const float* __restrict__ sync_stats, int sync_ranks);
 __device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads& gr, const TailSaved& sv, const float* __restrict__ dzm_part,
-                         const float* __restrict__ g_mhat, const float* __restrict__ t_onehot, float* lds);
+                         const float* __restrict__ g_mhat, const float* __restrict__ t_onehot, float* lds, float* __restrict__ sync_dy, float* __restrict__ sync_local);
 
 // The launch carries one extra block row (blockIdx.y == KS): its block 0 runs mechanism_net's forward, which depends only on t and
 // is hidden behind the weight stream.
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_partial_kernel(const float* __
                                                                  int M, int K, int N, int kslice, int KS, TailDims d, TailParams tp, TailSaved sv, MechFwdArgs ma) {
     extern __shared__ float dyn_lds[];
     if ((int)blockIdx.y == KS) {
-        if (blockIdx.x == 0) mech_fwd(d, tp, sv, ma.t_onehot, ma.running_mean, ma.running_var, ma.num_batches_tracked, ma.momentum, ma.bn_eps, ma.bn_training, dyn_lds);
+        if (blockIdx.x == 0) mech_fwd(d, tp, sv, ma.t_onehot, ma.running_mean, ma.running_var, ma.num_batches_tracked, ma.momentum, ma.bn_eps, ma.bn_training, dyn_lds, ma.sync_stats, ma.sync_ranks);
         return;
     }
     constexpr int R = 4;
@@ -179,6 +181,9 @@ __device__ void wg_linear_fwd(const float* __restrict__ Wt, const float* __restr
 }
 
 // dW[n][k] = sum_m gs[m][n] xs[m][k];  db[n] = sum_m gs[m][n];  dxs[m][k] = sum_n gs[m][n] W[n][k]  (dxs may be null).
+// BatchNorm backward for one element: k (n dy - sum dy - xhat sum(dy xhat)), the one spelling both the rank-local and the SyncBatchNorm path use
+__device__ inline float bn_bwd_dx(float k, float nb, float dy, float dbet, float xh, float dgam) { return k * fmaf(-xh, dgam, fmaf(nb, dy, -dbet)); }
+
 __device__ void wg_linear_bwd(const float* __restrict__ Wt, float* __restrict__ dW, float* __restrict__ db, const float* gs, const float* xs, float* dxs,
                               int M, int K, int N) {
     const int T = blockDim.x;
@@ -209,7 +214,8 @@ __device__ void wg_linear_bwd(const float* __restrict__ Wt, float* __restrict__ 
 // One 256-thread workgroup (an extra block of the enc_fc.0 launch, which hides it): Linear(t) -> BatchNorm1d (batch statistics,
 // running-stat update) -> ReLU -> Linear -> ReLU -> Linear.  `lds` holds 4 * M * HM + M * T floats.
 __device__ void mech_fwd(const TailDims& d, const TailParams& p, const TailSaved& sv, const float* __restrict__ t_onehot, float* __restrict__ running_mean,
-                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked, float momentum, float bn_eps, int bn_training, float* lds) {
+                         float* __restrict__ running_var, long long* __restrict__ num_batches_tracked, float momentum, float bn_eps, int bn_training, float* lds,
+                         const float* __restrict__ sync_stats, int sync_ranks) {
     const int M = d.M, T = blockDim.x, tid = threadIdx.x, HM = d.HM;
     float* ts = lds;                 // [M][T]
     float* a1s = ts + M * d.T;       // [M][HM]
@@ -226,15 +232,31 @@ __device__ void mech_fwd(const TailDims& d, const TailParams& p, const TailSaved
     for (int j = tid; j < HM; j += T) {                      // BatchNorm1d + ReLU
         float mean, var;
         if (bn_training) {
-            mean = 0.f;
-            for (int m = 0; m < M; ++m) mean += a1s[m * HM + j];
-            mean /= (float)M;
-            var = 0.f;
-            for (int m = 0; m < M; ++m) { const float c = a1s[m * HM + j] - mean; var += c * c; }
-            var /= (float)M;
+            float nb = (float)M;                             // samples behind the statistics
+            if (sync_stats) {
+                // the GLOBAL batch: every rank's (sum, squared deviations from its own mean) of M samples, gathered by the caller and combined
+                // here in rank order (the same arithmetic on every rank: replicas stay bit-identical).  Chan's pairwise update, no E[x^2] - mean^2.
+                nb = (float)M * (float)sync_ranks;
+                mean = 0.f;
+                for (int r = 0; r < sync_ranks; ++r) mean += sync_stats[(size_t)r * 2 * HM + j];
+                mean /= nb;
+                var = 0.f;
+                for (int r = 0; r < sync_ranks; ++r) {
+                    const float c = sync_stats[(size_t)r * 2 * HM + j] / (float)M - mean;
+                    var += sync_stats[(size_t)r * 2 * HM + HM + j] + (float)M * c * c;
+                }
+                var /= nb;
+            } else {
+                mean = 0.f;
+                for (int m = 0; m < M; ++m) mean += a1s[m * HM + j];
+                mean /= (float)M;
+                var = 0.f;
+                for (int m = 0; m < M; ++m) { const float c = a1s[m * HM + j] - mean; var += c * c; }
+                var /= (float)M;
+            }
             if (running_mean) {
                 running_mean[j] = (1.f - momentum) * running_mean[j] + momentum * mean;
-                running_var[j] = (1.f - momentum) * running_var[j] + momentum * var * ((float)M / (float)(M - 1));
+                running_var[j] = (1.f - momentum) * running_var[j] + momentum * var * (nb / (nb - 1.f));
             }
         } else {
             mean = running_mean[j]; var = running_var[j];
@@ -565,7 +587,7 @@ __device__ void load_dzm(const float* __restrict__ dzm_acc, float* dzs, int n, i
 // ------------------------------------------------------------------------------------------------ mechanism_net backward
 // One 256-thread workgroup (an extra block of the enc_fc.0 backward launch, which hides it).  lds: M*K4 + 5*M*HM + M*T + M*DM.
 __device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads& gr, const TailSaved& sv, const float* __restrict__ dzm_part,
-                         const float* __restrict__ g_mhat, const float* __restrict__ t_onehot, float* lds) {
+                         const float* __restrict__ g_mhat, const float* __restrict__ t_onehot, float* lds, float* __restrict__ sync_dy, float* __restrict__ sync_local) {
     const int M = d.M, T = blockDim.x, tid = threadIdx.x, HM = d.HM, K4 = d.Z + d.DM;
     float* dzs = lds;                    // [M][K4]
     float* dmh = dzs + M * K4;           // [M][DM]
@@ -599,9 +621,61 @@ __device__ void mech_bwd(const TailDims& d, const TailParams& p, const TailGrads
             dbet += g;
         }
         gr.dgamma[j] = dgam; gr.dbeta[j] = dbet;
+        if (sync_local) {
+            // SyncBatchNorm: d(input) needs sum(dy) and sum(dy * xhat) over the GLOBAL batch.  This rank's sums (they are also its share of d beta /
+            // d gamma) and its masked dy leave here; the caller all-reduces the sums and mech_bn_finish_kernel does the rest (dWm0, dbm0).
+            sync_local[j] = dbet; sync_local[HM + j] = dgam;
+            for (int m = 0; m < M; ++m) sync_dy[m * HM + j] = dy[m * HM + j];
+            continue;
+        }
         const float k = p.gamma[j] * sv.invstd[j] / (float)M;
-        for (int m = 0; m < M; ++m) dy[m * HM + j] = k * ((float)M * dy[m * HM + j] - dbet - xh[m * HM + j] * dgam);
+        for (int m = 0; m < M; ++m) dy[m * HM + j] = bn_bwd_dx(k, (float)M, dy[m * HM + j], dbet, xh[m * HM + j], dgam);
     }
+    if (sync_local) return;                                  // uniform
+    __syncthreads();
+    wg_linear_bwd(p.Wm0, gr.dWm0, gr.dbm0, dy, ts, nullptr, M, d.T, HM);
+}
+
+// ------------------------------------------------------------------------------------------------ SyncBatchNorm (data-parallel ranks)
+// Before the step's forward: this rank's statistics of mechanism_net.0's output, h[m][j] = bm0[j] + t_onehot[m] . Wm0[j] (the same
+// accumulation order as mech_fwd, so the values are mech_fwd's), as (sum, squared deviations from the rank's own mean).  One workgroup.
+__global__ __launch_bounds__(256) void mech_bn_local_stats_kernel(const float* __restrict__ Wm0, const float* __restrict__ bm0, const float* __restrict__ t_onehot,
+                                                                   const long long* __restrict__ t_labels, float* __restrict__ out, int M, int T, int HM) {
+    for (int j = threadIdx.x; j < HM; j += blockDim.x) {
+        float h[BN_MAXM];
+        float sum = 0.f;
+        for (int m = 0; m < M; ++m) {
+            float acc = bm0[j];
+            if (t_labels) {
+                const long long lab = t_labels[m];
+                if (lab >= 0 && lab < T) acc += Wm0[j * T + lab];          // 1.0f * w, the other terms of the dot product are 0.0f * w: the same bits
+            } else {
+                for (int k = 0; k < T; ++k) acc += t_onehot[m * T + k] * Wm0[j * T + k];
+            }
+            h[m] = acc; sum += acc;
+        }
+        const float mean = sum / (float)M;
+        float m2 = 0.f;
+        for (int m = 0; m < M; ++m) { const float c = h[m] - mean; m2 += c * c; }
+        out[j] = sum; out[HM + j] = m2;
+    }
+}
+
+// After the backward's all-reduce of (sum dy, sum dy * xhat): d(BatchNorm input) with the GLOBAL sums, then mechanism_net.0's weight and bias
+// gradients (this rank's share, like every other parameter gradient).  One workgroup; lds: 2 * M * HM + M * T floats.
+__global__ __launch_bounds__(256) void mech_bn_finish_kernel(TailDims d, TailParams p, TailGrads gr, TailSaved sv, const float* __restrict__ t_onehot,
+                                                              const float* __restrict__ sync_dy, const float* __restrict__ sums, int ranks) {
+    extern __shared__ float dyn_lds[];
+    const int M = d.M, T = blockDim.x, tid = threadIdx.x, HM = d.HM;
+    float* dy = dyn_lds;                 // [M][HM]
+    float* ts = dy + M * HM;             // [M][T]
+    const float nb = (float)M * (float)ranks;
+    for (int i = tid; i < M * HM; i += T) {
+        const int j = i % HM;
+        const float k = p.gamma[j] * sv.invstd[j] / nb;
+        dy[i] = bn_bwd_dx(k, nb, sync_dy[i], sums[j], sv.xhat[i], sums[HM + j]);
+    }
+    for (int i = tid; i < M * d.T; i += T) ts[i] = t_onehot[i];
     __syncthreads();
     wg_linear_bwd(p.Wm0, gr.dWm0, gr.dbm0, dy, ts, nullptr, M, d.T, HM);
 }
@@ -775,7 +849,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
                                                                  int NS, TailDims d, TailParams tp, TailGrads tg, TailSaved sv, MechBwdArgs mb) {
     extern __shared__ float dyn_lds[];
     if ((int)blockIdx.y == NS) {                             // extra block row: mechanism_net's backward, hidden behind the W stream
-        if (blockIdx.x == 0) mech_bwd(d, tp, tg, sv, mb.dzm_part, mb.g_mhat, mb.t_onehot, dyn_lds);
+        if (blockIdx.x == 0) mech_bwd(d, tp, tg, sv, mb.dzm_part, mb.g_mhat, mb.t_onehot, dyn_lds, mb.sync_dy, mb.sync_local);
         return;
     }
     __shared__ float gs[MT][64];
@@ -946,14 +1020,32 @@ static void launch_bwd_colwise(const float* g, const float* x, const float* W1, 
                        nslice, F, S, NS, d, p, tg, sv, mb);
 }
 
+extern "C" int cvae_bottleneck_bn_local_stats(const float* Wm0, const float* bm0, const float* t_onehot, const int64_t* t_labels, float* local_stats, int64_t M, int64_t t_dim,
+                                              int64_t HM, void* stream) {
+    if (M < 1 || M > BN_MAXM || t_dim < 1 || HM < 1 || HM > 1024) return CVAE_E_BADSHAPE;
+    if (!Wm0 || !bm0 || !local_stats || (!t_onehot && !t_labels)) return CVAE_E_NULLPTR;
+    hipLaunchKernelGGL(mech_bn_local_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Wm0, bm0, t_onehot, (const long long*)t_labels, local_stats, (int)M, (int)t_dim, (int)HM);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
 extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, float* t_onehot,
                                    const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
                                    int bn_training, float* xcat, float* partial, float* dzm_acc, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype,
                                    void* stream) {
+    return cvae_bottleneck_fwd_sync(q, w, y_cl, m, t_onehot, t_labels, eps, running_mean, running_var, num_batches_tracked, momentum, bn_eps, bn_training, xcat, partial, dzm_acc,
+                                    sv, dec_cl, dtype, nullptr, 0, stream);
+}
+
+extern "C" int cvae_bottleneck_fwd_sync(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, float* t_onehot,
+                                        const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                                        float bn_eps, int bn_training, float* xcat, float* partial, float* dzm_acc, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype,
+                                        const float* bn_rank_stats, int bn_ranks, void* stream) {
     if (!dims_ok(q)) return CVAE_E_BADSHAPE;
+    if (bn_rank_stats && (bn_ranks < 1 || !bn_training)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (!w || !sv || !y_cl || !m || !t_onehot || !eps || !xcat || !partial || !dec_cl) return CVAE_E_NULLPTR;
-    if (bn_training && q->M < 2) return CVAE_E_BADSHAPE;
+    if (bn_training && q->M * (bn_rank_stats ? bn_ranks : 1) < 2) return CVAE_E_BADSHAPE;
     if (!bn_training && (!running_mean || !running_var)) return CVAE_E_NULLPTR;
     hipStream_t st = (hipStream_t)stream;
     const int M = (int)q->M, S = (int)(q->OD * q->OH * q->OW), C = (int)q->C, F = C * S;
@@ -968,7 +1060,7 @@ extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bot
     const TailDims d = tail_dims(q, KS, 0);
     const TailParams p{w->b1, w->W2, w->b2, w->Wmu, w->bmu, w->Wlv, w->blv, w->Wm0, w->bm0, w->gamma, w->beta, w->Wm3, w->bm3, w->Wm5, w->bm5};
     const TailSaved s{sv->h1, sv->h2, sv->mu, sv->logvar, sv->xhat, sv->invstd, sv->a1n, sv->a2, sv->m_hat, sv->zm};
-    const MechFwdArgs ma{t_onehot, running_mean, running_var, num_batches_tracked, momentum, bn_eps, bn_training};
+    const MechFwdArgs ma{t_onehot, running_mean, running_var, num_batches_tracked, momentum, bn_eps, bn_training, bn_rank_stats, bn_ranks};
     if (M <= 4) launch_fwd_partial<4>(xcat, w->W1, partial, M, K1, (int)q->N1, KS, d, p, s, ma, st);
     else if (M <= 8) launch_fwd_partial<8>(xcat, w->W1, partial, M, K1, (int)q->N1, KS, d, p, s, ma, st);
     else launch_fwd_partial<16>(xcat, w->W1, partial, M, K1, (int)q->N1, KS, d, p, s, ma, st);
@@ -990,7 +1082,30 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
                                    const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat, const float* t_onehot, const float* eps,
                                    const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1, float* dx_partial, void* dy_cl, int dtype,
                                    void* stream) {
+    return cvae_bottleneck_bwd_sync(q, w, gr, sv, g_dec_cl, g_mu, g_logvar, g_mhat, t_onehot, eps, xcat, y_cl, relu_mask, dzm_partial, g1, dx_partial, dy_cl, dtype, nullptr,
+                                    nullptr, stream);
+}
+
+extern "C" int cvae_bottleneck_bn_bwd_finish(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const cvae_bottleneck_grads* gr, const cvae_bottleneck_saved* sv,
+                                             const float* t_onehot, const float* bn_dy, const float* bn_sums, int bn_ranks, void* stream) {
+    if (!dims_ok(q) || bn_ranks < 1) return CVAE_E_BADSHAPE;
+    if (!w || !gr || !sv || !t_onehot || !bn_dy || !bn_sums) return CVAE_E_NULLPTR;
+    const TailDims d = tail_dims(q, 0, 0);
+    const TailParams p{w->b1, w->W2, w->b2, w->Wmu, w->bmu, w->Wlv, w->blv, w->Wm0, w->bm0, w->gamma, w->beta, w->Wm3, w->bm3, w->Wm5, w->bm5};
+    const TailGrads g{gr->db1, gr->dW2, gr->db2, gr->dWmu, gr->dbmu, gr->dWlv, gr->dblv, gr->dWm0, gr->dbm0, gr->dgamma, gr->dbeta, gr->dWm3, gr->dbm3, gr->dWm5, gr->dbm5};
+    const TailSaved s{sv->h1, sv->h2, sv->mu, sv->logvar, sv->xhat, sv->invstd, sv->a1n, sv->a2, sv->m_hat, sv->zm};
+    hipLaunchKernelGGL(mech_bn_finish_kernel, dim3(1), dim3(256), sizeof(float) * (size_t)q->M * (size_t)(q->HM + q->t_dim), (hipStream_t)stream, d, p, g, s, t_onehot, bn_dy, bn_sums,
+                       bn_ranks);
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+extern "C" int cvae_bottleneck_bwd_sync(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const cvae_bottleneck_grads* gr, const cvae_bottleneck_saved* sv,
+                                        const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat, const float* t_onehot, const float* eps,
+                                        const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1, float* dx_partial, void* dy_cl, int dtype,
+                                        float* bn_dy, float* bn_local_sums, void* stream) {
     if (!dims_ok(q)) return CVAE_E_BADSHAPE;
+    if ((bn_dy == nullptr) != (bn_local_sums == nullptr)) return CVAE_E_NULLPTR;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (!w || !gr || !sv || !g_dec_cl || !t_onehot || !eps || !xcat || !y_cl || !dzm_partial || !g1 || !dx_partial || !dy_cl) return CVAE_E_NULLPTR;
     hipStream_t st = (hipStream_t)stream;
@@ -1015,7 +1130,7 @@ extern "C" int cvae_bottleneck_bwd(const cvae_bottleneck_dims* q, const cvae_bot
     hipLaunchKernelGGL(fc2_bwd_kernel, dim3((unsigned)((q->N1 + 15) / 16)), dim3(256), sizeof(float) * ((size_t)M * q->N2 + 17 * (size_t)M * 16), st, d, p, g, s,
                        (const float*)dh2, g1);
     CVAE_CHECK_LAUNCH();
-    const MechBwdArgs mb{dzm_partial, g_mhat, t_onehot};
+    const MechBwdArgs mb{dzm_partial, g_mhat, t_onehot, bn_dy, bn_local_sums};
     if (M <= 4) launch_bwd_colwise<4>(g1, xcat, w->W1, gr->dW1, dx_partial, M, K1, (int)q->N1, NS, F, S, d, p, g, s, mb, st);
     else if (M <= 8) launch_bwd_colwise<8>(g1, xcat, w->W1, gr->dW1, dx_partial, M, K1, (int)q->N1, NS, F, S, d, p, g, s, mb, st);
     else launch_bwd_colwise<16>(g1, xcat, w->W1, gr->dW1, dx_partial, M, K1, (int)q->N1, NS, F, S, d, p, g, s, mb, st);

@@ -26,6 +26,20 @@ def _capture(graph, **kw):
     return torch.cuda.graph(graph, capture_error_mode="thread_local", **kw)
 
 
+def _check_sync_bn_capturable(model):
+    """A SyncBatchNorm model (parallel.convert_sync_batchnorm) issues two small collectives INSIDE forward / backward, i.e. inside the captured region.
+    RCCL collectives can be captured into a HIP graph (torch's ProcessGroupNCCL supports it); gloo's cannot (they go through the host)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for mod in model.modules():
+        if getattr(mod, "sync", False):
+            group = getattr(mod, "sync_group", None)
+            if dist.get_world_size(group) > 1 and dist.get_backend(group) != "nccl":
+                raise CvaeError("GraphedTrainStep: SyncBatchNorm collectives can only be captured on an RCCL ('nccl') process group; run the eager train_step "
+                                f"on '{dist.get_backend(group)}'")
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, batch, loss_fn=None, reducer=None, warmup=3, overlap_exchange=False):
         """batch: (x, m, t) example tensors on the GPU (their storage becomes the static input buffers).
@@ -34,6 +48,7 @@ class GraphedTrainStep:
         if not isinstance(optimizer, FusedAdam) or not optimizer.device_step:
             raise CvaeError("GraphedTrainStep needs FusedAdam(..., device_step=True): the step count must live on the device")
         self.model, self.opt, self.reducer = model, optimizer, reducer
+        _check_sync_bn_capturable(model)
         self.x, self.m, self.t = (b.clone() for b in batch)
         self.loss_fn = loss_fn
         side = torch.cuda.Stream()

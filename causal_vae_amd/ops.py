@@ -1549,6 +1549,9 @@ class BioBottleneck(torch.autograd.Function):
              the 18 parameters in _lib.BOTTLENECK_PARAMS order, then (running_mean, running_var, num_batches_tracked, momentum,
              bn_eps, out_size).  returns (mu, logvar, m_hat, dec_cl [B, OD, OH, OW, C] in y_cl's dtype).
     Same arithmetic (fp32) as the layer-by-layer path, which stays the general fallback (eval mode, B > 16, odd pool windows).
+    An optional last argument `sync` = (group, rank_stats) makes mechanism_net's BatchNorm1d a SyncBatchNorm over the ranks of `group`:
+    rank_stats is bottleneck_bn_rank_stats(...) (this step's gathered per-rank statistics); the backward all-reduces 2 * HM floats and finishes
+    mechanism_net.0's gradients in one extra small launch (include/cvae_hip.h, cvae_bottleneck_*_sync).
     """
 
     @staticmethod
@@ -1559,7 +1562,8 @@ class BioBottleneck(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y_cl, m, t_onehot, eps, *rest):
-        params, (rm, rv, nbt, momentum, bn_eps, out_size) = rest[:18], rest[18:]
+        params, (rm, rv, nbt, momentum, bn_eps, out_size), sync = rest[:18], rest[18:24], (rest[24] if len(rest) > 24 else None)
+        ctx.n_extra = len(rest) - 18
         L.require_gpu(y_cl, m, t_onehot, eps, *params)
         params = [p.contiguous() for p in params]
         W1, W2, Wmu, Wm0 = params[0], params[2], params[4], params[8]
@@ -1584,9 +1588,17 @@ class BioBottleneck(torch.autograd.Function):
         dec_cl = torch.empty(B, *out_size, C, dtype=y_cl.dtype, device=dev)
         pstruct = L.BottleneckPtrs18(*[ptr(p) for p in params])
         sstruct = L.BottleneckSaved(*[ptr(saved[k]) for k in L.BOTTLENECK_SAVED])
-        check(lib.cvae_bottleneck_fwd(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(t_labels), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
-                                      float(bn_eps), 1, ptr(xcat), ptr(partial), ptr(dzm_acc), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), stream()), "bottleneck_fwd")
+        rank_stats, ranks = None, 0
+        if sync is not None:
+            rank_stats = sync[1].contiguous()
+            ranks = rank_stats.shape[0]
+            if tuple(rank_stats.shape) != (ranks, 2, HM) or rank_stats.dtype != f32:
+                raise L.CvaeError(f"BioBottleneck: sync rank_stats must be float32 [ranks, 2, {HM}], got {tuple(rank_stats.shape)}")
+        check(lib.cvae_bottleneck_fwd_sync(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(t_labels), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
+                                           float(bn_eps), 1, ptr(xcat), ptr(partial), ptr(dzm_acc), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), ptr(rank_stats), ranks,
+                                           stream()), "bottleneck_fwd")
         ctx.dims, ctx.scratch = dims, n_dx
+        ctx.sync = None if sync is None else (sync[0], ranks)
         ctx.save_for_backward(y_cl, t_onehot, eps, xcat, *params, *[saved[k] for k in L.BOTTLENECK_SAVED], dzm_acc)
         ctx.mark_non_differentiable(*[t for t in (rm, rv, nbt) if t is not None])
         return saved["mu"], saved["logvar"], saved["m_hat"], dec_cl
@@ -1607,10 +1619,39 @@ class BioBottleneck(torch.autograd.Function):
         pstruct = L.BottleneckPtrs18(*[ptr(p) for p in params])
         gstruct = L.BottleneckPtrs18(*[ptr(g) for g in grads])
         sstruct = L.BottleneckSaved(*[ptr(t) for t in saved])
-        check(lib.cvae_bottleneck_bwd(C_.byref(dims), C_.byref(pstruct), C_.byref(gstruct), C_.byref(sstruct), ptr(g_dec), ptr(g_mu), ptr(g_logvar), ptr(g_mhat),
-                                      ptr(t_onehot), ptr(eps), ptr(xcat), ptr(y_cl), 1, ptr(dzm_part), ptr(g1), ptr(dx_part), ptr(dy_cl),
-                                      L.dtype_code(y_cl.dtype), stream()), "bottleneck_bwd")
-        return (dy_cl, None, None, None, *grads, None, None, None, None, None, None)
+        bn_dy = bn_sums = None
+        if ctx.sync is not None:
+            bn_dy, bn_sums = torch.empty(dims.M, dims.HM, dtype=f32, device=dev), torch.empty(2, dims.HM, dtype=f32, device=dev)
+        check(lib.cvae_bottleneck_bwd_sync(C_.byref(dims), C_.byref(pstruct), C_.byref(gstruct), C_.byref(sstruct), ptr(g_dec), ptr(g_mu), ptr(g_logvar), ptr(g_mhat),
+                                           ptr(t_onehot), ptr(eps), ptr(xcat), ptr(y_cl), 1, ptr(dzm_part), ptr(g1), ptr(dx_part), ptr(dy_cl),
+                                           L.dtype_code(y_cl.dtype), ptr(bn_dy), ptr(bn_sums), stream()), "bottleneck_bwd")
+        if ctx.sync is not None:
+            group, ranks = ctx.sync
+            _all_reduce_sum(bn_sums, group)                  # 2 * HM floats: sum(dy), sum(dy * xhat) over the global batch
+            check(lib.cvae_bottleneck_bn_bwd_finish(C_.byref(dims), C_.byref(pstruct), C_.byref(gstruct), C_.byref(sstruct), ptr(t_onehot), ptr(bn_dy), ptr(bn_sums), ranks,
+                                                    stream()), "bottleneck_bn_bwd_finish")
+        return (dy_cl, None, None, None, *grads, *([None] * ctx.n_extra))
+
+
+def bottleneck_bn_rank_stats(Wm0, bm0, t, group=None):
+    """Per-rank statistics of mechanism_net.0's output for the SyncBatchNorm form of BioBottleneck: float32 [ranks, 2, HM] = every rank's (sum, squared
+    deviations from its own mean) over its B samples — one small launch and one all-gather of 2 * HM floats.  The layer's input is t alone, so this runs at the
+    top of the step, before the encoder.  t: int64 labels [B] or the float one-hot [B, t_dim].  Every rank must hold the same B."""
+    import torch.distributed as dist
+    L.require_gpu(Wm0, bm0, t)
+    Wm0, bm0 = Wm0.contiguous(), bm0.contiguous()
+    HM, T = Wm0.shape
+    labels = t.contiguous().long() if (t.dim() == 1 and not t.is_floating_point()) else None
+    onehot = None if labels is not None else t.contiguous().float()
+    B = t.shape[0]
+    local = torch.empty(2, HM, dtype=torch.float32, device=Wm0.device)
+    check(lib.cvae_bottleneck_bn_local_stats(ptr(Wm0), ptr(bm0), ptr(onehot), ptr(labels), ptr(local), B, T, HM, stream()), "bottleneck_bn_local_stats")
+    world = _group_size(group)
+    if world == 1:
+        return local.unsqueeze(0)
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)
+    return torch.stack(parts)
 
 
 # ------------------------------------------------------------------------------------------------ CausalVesselVAE extras

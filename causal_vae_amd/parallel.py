@@ -241,15 +241,13 @@ def convert_sync_batchnorm(module, group=None):
     """Make every train-mode BatchNorm1d of `module` normalise with the statistics of the GLOBAL batch (ops.SyncBatchNorm1dTrain: 2 x F-float
     all-reduces forward, one backward) instead of the rank-local one — the exact-equivalence option of SURVEY.md §8(e): with it (and
     summed gradients) an N-rank step of B samples each equals the reference's single-process step on N * B samples.  The fused bottleneck
-    (ops.BioBottleneck) computes mechanism_net's BatchNorm inside its own launches, so models that have it fall back to the layer-by-layer
-    path (`fuse_bottleneck = False`: ~0.25 ms per step at 128^3).  Returns the module."""
+    (ops.BioBottleneck) keeps its launches: the per-rank statistics of mechanism_net.0's output (a function of t alone) are gathered at the top
+    of the step (2 x 64 floats), its backward all-reduces 2 x 64 floats and finishes mechanism_net.0's gradients in one extra small launch.
+    Returns the module."""
     from .layers import BatchNorm1d
-    found = False
     for m in module.modules():
         if isinstance(m, BatchNorm1d):
-            m.sync, m.sync_group, found = True, group, True
-    if found and hasattr(module, "fuse_bottleneck"):
-        module.fuse_bottleneck = False
+            m.sync, m.sync_group = True, group
     return module
 
 

@@ -270,6 +270,31 @@ int cvae_bottleneck_bwd(const cvae_bottleneck_dims* dims, const cvae_bottleneck_
                         const float* t_onehot, const float* eps, const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1,
                         float* dx_partial, void* dy_cl, int dtype, void* stream);
 
+/* ---- The same pair with mechanism_net's BatchNorm1d normalising over the GLOBAL batch of `bn_ranks` data-parallel ranks (SyncBatchNorm; replaces what
+ * nn.SyncBatchNorm.convert_sync_batchnorm does to causal_cascade/models.py:36 under DDP).  The library runs no collective itself; the caller moves
+ * 2 * HM floats per rank twice per step:
+ *   1. cvae_bottleneck_bn_local_stats: local_stats [2][HM] = this rank's (sum, squared deviations from its own mean) of mechanism_net.0's output
+ *      (it depends on t only, so it can run — and the all-gather can travel — before the encoder).  Wm0 [HM][t_dim], bm0 [HM]; t_onehot [M][t_dim] or t_labels [M]
+ *      (either may be NULL);
+ *   2. all-gather -> bn_rank_stats [bn_ranks][2][HM]; cvae_bottleneck_fwd_sync combines them in rank order (Chan's update: identical bits on every rank),
+ *      normalises with the global mean / variance and updates the running statistics with the global unbiased variance.  bn_rank_stats NULL: cvae_bottleneck_fwd;
+ *   3. cvae_bottleneck_bwd_sync: as cvae_bottleneck_bwd, but mechanism_net's backward stops at the BatchNorm: bn_dy [M][HM] = the masked gradient at its output,
+ *      bn_local_sums [2][HM] = this rank's (sum dy, sum dy * xhat) (also written to dbeta / dgamma: the rank's share, summed by the gradient exchange);
+ *      both NULL: cvae_bottleneck_bwd;
+ *   4. all-reduce (sum) of bn_local_sums -> bn_sums; cvae_bottleneck_bn_bwd_finish writes dWm0 / dbm0 from bn_dy and the global sums (one small launch). */
+int cvae_bottleneck_bn_local_stats(const float* Wm0, const float* bm0, const float* t_onehot, const int64_t* t_labels, float* local_stats, int64_t M, int64_t t_dim,
+                                   int64_t HM, void* stream);
+int cvae_bottleneck_fwd_sync(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, float* t_onehot,
+                             const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                             float bn_eps, int bn_training, float* xcat, float* fwd_partial, float* dzm_acc, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype,
+                             const float* bn_rank_stats, int bn_ranks, void* stream);
+int cvae_bottleneck_bwd_sync(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const cvae_bottleneck_grads* grads,
+                             const cvae_bottleneck_saved* saved, const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat,
+                             const float* t_onehot, const float* eps, const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1,
+                             float* dx_partial, void* dy_cl, int dtype, float* bn_dy, float* bn_local_sums, void* stream);
+int cvae_bottleneck_bn_bwd_finish(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const cvae_bottleneck_grads* grads,
+                                  const cvae_bottleneck_saved* saved, const float* t_onehot, const float* bn_dy, const float* bn_sums, int bn_ranks, void* stream);
+
 /* dW fp32 [Cs][Cl][taps] (overwritten) = sum over batch and positions.  workspace: cvae_conv_wgrad_workspace_bytes().
  * dbias (optional, overwritten) rides along in the same pass, where both tensors are read anyway:
  *   dbias_side 0: fp32 [Cs] = sum over batch and positions of S — the bias gradient of a Conv layer (S = output gradient);

@@ -118,26 +118,34 @@ def mode_sync_bn(rank, world, dev):
     from causal_vae_amd import FusedAdam
     from causal_vae_amd.causal_cascade import CausalBioVAE3D, train_step
     from causal_vae_amd.parallel import GradAllReducer, broadcast_parameters, convert_sync_batchnorm
-    B, S = 2, 32
-    x, m, t, eps = global_batch(world, B, S, seed=78)
-    sl = slice(rank * B, (rank + 1) * B)
-    torch.manual_seed(42)
-    model = convert_sync_batchnorm(CausalBioVAE3D().to(dev).train())
-    assert model.fuse_bottleneck is False
-    broadcast_parameters(model)
-    opt = FusedAdam(model.parameters(), lr=1e-3)
-    loss, _, _ = train_step(model, opt, x[sl].to(dev), m[sl].to(dev), t[sl].to(dev), eps=eps[sl].to(dev), grad_hook=GradAllReducer(model.parameters()))
-    tot = loss.clone()
-    dist.all_reduce(tot)
-    sd = oracle.init_state_dict("bio3d", seed=42)
-    ref = oracle.cascade_train_step(sd, x, m, t, eps, nd=3, lr=1e-3)
-    assert rel(tot, ref["loss"]) < 1e-4, (float(tot), float(ref["loss"]))
-    for k, p in model.named_parameters():
-        if k != NOISE_KEY:
-            grad_close(p.grad, ref["grads"][k], k)
-            adam_close(p, sd[k], k)
-    for k in ("mechanism_net.1.running_mean", "mechanism_net.1.running_var"):
-        torch.testing.assert_close(model.state_dict()[k].cpu(), sd[k], rtol=1e-5, atol=1e-6)
+    for S, fused in ((32, False), (64, True)):                   # 32^3: layer-by-layer path (ops.SyncBatchNorm1dTrain); 64^3: inside the fused bottleneck (cvae_bottleneck_*_sync)
+        B = 2
+        x, m, t, eps = global_batch(world, B, S, seed=78)
+        sl = slice(rank * B, (rank + 1) * B)
+        torch.manual_seed(42)
+        model = convert_sync_batchnorm(CausalBioVAE3D().to(dev).train())
+        assert model.fuse_bottleneck is True
+        broadcast_parameters(model)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        loss, _, _ = train_step(model, opt, x[sl].to(dev), m[sl].to(dev), t[sl].to(dev), eps=eps[sl].to(dev), grad_hook=GradAllReducer(model.parameters()))
+        assert (model._enc_out is not None) == fused, (S, fused)
+        tot = loss.clone()
+        dist.all_reduce(tot)
+        sd = oracle.init_state_dict("bio3d", seed=42)
+        ref = oracle.cascade_train_step(sd, x, m, t, eps, nd=3, lr=1e-3)
+        assert rel(tot, ref["loss"]) < 1e-4, (float(tot), float(ref["loss"]))
+        for k, p in model.named_parameters():
+            if k != NOISE_KEY:
+                grad_close(p.grad, ref["grads"][k], k)
+                adam_close(p, sd[k], k)
+        for k in ("mechanism_net.1.running_mean", "mechanism_net.1.running_var"):
+            torch.testing.assert_close(model.state_dict()[k].cpu(), sd[k], rtol=1e-5, atol=1e-6)
+        # the replicas hold the same statistics bit for bit (every rank combines the gathered statistics in rank order)
+        for k in ("mechanism_net.1.running_mean", "mechanism_net.1.running_var"):
+            mine = model.state_dict()[k].clone()
+            other = mine.clone()
+            dist.broadcast(other, src=0)
+            assert torch.equal(mine, other), k
 
 
 def mode_pos_weight(rank, world, dev):

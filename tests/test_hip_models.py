@@ -991,6 +991,58 @@ def test_elbo_values_are_bit_reproducible_and_onehot_input_equals_label_input():
         assert torch.equal(u, v)
 
 
+def test_sync_batchnorm_inside_the_fused_bottleneck():
+    """parallel.convert_sync_batchnorm keeps ops.BioBottleneck (cvae_bottleneck_*_sync).  (a) One rank: the gathered-statistics path is the plain
+    fused step bit for bit — loss, every gradient, the running statistics.  (b) The statistics hand-off itself: the two halves of a batch of 4 as two
+    "ranks" (their local statistics stacked by hand) give m_hat and the running statistics of the whole batch in one process (fp32 rounding apart),
+    identical on both.  The backward hand-off (the all-reduced sums) is checked against the oracle's global-batch step by tests/dist_worker.py sync_bn."""
+    from causal_vae_amd.parallel import convert_sync_batchnorm
+    g = torch.Generator().manual_seed(21)
+    x, m = torch.randn(4, 1, 64, 64, 64, generator=g).to(DEV), torch.rand(4, 12, generator=g).to(DEV)
+    t = torch.tensor([3, 8, 13, 18]).to(DEV)
+    eps = torch.randn(4, 64, generator=g).to(DEV)
+    runs = []
+    for sync in (False, True):
+        torch.manual_seed(5)
+        model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+        if sync:
+            convert_sync_batchnorm(model)
+            assert model.fuse_bottleneck and model.mechanism_net[1].sync
+        loss, _, _ = model.forward_elbo(x, m, t, eps=eps)
+        ops_mod.backward_from(loss)
+        assert model._enc_out is not None                    # the fused path ran
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}, model.mechanism_net[1].running_mean.clone(),
+                     model.mechanism_net[1].running_var.clone()))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), (k, float((runs[0][1][k] - runs[1][1][k]).abs().max()), float(runs[0][1][k].abs().max()))
+    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
+    # (b) two half-batches with hand-stacked statistics against the whole batch
+    lin0, bn = model.mechanism_net[0], model.mechanism_net[1]
+    whole = ops_mod.bottleneck_bn_rank_stats(lin0.weight, lin0.bias, t)
+    halves = torch.cat([ops_mod.bottleneck_bn_rank_stats(lin0.weight, lin0.bias, t[i:i + 2]) for i in (0, 2)])
+    h = (lin0.weight.detach()[:, t].t() + lin0.bias.detach()).double()
+    torch.testing.assert_close(whole[0, 0].double(), h.sum(0), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(whole[0, 1].double(), ((h - h.mean(0)) ** 2).sum(0), rtol=1e-5, atol=1e-7)
+    hy = torch.randn(4, 8, 8, 8, 256, generator=g).to(DEV).relu().to(torch.bfloat16)
+    lins = [model.enc_fc[0], model.enc_fc[2], model.fc_mu, model.fc_logvar, lin0]
+    params = [p for l in lins for p in (l.weight, l.bias)] + [bn.weight, bn.bias]
+    params += [p for l in (model.mechanism_net[3], model.mechanism_net[5], model.dec_input) for p in (l.weight, l.bias)]
+    def run(rows, stats):
+        ps = [p.detach().clone().requires_grad_(True) for p in params]
+        rm, rv, nbt = torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+        extra = () if stats is None else ((None, stats),)
+        out = ops_mod.BioBottleneck.apply(hy[rows], m[rows], t[rows], eps[rows], *ps, rm, rv, nbt, bn.momentum, bn.eps, (4, 4, 4), *extra)
+        return out, ps, rm, rv
+    (mu_w, lv_w, mh_w, dec_w), ps_w, rm_w, rv_w = run(slice(0, 4), None)
+    outs = [run(slice(i, i + 2), halves) for i in (0, 2)]
+    torch.testing.assert_close(torch.cat([o[0][2] for o in outs]), mh_w, rtol=1e-5, atol=1e-6)          # m_hat of the global batch
+    for o in outs:
+        torch.testing.assert_close(o[2], rm_w, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(o[3], rv_w, rtol=1e-5, atol=1e-7)
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])                     # replicas agree bit for bit
+
+
 def test_adam_overlapped_with_backward_gives_the_same_training():
     """FusedAdam.overlap_backward: the non-encoder update runs on a side stream under the encoder backward; same losses and
     parameters as the plain step, bit for bit."""
