@@ -135,6 +135,7 @@ SIGNATURES = {
     "cvae_bottleneck_bwd": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p],
     "cvae_bottleneck_bn_local_stats": [_p] * 5 + [_i64, _i64, _i64, _p],
     "cvae_bottleneck_fwd_sync": [_p] * 10 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
+    "cvae_bottleneck_fwd_ex": [_p] * 10 + [_f, _f, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p],
     "cvae_bottleneck_bwd_sync": [_p] * 12 + [_i, _p, _p, _p, _p, _i, _p, _p, _p],
     "cvae_bottleneck_bn_bwd_finish": [_p] * 7 + [_i, _p],
 }
@@ -165,6 +166,11 @@ class BottleneckPtrs18(C.Structure):
 class BottleneckSaved(C.Structure):
     """cvae_bottleneck_saved"""
     _fields_ = [(n, _p) for n in BOTTLENECK_SAVED]
+
+
+class BottleneckNoise(C.Structure):
+    """cvae_bottleneck_noise"""
+    _fields_ = [("seed", _u64), ("subsequence", _u64), ("call_counter", _p)]
 
 
 class KernelTimer:

@@ -126,7 +126,7 @@ class CausalBioVAE(nn.Module):
         if (not self.training or not torch.is_grad_enabled() or not (2 <= x.shape[0] <= 16) or any(s < 4 or s % 4 for s in sp)
                 or any(s % 16 for s in x.shape[2:]) or not bn.track_running_stats or bn.momentum is None):
             return None
-        sync = ()
+        sync = (None,)
         if getattr(bn, "sync", False):
             # SyncBatchNorm (parallel.convert_sync_batchnorm): mechanism_net.0 sees t only, so its per-rank statistics are gathered here, ahead of the encoder
             sync = ((bn.sync_group, ops.bottleneck_bn_rank_stats(self.mechanism_net[0].weight, self.mechanism_net[0].bias, t, bn.sync_group)),)
@@ -139,15 +139,17 @@ class CausalBioVAE(nn.Module):
         self._enc_out = h                                    # graph.GraphedTrainStep splits the backward here (exchange overlap)
         if not ops.BioBottleneck.supported(h, out_size, True) or last_act != "relu":
             raise ops.L.CvaeError("fused bottleneck: unexpected encoder output " + str(tuple(h.shape)))
-        if eps is None:
-            eps = self._eps.draw(torch.empty(x.shape[0], self.fc_mu.out_features, device=x.device))
+        noise = None
+        if eps is None:                                      # the draw of self._eps.draw(...), made by the bottleneck's first launch
+            eps = torch.empty(x.shape[0], self.fc_mu.out_features, dtype=torch.float32, device=x.device)
+            noise = self._eps.noise_args(x.device)
         lin = [self.enc_fc[0], self.enc_fc[2], self.fc_mu, self.fc_logvar, self.mechanism_net[0]]
         params = [p for l in lin for p in (l.weight, l.bias)] + [bn.weight, bn.bias]
         params += [p for l in (self.mechanism_net[3], self.mechanism_net[5], self.dec_input) for p in (l.weight, l.bias)]
         if t.dim() != 1 or t.dtype != torch.int64:          # BioBottleneck builds the one-hot itself from int64 labels (one_hot raises otherwise)
             t = ops.one_hot(t, self.t_dim)
         mu, logvar, m_hat, dec_cl = ops.BioBottleneck.apply(h, m, t, eps, *params, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                                            bn.momentum, bn.eps, out_size, *sync)
+                                                            bn.momentum, bn.eps, out_size, *sync, noise)
         out_cl = self.dec_conv.forward_from_cl(dec_cl, packed=packed[len(we):], f8=f8)
         if f8 is not None:
             f8.end_step()

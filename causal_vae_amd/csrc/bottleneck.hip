@@ -46,14 +46,26 @@ __device__ __forceinline__ int pool_hi(int o, int in, int out) { return ((o + 1)
 
 // ------------------------------------------------------------------------------------------------ pool_cat_fwd
 // grid (S + 1, M): block (s, b) averages window s of sample b for all C channels (coalesced along c) and writes
-// xcat[b][c * S + s]; block (S, b) copies m and t behind the features.
+// xcat[b][c * S + s]; block (S, b) copies m and t behind the features.  Block (S, 0) can also draw the step's reparameterisation noise
+// (cvae_philox_normal_advance's numbers and call-counter bump, without its launch).
+struct NoiseDraw { float* eps; int n; uint64_t seed, subseq; int* counter; };
 template <typename T>
 __global__ __launch_bounds__(256) void pool_cat_fwd_kernel(const T* __restrict__ y, const float* __restrict__ m, float* __restrict__ t,
                                                            const long long* __restrict__ t_labels, float* __restrict__ xcat, int D, int H, int W, int C,
-                                                           int OD, int OH, int OW, int m_dim, int t_dim, int K1) {
+                                                           int OD, int OH, int OW, int m_dim, int t_dim, int K1, NoiseDraw nz) {
     const int S = OD * OH * OW, b = blockIdx.y, s = blockIdx.x;
     float* row = xcat + (size_t)b * K1;
     if (s == S) {
+        if (nz.counter && b == 0) {                          // uniform over the block
+            const uint64_t offset = ((uint64_t)(unsigned)(*nz.counter)) << 24;
+            __syncthreads();                                 // every thread has read the counter
+            if (threadIdx.x == 0) *nz.counter += 1;
+            for (int i = threadIdx.x; i < (nz.n + 3) / 4; i += 256) {
+                float v[4];
+                philox_normal4(offset + (uint64_t)i, nz.subseq, nz.seed, v);
+                for (int j = 0; j < 4; ++j) if (i * 4 + j < nz.n) nz.eps[i * 4 + j] = v[j];
+            }
+        }
         if (t_labels) {                                      // F.one_hot(t).float() made here: t[b][.] is an output of this block
             const long long lab = t_labels[b];
             for (int i = threadIdx.x; i < t_dim; i += 256) { const float v = (i == lab) ? 1.f : 0.f; t[b * t_dim + i] = v; row[C * S + m_dim + i] = v; }
@@ -1033,15 +1045,25 @@ extern "C" int cvae_bottleneck_fwd(const cvae_bottleneck_dims* q, const cvae_bot
                                    const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float bn_eps,
                                    int bn_training, float* xcat, float* partial, float* dzm_acc, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype,
                                    void* stream) {
-    return cvae_bottleneck_fwd_sync(q, w, y_cl, m, t_onehot, t_labels, eps, running_mean, running_var, num_batches_tracked, momentum, bn_eps, bn_training, xcat, partial, dzm_acc,
-                                    sv, dec_cl, dtype, nullptr, 0, stream);
+    return cvae_bottleneck_fwd_ex(q, w, y_cl, m, t_onehot, t_labels, (float*)eps, running_mean, running_var, num_batches_tracked, momentum, bn_eps, bn_training, xcat, partial,
+                                  dzm_acc, sv, dec_cl, dtype, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int cvae_bottleneck_fwd_sync(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, float* t_onehot,
                                         const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                                         float bn_eps, int bn_training, float* xcat, float* partial, float* dzm_acc, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype,
                                         const float* bn_rank_stats, int bn_ranks, void* stream) {
+    return cvae_bottleneck_fwd_ex(q, w, y_cl, m, t_onehot, t_labels, (float*)eps, running_mean, running_var, num_batches_tracked, momentum, bn_eps, bn_training, xcat, partial,
+                                  dzm_acc, sv, dec_cl, dtype, bn_rank_stats, bn_ranks, nullptr, stream);
+}
+
+extern "C" int cvae_bottleneck_fwd_ex(const cvae_bottleneck_dims* q, const cvae_bottleneck_params* w, const void* y_cl, const float* m, float* t_onehot,
+                                      const int64_t* t_labels, float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                                      float bn_eps, int bn_training, float* xcat, float* partial, float* dzm_acc, const cvae_bottleneck_saved* sv, void* dec_cl, int dtype,
+                                      const float* bn_rank_stats, int bn_ranks, const cvae_bottleneck_noise* noise, void* stream) {
     if (!dims_ok(q)) return CVAE_E_BADSHAPE;
+    if (noise && !noise->call_counter) return CVAE_E_NULLPTR;
+    const NoiseDraw nz = noise ? NoiseDraw{eps, (int)(q->M * q->Z), noise->seed, noise->subsequence, noise->call_counter} : NoiseDraw{nullptr, 0, 0, 0, nullptr};
     if (bn_rank_stats && (bn_ranks < 1 || !bn_training)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (!w || !sv || !y_cl || !m || !t_onehot || !eps || !xcat || !partial || !dec_cl) return CVAE_E_NULLPTR;
@@ -1052,10 +1074,10 @@ extern "C" int cvae_bottleneck_fwd_sync(const cvae_bottleneck_dims* q, const cva
     const int K1 = F + (int)q->m_dim + (int)q->t_dim, K4 = (int)(q->Z + q->m_dim), KS = fwd_ksplit(K1);
     if (dtype == CVAE_BF16)
         hipLaunchKernelGGL(pool_cat_fwd_kernel<bf16>, dim3(S + 1, M), dim3(256), 0, st, (const bf16*)y_cl, m, t_onehot, (const long long*)t_labels, xcat, (int)q->D, (int)q->H, (int)q->W, C,
-                           (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1);
+                           (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1, nz);
     else
         hipLaunchKernelGGL(pool_cat_fwd_kernel<float>, dim3(S + 1, M), dim3(256), 0, st, (const float*)y_cl, m, t_onehot, (const long long*)t_labels, xcat, (int)q->D, (int)q->H, (int)q->W, C,
-                           (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1);
+                           (int)q->OD, (int)q->OH, (int)q->OW, (int)q->m_dim, (int)q->t_dim, K1, nz);
     CVAE_CHECK_LAUNCH();
     const TailDims d = tail_dims(q, KS, 0);
     const TailParams p{w->b1, w->W2, w->b2, w->Wmu, w->bmu, w->Wlv, w->blv, w->Wm0, w->bm0, w->gamma, w->beta, w->Wm3, w->bm3, w->Wm5, w->bm5};

@@ -163,3 +163,23 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
         for (int i = 0; i < nw; ++i) r += red[i];
     return r;
 }
+
+// ---- Philox4x32-10 -> four N(0,1) draws (Box-Muller), shared by cvae_philox_normal* (losses.hip) and the bottleneck's first launch (bottleneck.hip):
+// counter words 0-1 = position in the stream (4 normals each), words 2-3 = subsequence, key = seed.
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox_normal4(uint64_t ctr, uint64_t subseq, uint64_t seed, float v[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)subseq, c3 = (uint32_t)(subseq >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+    sincosf(6.283185307179586f * u1, &v[1], &v[0]);
+    sincosf(6.283185307179586f * u3, &v[3], &v[2]);
+    v[0] *= r0; v[1] *= r0; v[2] *= r1; v[3] *= r1;
+}

@@ -600,11 +600,6 @@ extern "C" int cvae_bn1d_eval_fwd(const float* x, const float* w, const float* b
 }
 
 // ------------------------------------------------------------------------------------- Philox4x32-10 normals
-__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
 // ADVANCE (single-block launches only): after every thread has read the call counter, thread 0 increments it — the draw and the
 // "next call draws fresh numbers" bookkeeping in one launch instead of two.
 // `subseq` selects one of 2^64 independent streams of the same key (Philox counter words 2 and 3): the Python side passes
@@ -618,18 +613,8 @@ __global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_
     }
     const int64_t n4 = (n + 3) >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t ctr = offset + (uint64_t)i;
-        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)subseq, c3 = (uint32_t)(subseq >> 32);
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-        const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
-        const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
-        const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
         float v[4];
-        sincosf(6.283185307179586f * u1, &v[1], &v[0]);
-        sincosf(6.283185307179586f * u3, &v[3], &v[2]);
-        v[0] *= r0; v[1] *= r0; v[2] *= r1; v[3] *= r1;
+        philox_normal4(offset + (uint64_t)i, subseq, seed, v);
         for (int j = 0; j < 4; ++j) if (i * 4 + j < n) out[i * 4 + j] = v[j];
     }
 }

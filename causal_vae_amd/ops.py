@@ -1156,6 +1156,12 @@ class EpsSource:
         self._ensure(like.device)
         return philox_normal(like.shape, torch.initial_seed(), 0, like.device, self.counter, self.subsequence())
 
+    def noise_args(self, device):
+        """(seed, subsequence, device call counter) of the NEXT draw, for a launch that makes the draw itself (ops.BioBottleneck's `noise`): the numbers and
+        the counter bump are draw()'s."""
+        self._ensure(device)
+        return (torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, self.subsequence() & 0xFFFFFFFFFFFFFFFF, self.counter)
+
     def state(self):
         """{'calls': number of draws so far (one host sync), 'instance': which of the process's streams this model draws from}."""
         return {"calls": int(self.counter.item()) if self.counter is not None else int(self._pending or 0), "instance": int(self.instance)}
@@ -1551,7 +1557,8 @@ class BioBottleneck(torch.autograd.Function):
     Same arithmetic (fp32) as the layer-by-layer path, which stays the general fallback (eval mode, B > 16, odd pool windows).
     An optional last argument `sync` = (group, rank_stats) makes mechanism_net's BatchNorm1d a SyncBatchNorm over the ranks of `group`:
     rank_stats is bottleneck_bn_rank_stats(...) (this step's gathered per-rank statistics); the backward all-reduces 2 * HM floats and finishes
-    mechanism_net.0's gradients in one extra small launch (include/cvae_hip.h, cvae_bottleneck_*_sync).
+    mechanism_net.0's gradients in one extra small launch (include/cvae_hip.h, cvae_bottleneck_*_sync).  A further optional argument
+    `noise` = EpsSource.noise_args(device) makes `eps` an output of the first launch (the draw of EpsSource.draw without its launch).
     """
 
     @staticmethod
@@ -1563,6 +1570,7 @@ class BioBottleneck(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y_cl, m, t_onehot, eps, *rest):
         params, (rm, rv, nbt, momentum, bn_eps, out_size), sync = rest[:18], rest[18:24], (rest[24] if len(rest) > 24 else None)
+        noise = rest[25] if len(rest) > 25 else None
         ctx.n_extra = len(rest) - 18
         L.require_gpu(y_cl, m, t_onehot, eps, *params)
         params = [p.contiguous() for p in params]
@@ -1594,9 +1602,14 @@ class BioBottleneck(torch.autograd.Function):
             ranks = rank_stats.shape[0]
             if tuple(rank_stats.shape) != (ranks, 2, HM) or rank_stats.dtype != f32:
                 raise L.CvaeError(f"BioBottleneck: sync rank_stats must be float32 [ranks, 2, {HM}], got {tuple(rank_stats.shape)}")
-        check(lib.cvae_bottleneck_fwd_sync(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(t_labels), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
-                                           float(bn_eps), 1, ptr(xcat), ptr(partial), ptr(dzm_acc), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), ptr(rank_stats), ranks,
-                                           stream()), "bottleneck_fwd")
+        nstruct = None
+        if noise is not None:
+            if noise[2].dtype != torch.int32 or noise[2].device != dev:
+                raise L.CvaeError("BioBottleneck: the noise call counter must be an int32 tensor on the activations' device")
+            nstruct = C_.byref(L.BottleneckNoise(int(noise[0]), int(noise[1]), ptr(noise[2])))
+        check(lib.cvae_bottleneck_fwd_ex(C_.byref(dims), C_.byref(pstruct), ptr(y_cl), ptr(m), ptr(t_onehot), ptr(t_labels), ptr(eps), ptr(rm), ptr(rv), ptr(nbt), float(momentum),
+                                         float(bn_eps), 1, ptr(xcat), ptr(partial), ptr(dzm_acc), C_.byref(sstruct), ptr(dec_cl), L.dtype_code(y_cl.dtype), ptr(rank_stats), ranks,
+                                         nstruct, stream()), "bottleneck_fwd")
         ctx.dims, ctx.scratch = dims, n_dx
         ctx.sync = None if sync is None else (sync[0], ranks)
         ctx.save_for_backward(y_cl, t_onehot, eps, xcat, *params, *[saved[k] for k in L.BOTTLENECK_SAVED], dzm_acc)

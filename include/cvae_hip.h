@@ -288,6 +288,14 @@ int cvae_bottleneck_fwd_sync(const cvae_bottleneck_dims* dims, const cvae_bottle
                              const int64_t* t_labels, const float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                              float bn_eps, int bn_training, float* xcat, float* fwd_partial, float* dzm_acc, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype,
                              const float* bn_rank_stats, int bn_ranks, void* stream);
+/* The general forward: as cvae_bottleneck_fwd_sync, plus (noise != NULL) the reparameterisation noise drawn by the first launch: eps [M][Z] becomes an OUTPUT
+ * holding exactly the numbers cvae_philox_normal_advance(eps, M * Z, seed, 0, subsequence, call_counter) would have written, and *call_counter is incremented
+ * the same way (one launch fewer per step; the reference draws torch.randn_like in reparameterize, causal_cascade/models.py:65-68). */
+typedef struct { uint64_t seed, subsequence; int* call_counter; } cvae_bottleneck_noise;
+int cvae_bottleneck_fwd_ex(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const void* y_cl, const float* m, float* t_onehot,
+                           const int64_t* t_labels, float* eps, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                           float bn_eps, int bn_training, float* xcat, float* fwd_partial, float* dzm_acc, const cvae_bottleneck_saved* saved, void* dec_cl, int dtype,
+                           const float* bn_rank_stats, int bn_ranks, const cvae_bottleneck_noise* noise, void* stream);
 int cvae_bottleneck_bwd_sync(const cvae_bottleneck_dims* dims, const cvae_bottleneck_params* params, const cvae_bottleneck_grads* grads,
                              const cvae_bottleneck_saved* saved, const void* g_dec_cl, const float* g_mu, const float* g_logvar, const float* g_mhat,
                              const float* t_onehot, const float* eps, const float* xcat, const void* y_cl, int relu_mask, float* dzm_partial, float* g1,

@@ -991,6 +991,31 @@ def test_elbo_values_are_bit_reproducible_and_onehot_input_equals_label_input():
         assert torch.equal(u, v)
 
 
+def test_noise_drawn_by_the_bottleneck_launch_is_the_philox_stream():
+    """The fused step draws the reparameterisation noise in the bottleneck's first launch: same numbers, same counter bump as EpsSource.draw
+    (cvae_philox_normal_advance) — two steps with the folded draw == two steps fed philox_normal(...) of calls 0 and 1 explicitly, bit for bit."""
+    g = torch.Generator().manual_seed(23)
+    x, m = torch.randn(2, 1, 64, 64, 64, generator=g).to(DEV), torch.rand(2, 12, generator=g).to(DEV)
+    t = torch.tensor([4, 11]).to(DEV)
+    res = []
+    for explicit in (False, True):
+        ops_mod.EpsSource._instances = 0
+        torch.manual_seed(3)
+        model = CausalBioVAE3D().to(DEV).train().set_compute_dtype(torch.bfloat16)
+        losses = []
+        for call in range(2):
+            eps = None
+            if explicit:
+                eps = ops_mod.philox_normal((2, 64), torch.initial_seed(), call << 24, DEV, None, model._eps.subsequence())
+            losses.append(model.forward_elbo(x, m, t, eps=eps)[0].detach().clone())
+        res.append(losses)
+        if not explicit:
+            assert int(model._eps.counter.item()) == 2 and model._eps.state()["calls"] == 2
+    assert not torch.equal(res[0][0], res[0][1])                 # the second call drew fresh numbers
+    for u, v in zip(*res):
+        assert torch.equal(u, v), (float(u), float(v))
+
+
 def test_sync_batchnorm_inside_the_fused_bottleneck():
     """parallel.convert_sync_batchnorm keeps ops.BioBottleneck (cvae_bottleneck_*_sync).  (a) One rank: the gathered-statistics path is the plain
     fused step bit for bit — loss, every gradient, the running statistics.  (b) The statistics hand-off itself: the two halves of a batch of 4 as two
