@@ -50,6 +50,7 @@ SIGNATURES = {
     "cvae_quantize_fp8": [_p, _i, _p, _i64, _f, _p],
     "cvae_conv_pack_weight_fp8": [_p, _p, _i64, _i64, _i, _i, _f, _p],
     "cvae_conv_up_fp8": [_p, _p, _p, _p, _i, _f, _f] + [_i64] * 9 + [_i, _i, _p],
+    "cvae_conv_up_c1_fp8in": [_p, _p, _p, _p, _f, _i64, _i64, _i64, _i64, _i64, _i, _i, _p],
     "cvae_quantize_fp8_dev": [_p, _i, _p, _i64, _p, _p, _p],
     "cvae_absmax": [_p, _i, _i64, _p, _p],
     "cvae_conv_pack_weights_fp8": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],

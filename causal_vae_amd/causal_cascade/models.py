@@ -88,11 +88,11 @@ class CausalBioVAE(nn.Module):
         x_feat = self.dec_input(z_m_input).view(-1, 256, *([4] * self._ND))
         return self.dec_conv.forward_cl(x_feat)              # channels-last [B, D, H, W, C], compute dtype
 
-    def calibrate_fp8_decoder(self, z, m_hat, headroom=1.0):
+    def calibrate_fp8_decoder(self, z, m_hat, headroom=1.0, c1_fp8_input=True):
         """Scales + fp8 weight panels for decode(..., fp8_plan=...) from one bf16 pass over calibration rows (DeconvStack.calibrate_fp8)."""
         with torch.no_grad():
             x_feat = self.dec_input(ops.cat([z, m_hat])).view(-1, 256, *([4] * self._ND))
-            return self.dec_conv.calibrate_fp8(ops.ToChannelsLast.apply(x_feat, torch.bfloat16), headroom)
+            return self.dec_conv.calibrate_fp8(ops.ToChannelsLast.apply(x_feat, torch.bfloat16), headroom, c1_fp8_input)
 
     def decode(self, z, m_hat, size=None, fp8_plan=None):
         """Decoder half only: [z, m_hat] -> dec_input -> dec_conv -> resize to `size` (default: the native 64^nd).

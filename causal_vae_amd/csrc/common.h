@@ -164,6 +164,13 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return r;
 }
 
+// 8 fp8 (e4m3) codes -> 8 bf16 (exact: every e4m3 value is a bf16 value)
+__device__ __forceinline__ uint4 fp8x8_to_bf16x8(uint2 c) {
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.x, true);
+    const auto d = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, false), e = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.y, true);
+    return make_uint4(pack2_bf16(a[0], a[1]), pack2_bf16(b[0], b[1]), pack2_bf16(d[0], d[1]), pack2_bf16(e[0], e[1]));
+}
+
 // ---- Philox4x32-10 -> four N(0,1) draws (Box-Muller), shared by cvae_philox_normal* (losses.hip) and the bottleneck's first launch (bottleneck.hip):
 // counter words 0-1 = position in the stream (4 normals each), words 2-3 = subsequence, key = seed.
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {

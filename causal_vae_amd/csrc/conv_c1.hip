@@ -582,10 +582,15 @@ __global__ __launch_bounds__(256) void up_c1_mfma_kernel(const bf16* __restrict_
 // in LDS, so a step stages 2 planes instead of 4 (the halo is the kernel's L2 traffic: 2.8 source reads per voxel for a lone 2 x 8 x 16 tile, 1.4
 // when walking).  LDS holds two half-buffers of 2 planes; tile j of a walk reads logical planes {0,1} from buffer j % 2 and {2,3} from the other.
 // The host picks `walk` so that the launch still has >= ~1024 units (walk == 1 for the training batch: same traffic as up_c1_mfma_kernel).
-template <int EPI, bool MASKED>
-__global__ __launch_bounds__(256) void up_c1_mfma_walk_kernel(const bf16* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
+// TIN = fp8 (the decode sweep's hand-off from an fp8 layer, cvae_conv_up_c1_fp8in): S holds e4m3 codes of activation / in_scale; a position's 32 channels are
+// 32 bytes, fetched as four 8-byte pieces in the same thread -> (position, piece) map, widened to bf16 (exactly: 3 mantissa bits) on the way into LDS, and the
+// accumulator is multiplied by in_scale before the bias (the product is linear in S).  Half the bytes of the layer's input, the same tap loop.
+template <int EPI, bool MASKED, typename TIN = bf16>
+__global__ __launch_bounds__(256) void up_c1_mfma_walk_kernel(const TIN* __restrict__ S, const float* __restrict__ w, const float* __restrict__ bias,
                                                               const bf16* __restrict__ mask, bf16* __restrict__ L, int sd, int sh, int sw, int tiles_d,
-                                                              int tiles_h, int tiles_w, int walk, int segs, int nunits, int act) {
+                                                              int tiles_h, int tiles_w, int walk, int segs, int nunits, int act, float in_scale) {
+    constexpr bool IN8 = sizeof(TIN) == 1;
+    using HV = typename std::conditional<IN8, uint2, uint4>::type;
     using TLU = TileC1U<3>;
     constexpr int TD = TLU::TD, TH = TLU::TH, TW = TLU::TW;
     static_assert(TD == 2 && TW == 16 && TD * TH * TW == 256, "two z planes per tile, 16 consecutive-x voxels per column set");
@@ -594,30 +599,34 @@ __global__ __launch_bounds__(256) void up_c1_mfma_walk_kernel(const bf16* __rest
     __shared__ uint4 halo[4 * PPITCH];
     __shared__ __attribute__((aligned(16))) bf16 wfr[NNB * 4 * 8 * 8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, kq = lane >> 4;
-    uint4 hva[HN], hvb[HN];
+    HV hva[HN], hvb[HN];
     // two planes gz0, gz0 + 1 of the halo of tile column (b, o0h, o0w): piece t % 4 of positions t / 4 + 64 i
-    auto issue_half = [&](uint4 (&hv)[HN], int b, int o0h, int o0w, int gz0) {
+    auto issue_half = [&](HV (&hv)[HN], int b, int o0h, int o0w, int gz0) {
         constexpr int DX = 64 % IW, DY = (64 / IW) % IH, DZ = 64 / PLANE;
         const int piece = t & 3, pos0 = t >> 2;
         int x = pos0 % IW, y = (pos0 / IW) % IH, z = pos0 / PLANE;
-        const bf16* Sb = S + (size_t)b * sd * sh * sw * 32 + piece * 8;
+        const TIN* Sb = S + (size_t)b * sd * sh * sw * 32 + piece * 8;
 #pragma unroll
         for (int i = 0; i < HN; ++i) {
             const int gz = gz0 + z, gy = o0h - 1 + y, gx = o0w - 1 + x;
             const bool ok = (z < 2) & (gz >= 0) & (gz < sd) & (gy >= 0) & (gy < sh) & (gx >= 0) & (gx < sw);
-            const uint4 v = *(const uint4*)(Sb + (((size_t)min(max(gz, 0), sd - 1) * sh + min(max(gy, 0), sh - 1)) * sw + min(max(gx, 0), sw - 1)) * 32);
-            hv[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+            const HV v = *(const HV*)(Sb + (((size_t)min(max(gz, 0), sd - 1) * sh + min(max(gy, 0), sh - 1)) * sw + min(max(gx, 0), sw - 1)) * 32);
+            hv[i] = ok ? v : HV{};                           // the fp8 code 0 is +0.0
             x += DX; if (x >= IW) { x -= IW; y += 1; }
             y += DY; if (y >= IH) { y -= IH; z += 1; }
             if (y >= IH) { y -= IH; z += 1; }
             z += DZ;
         }
     };
-    auto store_half = [&](const uint4 (&hv)[HN], int buf) {
+    auto store_half = [&](const HV (&hv)[HN], int buf) {
 #pragma unroll
         for (int i = 0; i < HN; ++i) {
             const int it = t + i * 256;
-            if (it < HPOS * 4) halo[(it & 3) * PPITCH + buf * HPOS + (it >> 2)] = hv[i];
+            if constexpr (IN8) {
+                if (it < HPOS * 4) halo[(it & 3) * PPITCH + buf * HPOS + (it >> 2)] = fp8x8_to_bf16x8(hv[i]);
+            } else {
+                if (it < HPOS * 4) halo[(it & 3) * PPITCH + buf * HPOS + (it >> 2)] = hv[i];
+            }
         }
     };
     auto decode = [&](int unit, int& b, int& td0, int& td1, int& o0h, int& o0w) {
@@ -682,7 +691,9 @@ __global__ __launch_bounds__(256) void up_c1_mfma_walk_kernel(const bf16* __rest
 #pragma unroll
                 for (int py = 0; py < 2; ++py) {
                     const size_t idx = (((size_t)b * ld + lz) * lh + 2 * qy + py) * lw + 2 * qx;
-                    float v0 = apply_act_t<EPI>(acc[cs][2 * py] + bz, act), v1 = apply_act_t<EPI>(acc[cs][2 * py + 1] + bz, act);
+                    float a0 = acc[cs][2 * py], a1 = acc[cs][2 * py + 1];
+                    if constexpr (IN8) { a0 *= in_scale; a1 *= in_scale; }
+                    float v0 = apply_act_t<EPI>(a0 + bz, act), v1 = apply_act_t<EPI>(a1 + bz, act);
                     if constexpr (MASKED) {
                         union { uint32_t u; bf16 e[2]; } mk;
                         mk.u = *(const uint32_t*)(mask + idx);
@@ -1036,7 +1047,7 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
             const int segs = (tiles_d + walk - 1) / walk;
             const int nunits = (int)B * segs * tiles_h * tiles_w;
             dim3 wgrid((unsigned)(nunits < CVAE_C1_MAX_WG ? nunits : CVAE_C1_MAX_WG), 1, 1);
-#define LAUNCH_UP_WALK_(EPI, MASKED) hipLaunchKernelGGL((up_c1_mfma_walk_kernel<EPI, MASKED>), wgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_d, tiles_h, tiles_w, walk, segs, nunits, act)
+#define LAUNCH_UP_WALK_(EPI, MASKED) hipLaunchKernelGGL((up_c1_mfma_walk_kernel<EPI, MASKED>), wgrid, dim3(256), 0, stream, (const bf16*)S, w, bias, (const bf16*)mask, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_d, tiles_h, tiles_w, walk, segs, nunits, act, 1.f)
 #define LAUNCH_UP_WALK(EPI) do { if (mask) LAUNCH_UP_WALK_(EPI, true); else LAUNCH_UP_WALK_(EPI, false); } while (0)
             if (epi == 0) LAUNCH_UP_WALK(0); else if (epi == 1) LAUNCH_UP_WALK(1); else LAUNCH_UP_WALK(2);
 #undef LAUNCH_UP_WALK
@@ -1060,6 +1071,29 @@ int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void
                        (int)sh, (int)sw, (int)ld, (int)lh, (int)lw, act)
     if (nd == 3) LAUNCH_UP_C1(float, 3); else LAUNCH_UP_C1(float, 2);      // bf16 took the MFMA form above
 #undef LAUNCH_UP_C1
+    CVAE_CHECK_LAUNCH();
+    return CVAE_OK;
+}
+
+// The single-channel ConvTranspose3d end fed by fp8 (e4m3) codes: L (bf16) = act(in_scale * (S8 (*) w) + bias).  3D, Cs == 32, exact 2x.
+int cvae_conv_up_c1_fp8in_impl(const void* S8, const float* w, const float* bias, void* L, float in_scale, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int act,
+                          hipStream_t stream) {
+    if (Cs != 32) return CVAE_E_UNSUPPORTED;
+    if (B * sd * sh * sw >= ((int64_t)1 << 30)) return CVAE_E_UNSUPPORTED;
+    const int td = 2, th = 8, tw = 16;                       // TileC1U<3>
+    const int tiles_d = (int)((sd + td - 1) / td), tiles_h = (int)((sh + th - 1) / th), tiles_w = (int)((sw + tw - 1) / tw);
+    const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
+    if (ntiles > 0x7fffffff) return CVAE_E_BADSHAPE;
+    int walk = (int)(ntiles / CVAE_C1U_WALK_MIN_UNITS);
+    if (walk < 1) walk = 1;
+    if (walk > tiles_d) walk = tiles_d;
+    const int segs = (tiles_d + walk - 1) / walk;
+    const int nunits = (int)B * segs * tiles_h * tiles_w;
+    dim3 wgrid((unsigned)(nunits < CVAE_C1_MAX_WG ? nunits : CVAE_C1_MAX_WG), 1, 1);
+    const int epi = CVAE_EPI_OF(act);
+#define LAUNCH_UP_WALK8(EPI) hipLaunchKernelGGL((up_c1_mfma_walk_kernel<EPI, false, fp8>), wgrid, dim3(256), 0, stream, (const fp8*)S8, w, bias, (const bf16*)nullptr, (bf16*)L, (int)sd, (int)sh, (int)sw, tiles_d, tiles_h, tiles_w, walk, segs, nunits, act, in_scale)
+    if (epi == 0) LAUNCH_UP_WALK8(0); else if (epi == 1) LAUNCH_UP_WALK8(1); else LAUNCH_UP_WALK8(2);
+#undef LAUNCH_UP_WALK8
     CVAE_CHECK_LAUNCH();
     return CVAE_OK;
 }

@@ -1817,6 +1817,8 @@ int cvae_conv_down_c1(const void* L, int l_dtype, const float* w, const float* b
                       int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, F8Side f8 = F8Side{nullptr, nullptr, nullptr});
 int cvae_conv_up_c1(const void* S, const float* w, const float* bias, const void* mask, void* L, int64_t B, int64_t sd, int64_t sh, int64_t sw,
                     int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, int act, hipStream_t stream, long long walk_units = 0);
+int cvae_conv_up_c1_fp8in_impl(const void* S8, const float* w, const float* bias, void* L, float in_scale, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int act,
+                               hipStream_t stream);
 size_t cvae_conv_wgrad_c1_workspace_bytes(int64_t Cs, int nd);
 int cvae_conv_wgrad_c1(const void* S, const void* L, int l_dtype, float* dW, float* dbias, float* dbias_l, void* workspace, size_t workspace_bytes, int64_t B, int64_t sd, int64_t sh,
                        int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int nd, int dtype, hipStream_t stream);
@@ -2353,4 +2355,12 @@ extern "C" int cvae_conv_up_fp8(const void* S, const void* w, const float* bias,
                                 void* stream) {
     return cvae_conv_fp8(1, S, w, bias, L, out_dtype, nullptr, nullptr, acc_scale, out_dtype == CVAE_FP8 ? out_inv_scale : 1.f, nullptr, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, act,
                          nullptr, 0, -1, nullptr, stream);
+}
+
+extern "C" int cvae_conv_up_c1_fp8in(const void* S8, const float* w, const float* bias, void* L, float in_scale, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int nd,
+                                     int act, void* stream) {
+    if (!S8 || !w || !L) return CVAE_E_NULLPTR;
+    if (nd != 3 || B < 1 || sd < 1 || sh < 1 || sw < 1) return CVAE_E_UNSUPPORTED;
+    if (act < CVAE_ACT_NONE || act > CVAE_ACT_LEAKY02) return CVAE_E_BADSHAPE;
+    return cvae_conv_up_c1_fp8in_impl(S8, w, bias, L, in_scale, B, sd, sh, sw, Cs, act, (hipStream_t)stream);
 }

@@ -268,9 +268,10 @@ class DeconvStack(nn.Sequential):
         return ops.FromChannelsLast.apply(self.forward_cl(h), h.dim() - 2)
 
     # ---- fp8 (e4m3) inference: the batched counterfactual decode ----
-    def calibrate_fp8(self, x_cl, headroom=1.0):
+    def calibrate_fp8(self, x_cl, headroom=1.0, c1_fp8_input=True):
         """Per-tensor scales and fp8 weight panels for the ConvTranspose layers with more than one output channel, from ONE bf16 pass over the
         calibration rows x_cl [B, .., C] (channels-last, any float dtype): scale = headroom * amax / 448 for every fp8 layer's input and weight.
+        c1_fp8_input: a single-channel 3D output layer behind an fp8 layer takes that layer's fp8 codes as its input (False: bf16 between the two, round 2's plan).
         Returns the plan forward_fp8 takes.  Host syncs here (amax readbacks): call it once, outside any timed or captured region."""
         mods = list(self)
         convs = [(i, m) for i, m in enumerate(mods) if isinstance(m, _ConvBase)]
@@ -283,6 +284,11 @@ class DeconvStack(nn.Sequential):
                     sx = max(float(x.float().abs().max()), 1e-12) * headroom / ops.FP8_MAX
                     sw = max(float(conv.weight.abs().max()), 1e-12) / ops.FP8_MAX
                     plan.append(dict(index=i, act=act, sx=sx, sw=sw, wq=ops.pack_weight_fp8(conv.weight.detach(), nd, True, sw)))
+                elif (nd == 3 and tuple(conv.weight.shape[:2]) == (32, 1) and plan and plan[-1]["sx"] is not None and c1_fp8_input
+                      and isinstance(conv, ConvTranspose3d)):
+                    # the single-channel output layer behind an fp8 layer reads that layer's fp8 codes (cvae_conv_up_c1_fp8in): the 32-channel tensor between the last
+                    # two layers — the largest of the chain — is written and read at one byte per element
+                    plan.append(dict(index=i, act=act, sx=None, sx8=max(float(x.float().abs().max()), 1e-12) * headroom / ops.FP8_MAX))
                 else:
                     plan.append(dict(index=i, act=act, sx=None))
                 x = ops.ConvUp.apply(x, conv.weight.detach(), conv.bias.detach() if conv.bias is not None else None, nd, act, False, False, None)
@@ -298,6 +304,9 @@ class DeconvStack(nn.Sequential):
             for j, e in enumerate(plan):
                 conv = mods[e["index"]]
                 bias = conv.bias.detach() if conv.bias is not None else None
+                if e["sx"] is None and e.get("sx8") is not None and x_is_q:
+                    x, x_is_q = ops.conv_up_c1_fp8in(x, conv.weight.detach(), bias, e["sx8"], nd, e["act"]), False
+                    continue
                 if e["sx"] is None:
                     if x_is_q:
                         raise CvaeError("forward_fp8: an fp8 layer cannot feed a non-fp8 layer without its output scale")
@@ -306,7 +315,7 @@ class DeconvStack(nn.Sequential):
                 if not x_is_q:
                     x = ops.quantize_fp8(x, e["sx"])
                 nxt = plan[j + 1] if j + 1 < len(plan) else None
-                out_scale = nxt["sx"] if (nxt is not None and nxt["sx"] is not None) else None
+                out_scale = (nxt["sx"] if nxt["sx"] is not None else nxt.get("sx8")) if nxt is not None else None
                 x = ops.conv_up_fp8(x, e["wq"], bias, conv.weight.shape[1], nd, e["act"], e["sx"] * e["sw"], out_scale)
                 x_is_q = out_scale is not None
         return x

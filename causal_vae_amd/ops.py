@@ -734,6 +734,20 @@ def conv_up_fp8(Sq, wq, bias, Cl, nd, act, acc_scale, out_scale=None):
     return conv_fp8(True, Sq, wq, bias, Cl, nd, act, acc_scale=acc_scale, out8_scale=out_scale, codes_only=out_scale is not None)
 
 
+def conv_up_c1_fp8in(Sq, weight, bias, in_scale, nd, act):
+    """The single-channel nn.ConvTranspose3d(32, 1, 4, 2, 1) end of a decoder fed by fp8 codes (forward only; cvae_conv_up_c1_fp8in): Sq uint8 [B, sd, sh, sw, 32] =
+    codes of activation / in_scale, weight / bias the layer's fp32 parameters.  Returns bf16 [B, 2sd, 2sh, 2sw, 1]."""
+    L.require_gpu(Sq, weight)
+    if Sq.dtype != torch.uint8 or nd != 3 or Sq.dim() != 5 or Sq.shape[-1] != 32 or tuple(weight.shape[:2]) != (32, 1):
+        raise L.CvaeError(f"conv_up_c1_fp8in: 3D fp8 codes [B, d, h, w, 32] and a ConvTranspose3d(32, 1) weight expected, got {tuple(Sq.shape)} {Sq.dtype} / {tuple(weight.shape)}")
+    Sq, weight = Sq.contiguous(), weight.contiguous().float()
+    B, sd, sh, sw, Cs = Sq.shape
+    out = torch.empty(B, 2 * sd, 2 * sh, 2 * sw, 1, dtype=torch.bfloat16, device=Sq.device)
+    check(lib.cvae_conv_up_c1_fp8in(ptr(Sq), ptr(weight), ptr(bias.contiguous().float() if bias is not None else None), ptr(out), float(in_scale), B, sd, sh, sw, Cs, nd,
+                                    L.act_code(act), stream()), "conv_up_c1_fp8in")
+    return out
+
+
 AMAX_SLOTS = 4096        # CVAE_AMAX_SLOTS
 
 

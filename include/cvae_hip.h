@@ -170,6 +170,11 @@ int cvae_conv_fp8(int up, const void* in8, const void* w8, const float* bias, vo
 int cvae_conv_up_fp8(const void* S, const void* w, const float* bias, void* L, int out_dtype, float acc_scale, float out_inv_scale,
                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int act,
                      void* stream);
+/* The decode sweep's last layer fed by the fp8 layer before it: nn.ConvTranspose3d(32, 1, 4, 2, 1) (causal_cascade/models.py:54 lifted to 3D) of S8 [B][sd][sh][sw][32] e4m3
+ * codes (activation / in_scale, e.g. the codes cvae_conv_up_fp8 leaves with out_dtype CVAE_FP8), fp32 master weight w [32][1][64] and bias as they are: L [B][2sd][2sh][2sw][1] bf16 =
+ * act(in_scale * (S8 (*) w) + bias).  The 32-channel tensor between the last two layers travels at one byte per element and is never widened in memory.  3D, Cs == 32 only. */
+int cvae_conv_up_c1_fp8in(const void* S8, const float* w, const float* bias, void* L, float in_scale, int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs, int nd, int act,
+                          void* stream);
 /* cvae_conv_down_image with bf16 S and the fp8 side channel of a training forward whose next conv runs on fp8 operands: S8 (optional) = fp8(S * *inv_scale_dev),
  * amax_slots (optional) records max |S|, relu_bits_out (optional) receives the ReLU mask of S as bits (cvae_conv_down_bits; this entry point also serves a
  * bf16 step that only wants the bits: S8 = NULL).  Needs the 16-byte-row form (cvae_conv_image_supported). */

@@ -815,12 +815,16 @@ def test_fp8_and_bf16_sweep_decode_close_to_fp32_decode():
     assert model.dec_conv.compute_dtype == torch.bfloat16
     z_rep, m_cf = sweep_inputs(zd, md, feats, vals)
     plan = model.calibrate_fp8_decoder(z_rep[:60], m_cf[:60])
-    assert [e["sx"] is not None for e in plan] == [True, True, True, False]       # the single-channel output layer stays bf16
+    assert [e["sx"] is not None for e in plan] == [True, True, True, False]       # the single-channel output layer keeps bf16 weights and output ...
+    assert plan[-1]["sx8"] > 0                                                      # ... and reads the fp8 codes of the layer before it (cvae_conv_up_c1_fp8in)
     f8 = batched_counterfactual(model, zd, md, feats, vals, fp8_plan=plan)
+    plan_r2 = model.calibrate_fp8_decoder(z_rep[:60], m_cf[:60], c1_fp8_input=False)   # round 2's plan: bf16 between the last two layers
+    assert "sx8" not in plan_r2[-1]
+    f8_r2 = batched_counterfactual(model, zd, md, feats, vals, fp8_plan=plan_r2)
     assert f8.shape == ref.shape and f8.dtype == ref.dtype
     sse = lambda a: ((a.reshape(240, -1) - x.reshape(240, -1)) ** 2).sum(1)
     rl2 = lambda a, b: float((a - b).norm() / b.norm())
-    for name, got, bound in (("bf16", b16, 4.5e-3), ("fp8", f8, 9e-3)):
+    for name, got, bound in (("bf16", b16, 4.5e-3), ("fp8", f8, 9e-3), ("fp8, bf16 hand-off", f8_r2, 9e-3)):
         assert rl2(got, ref) < bound, (name, rl2(got, ref))
         assert rl2(got[1:], ref[1:]) < bound, (name, "rows outside the calibration set")
         d = float(((sse(got) - sse(ref)).abs() / sse(ref)).max())

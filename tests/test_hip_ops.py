@@ -331,6 +331,28 @@ def test_conv_up_fp8_matches_dequantised_reference(nd, B, Cl, Cs, ssize, act, q_
         close(from_cl(y, nd), ref, torch.bfloat16, "y")
 
 
+@pytest.mark.parametrize("B,ssize,act", [(2, (16, 16, 16), None), (3, (5, 9, 17), "sigmoid"), (1, (2, 3, 4), None), (5, (32, 8, 16), None)])
+def test_conv_up_c1_from_fp8_codes_matches_dequantised_reference(B, ssize, act):
+    """cvae_conv_up_c1_fp8in — the decode sweep's single-channel output layer reading the fp8 codes of the layer before it: == conv_transpose3d (fp32, CPU) of the
+    DEQUANTISED activations with the weight rounded to bf16 (the kernel's MFMA operand), once rounded to bf16; and == the bf16-input kernel on the same
+    (bf16-exact) activation values bit for bit (same tap loop, the scale applied to the accumulator)."""
+    g = torch.Generator().manual_seed(25)
+    x = torch.randn(B, 32, *ssize, generator=g).abs()
+    w = torch.randn(32, 1, 4, 4, 4, generator=g) / math.sqrt(32 * 8)
+    b = torch.randn(1, generator=g) * 0.1
+    sx = 2.0 ** -6                                                        # a power of two: dequantised values are bf16 values, so the bf16 kernel sees the same numbers
+    xq = ops.quantize_fp8(to_cl(x, torch.bfloat16), sx)
+    x_deq = from_cl(_e4m3_decode(xq) * sx, 3)
+    ref = F.conv_transpose3d(x_deq, w.bfloat16().float(), b, stride=2, padding=1)
+    if act == "sigmoid":
+        ref = torch.sigmoid(ref)
+    y = ops.conv_up_c1_fp8in(xq, w.to(DEV), b.to(DEV), sx, 3, act)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, 2 * ssize[0], 2 * ssize[1], 2 * ssize[2], 1)
+    close(from_cl(y, 3), ref, torch.bfloat16, "y")
+    y16 = ops.ConvUp.apply(to_cl(x_deq, torch.bfloat16), w.to(DEV), b.to(DEV), 3, act, False, False, None)
+    assert float((y.float() - y16.float()).abs().max()) <= 2.0 ** -7 * float(y16.float().abs().max())        # the scale multiplies the accumulator instead of the operand: <= 1 bf16 ulp
+
+
 @pytest.mark.parametrize("nd,B,Cl,Cs,lsize,splitk", [(3, 2, 32, 64, (16, 16, 16), True), (3, 2, 64, 128, (8, 8, 16), True), (3, 3, 128, 256, (8, 8, 8), True),
                                                      (3, 1, 128, 256, (8, 8, 8), False), (2, 2, 32, 64, (24, 40), True), (3, 1, 32, 64, (10, 12, 18), True)])
 def test_conv_down_fp8_dual_output_device_scales_and_amax(nd, B, Cl, Cs, lsize, splitk):
