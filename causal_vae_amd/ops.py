@@ -743,8 +743,8 @@ def conv_up_c1_fp8in(Sq, weight, bias, in_scale, nd, act):
     Sq, weight = Sq.contiguous(), weight.contiguous().float()
     B, sd, sh, sw, Cs = Sq.shape
     out = torch.empty(B, 2 * sd, 2 * sh, 2 * sw, 1, dtype=torch.bfloat16, device=Sq.device)
-    check(lib.cvae_conv_up_c1_fp8in(ptr(Sq), ptr(weight), ptr(bias.contiguous().float() if bias is not None else None), ptr(out), float(in_scale), B, sd, sh, sw, Cs, nd,
-                                    L.act_code(act), stream()), "conv_up_c1_fp8in")
+    check(L.timed(f"up_c1_fp8in nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} L1", lib.cvae_conv_up_c1_fp8in, ptr(Sq), ptr(weight), ptr(bias.contiguous().float() if bias is not None else None),
+                  ptr(out), float(in_scale), B, sd, sh, sw, Cs, nd, L.act_code(act), stream()), "conv_up_c1_fp8in")
     return out
 
 
@@ -780,7 +780,7 @@ def conv_fp8(up, xq, wq, bias, Cout, nd, act, acc_scale=None, out8_scale=None, c
     out = torch.empty(oshape, dtype=torch.uint8 if codes_only else torch.bfloat16, device=xq.device)
     out8 = torch.empty(oshape, dtype=torch.uint8, device=xq.device) if pair else None
     ws, nbytes = (None, 0) if codes_only else _conv_data_workspace(xq.device, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, int(bool(up)))
-    label = (f"conv_up nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}" if up else f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}")
+    label = (f"conv_up fp8 nd{nd} B{B} S{sd}x{sh}x{sw}x{Cs} -> L{Cl}" if up else f"conv_down fp8 nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}")
     bits = _bits_for(out) if (want_bits and not codes_only and Cout % 32 == 0) else None
     check(L.timed(label, lib.cvae_conv_fp8, int(bool(up)), ptr(xq), ptr(wq), ptr(bias), ptr(out), L.FP8 if codes_only else L.BF16, ptr(out8), ptr(dscale),
                   float(acc_scale if acc_scale is not None else 1.0), (1.0 / float(out8_scale)) if out8_scale is not None else 1.0, ptr(amax),

@@ -16,7 +16,7 @@ d = json.load(open("gpurun_out/prof/pmc_traffic.json"))
 d["_commit"] = h + " (kernels of this commit; bench.py --no-graph under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/profile_round.sh)"
 json.dump(d, open(f"profiles/{r}_pmc_traffic.json", "w"), indent=1)
 PY
-for w in mnist vol64-f32 decode; do
+for w in mnist vol64-f32 decode decode-fp8 vol128-fp8; do
   [ -f $P/stats_$w/run_kernel_stats.csv ] && cp $P/stats_$w/run_kernel_stats.csv profiles/${R}_bench_${w}_kernel_stats.csv && cp $P/bench_${w}_under_rocprof.json profiles/${R}_bench_${w}_under_rocprof.json
 done
 for f in gpurun_out/fin_*.json; do w=$(basename $f .json); cp $f profiles/${R}_bench_${w#fin_}.json; done

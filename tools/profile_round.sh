@@ -23,8 +23,13 @@ find $P -name "*kernel_trace.csv" -delete; find $P -name "*agent_info.csv" -dele
 ls -la $P $P/stats | head -30
 # kernel-stat summaries of the other BASELINE.json workloads (configs[1], configs[2], configs[4])
 cd /tmp
-for w in mnist vol64-f32 decode; do
-  rocprofv3 --kernel-trace --stats -d $P/stats_$w -o run --output-format csv -- python3 $R/bench.py --workload $w --cpu-seconds 0 > $P/bench_${w}_under_rocprof.json 2> $P/stats_$w.err
+for w in mnist vol64-f32 decode decode-fp8 vol128-fp8; do
+  case $w in
+    decode-fp8) ARGS="--workload decode --dtype fp8";;
+    vol128-fp8) ARGS="--dtype fp8";;
+    *) ARGS="--workload $w";;
+  esac
+  rocprofv3 --kernel-trace --stats -d $P/stats_$w -o run --output-format csv -- python3 $R/bench.py $ARGS --cpu-seconds 0 --no-secondary > $P/bench_${w}_under_rocprof.json 2> $P/stats_$w.err
   find $P/stats_$w -name "*kernel_trace.csv" -delete; find $P/stats_$w -name "*agent_info.csv" -delete
   echo "$w stats done"
 done
