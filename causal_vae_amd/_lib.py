@@ -79,6 +79,7 @@ SIGNATURES = {
     "cvae_linear_bwd_data": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
     "cvae_linear_bwd_weight": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i, _p, _sz, _p],
     "cvae_conv_up_variant": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _i, _i, _i64, _p],
+    "cvae_conv_down_variant": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _i, _p],
     "cvae_linear_fwd_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
     "cvae_linear_bwd_data_bf16": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
     "cvae_linear_bwd_weight_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],

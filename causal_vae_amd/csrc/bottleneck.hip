@@ -40,6 +40,25 @@ struct MechFwdArgs { const float* t_onehot; float *running_mean, *running_var; l
                      const float* sync_stats; int sync_ranks; };       // SyncBatchNorm: [ranks][2][HM] (sum, squared deviations from the rank's own mean) of every rank's batch
 struct MechBwdArgs { const float *dzm_part, *g_mhat, *t_onehot; float *sync_dy, *sync_local; };      // SyncBatchNorm: the backward stops at the BatchNorm (see mech_bwd)
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };       // float4 at dword alignment
+// streaming (nontemporal) forms of the dword-aligned 16-byte / 8-byte accesses, for the two passes over enc_fc.0's weight (-DCVAE_BN_NT=1 / 2 / 3: loads / stores / both)
+#ifndef CVAE_BN_NT
+#define CVAE_BN_NT 0
+#endif
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));
+struct F2U;
+template <typename V> __device__ __forceinline__ V ld_stream(const float* p) {
+    if constexpr (CVAE_BN_NT & 1) {
+        if constexpr (sizeof(V) == 16) { const v4f_u v = __builtin_nontemporal_load((const v4f_u*)p); V r; __builtin_memcpy(&r, &v, 16); return r; }
+        else { const v2f_u v = __builtin_nontemporal_load((const v2f_u*)p); V r; __builtin_memcpy(&r, &v, 8); return r; }
+    } else return *(const V*)p;
+}
+template <typename V> __device__ __forceinline__ void st_stream(float* p, const V& val) {
+    if constexpr (CVAE_BN_NT & 2) {
+        if constexpr (sizeof(V) == 16) { v4f_u v; __builtin_memcpy(&v, &val, 16); __builtin_nontemporal_store(v, (v4f_u*)p); }
+        else { v2f_u v; __builtin_memcpy(&v, &val, 8); __builtin_nontemporal_store(v, (v2f_u*)p); }
+    } else *(V*)p = val;
+}
 
 __device__ __forceinline__ int pool_lo(int o, int in, int out) { return (o * in) / out; }
 __device__ __forceinline__ int pool_hi(int o, int in, int out) { return ((o + 1) * in + out - 1) / out; }
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_partial_kernel(const float* __
 #pragma unroll
         for (int mm = 0; mm < MT; ++mm) xv[mm] = mm < M ? *(const F4U*)(x + (size_t)mm * K + k) : F4U{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < R; ++r) wv[r] = *(const F4U*)(wr[r] + k);
+        for (int r = 0; r < R; ++r) wv[r] = ld_stream<F4U>(wr[r] + k);
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -891,7 +910,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
             constexpr int UNR = MT >= 16 ? 2 : CVAE_BN_BWD_UNROLL;      // an unrolled row holds MT values of g: 8 rows of 16 are 128 registers by themselves
 #pragma unroll UNR
             for (int j = 0; j < cnt; ++j) {
-                typename SkinnyBwdCols<MT>::vec w = *(const typename SkinnyBwdCols<MT>::vec*)(Wt + (size_t)(nb + j) * K + k0), dw;
+                typename SkinnyBwdCols<MT>::vec w = ld_stream<typename SkinnyBwdCols<MT>::vec>(Wt + (size_t)(nb + j) * K + k0), dw;
                 const float* wf = (const float*)&w;
                 float* dwf = (float*)&dw;
 #pragma unroll
@@ -902,7 +921,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_colwise_kernel(const float* __
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) { dwf[c] += gv * xv[m][c]; acc[m][c] += gv * wf[c]; }
                 }
-                *(typename SkinnyBwdCols<MT>::vec*)(dW + (size_t)(nb + j) * K + k0) = dw;
+                st_stream<typename SkinnyBwdCols<MT>::vec>(dW + (size_t)(nb + j) * K + k0, dw);
             }
         } else if (nk > 0) {                                 // the row tail (K % CPT columns)
             for (int j = 0; j < cnt; ++j)

@@ -763,6 +763,12 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
 #ifndef CVAE_XPAIR_MIN_WGS
 #define CVAE_XPAIR_MIN_WGS 2048
 #endif
+#ifndef CVAE_XPAIR_2D
+#define CVAE_XPAIR_2D 1                 // the same for 2D layers, `down` and `up`
+#endif
+#ifndef CVAE_XPAIR_2D_MIN_WGS
+#define CVAE_XPAIR_2D_MIN_WGS 512
+#endif
 // Kernel-form selection of one `up` launch.  The library picks by launch size (-1 / 0 = automatic); cvae_conv_up_variant and cvae_conv_fp8 let a caller
 // force a form for ONE call — the tests run every narrow case through both forms that way.  No process-wide state.
 struct UpVariant {
@@ -801,10 +807,11 @@ int launch_data_epi(const void* in, const void* wp, const float* bias, const voi
     constexpr size_t LDS = LDS_MAIN > LDS_X ? LDS_MAIN : LDS_X;
     static_assert(LDS <= 160 * 1024, "LDS tile exceeds the 160 KiB of a CDNA4 CU");
     const int md = UP ? ((ND == 3) ? (g.ld + 1) / 2 : 1) : g.sd, mh = UP ? (g.lh + 1) / 2 : g.sh, mw = UP ? (g.lw + 1) / 2 : g.sw;
-    if constexpr (CVAE_XPAIR && XB == 1 && UP && ND == 3 && (TS == 2 || IsF8<T>::value)) {
-        // a layer at most half a tile wide, on a launch that fills the chip several times over (the decode sweep's 4^3 -> 8^3 layer): two samples per tile
-        const long long wgs = (long long)((md + TL::TD - 1) / TL::TD) * ((mh + TL::TH - 1) / TL::TH) * ((UP ? g.Cl : g.Cs) / BN) * 8 * g.B;
-        if (mw <= TL::TW / 2 && g.B >= 2 && (var.xpair == 1 || (var.xpair < 0 && wgs >= CVAE_XPAIR_MIN_WGS)))
+    if constexpr (CVAE_XPAIR && XB == 1 && sizeof(T) <= 2 && ((UP && ND == 3 && (TS == 2 || IsF8<T>::value)) || (ND == 2 && CVAE_XPAIR_2D))) {
+        // a layer at most half a tile wide, on a launch that fills the chip several times over (the decode sweep's 4^3 -> 8^3 layer; round 3: the 7 x 7 grids of the
+        // MNIST model at batch 1024, where one image fills 49 of a tile's 128 positions, in both directions): two samples per tile
+        const long long wgs = (long long)((md + TL::TD - 1) / TL::TD) * ((mh + TL::TH - 1) / TL::TH) * ((UP ? g.Cl : g.Cs) / BN) * (UP ? (ND == 3 ? 8 : 4) : 1) * g.B;
+        if (mw <= TL::TW / 2 && g.B >= 2 && (var.xpair == 1 || (var.xpair < 0 && wgs >= (ND == 3 ? CVAE_XPAIR_MIN_WGS : CVAE_XPAIR_2D_MIN_WGS))))
             return launch_data_epi<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, 2>(in, wp, bias, mask, out, g, act, workspace, workspace_bytes, stream, acc_scale, out_scale, f8, var);
     }
     auto kern = conv_data_kernel<T, ND, UP, WM, WN, MI, NI, EPI, KH, TO, BD, TS, XB>;
@@ -1951,7 +1958,7 @@ extern "C" size_t cvae_conv_data_workspace_bytes(int64_t B, int64_t sd, int64_t 
 static int conv_down_impl(const void* L, const void* w, const float* bias, const void* mask, void* S,
                           int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
                           int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
-                          void* workspace, size_t workspace_bytes, void* stream, F8Side side) {
+                          void* workspace, size_t workspace_bytes, void* stream, F8Side side, UpVariant var = UpVariant{}) {
     if (!geom_ok(B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd)) return CVAE_E_BADSHAPE;
     if (dtype != CVAE_F32 && dtype != CVAE_BF16) return CVAE_E_DTYPE;
     if (B == 0) return CVAE_OK;
@@ -1961,13 +1968,13 @@ static int conv_down_impl(const void* L, const void* w, const float* bias, const
     if (Cl % 16 || Cs % 64) return CVAE_E_UNSUPPORTED;
     GEOM_INIT();
 #if CVAE_KSPLIT_WAVES
-    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side)
-                                           : launch_data<bf16, 2, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side);
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, var, side)
+                                           : launch_data<bf16, 2, false, 1, 2, 4, 1, 2>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, var, side);
 #endif
-    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side)
-                                           : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side);
-    return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side)
-                   : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, UpVariant{}, side);
+    if (dtype == CVAE_BF16) return nd == 3 ? launch_data<bf16, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, var, side)
+                                           : launch_data<bf16, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, var, side);
+    return nd == 3 ? launch_data<float, 3, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, var, side)
+                   : launch_data<float, 2, false, 2, 2, 2, 1>(L, w, bias, mask, S, g, act, workspace, workspace_bytes, st, var, side);
 }
 
 extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, const void* mask, void* S,
@@ -1975,6 +1982,16 @@ extern "C" int cvae_conv_down(const void* L, const void* w, const float* bias, c
                               int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
                               void* workspace, size_t workspace_bytes, void* stream) {
     return conv_down_impl(L, w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, F8Side{nullptr, nullptr, nullptr});
+}
+// cvae_conv_down with the two-samples-per-tile form forced on (1) or off (0) for this call (the tests run every narrow case through both)
+extern "C" int cvae_conv_down_variant(const void* L, const void* w, const float* bias, const void* mask, void* S,
+                                      int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                                      int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                                      void* workspace, size_t workspace_bytes, int xpair, void* stream) {
+    if (xpair < -1 || xpair > 1) return CVAE_E_BADSHAPE;
+    UpVariant var;
+    var.xpair = xpair;
+    return conv_down_impl(L, w, bias, mask, S, B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, dtype, act, workspace, workspace_bytes, stream, F8Side{nullptr, nullptr, nullptr}, var);
 }
 // cvae_conv_down / cvae_conv_up with ReLU masks as BITS (F8Side, common.h): mask_bits replaces `mask` (1 bit per element of the result instead of the saved
 // activation: 1/16 of the bytes the backward launch reads for it), relu_bits_out receives the mask of THIS launch's result for the backward pass to come.

@@ -419,6 +419,10 @@ def _conv_down(Lt, wp, bias, mask, Cs, nd, act, out_dtype=None, mask_bits=None, 
     use_mb = mask_bits if (mask_bits is not None and c1_ok) else None      # the bit form of the mask wins over the tensor form when the launch can read it
     if use_mb is None and mask is not None:
         bits = None                                          # a tensor mask: the plain entry point (backward launches want no bits of their own anyway)
+    if DOWN_VARIANT is not None and Cl != 1 and use_mb is None:
+        check(lib.cvae_conv_down_variant(ptr(Lt), ptr(wp), ptr(bias), ptr(mask), ptr(S), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(Lt.dtype), L.act_code(act),
+                                         ptr(ws), nbytes, int(DOWN_VARIANT), stream()), "conv_down_variant")
+        return (S, None) if want_bits is not None else S
     if use_mb is not None or bits is not None:
         check(L.timed(label, lib.cvae_conv_down_bits, ptr(Lt), ptr(wp), ptr(bias), ptr(use_mb), ptr(S), ptr(bits), B, sd, sh, sw, Cs, ld, lh, lw, Cl, nd, L.dtype_code(Lt.dtype),
                       L.act_code(act), ptr(ws), nbytes, stream()), "conv_down_bits")
@@ -430,6 +434,7 @@ def _conv_down(Lt, wp, bias, mask, Cs, nd, act, out_dtype=None, mask_bits=None, 
     return (S, None) if want_bits is not None else S
 
 
+DOWN_VARIANT = None  # test hook: xpair (0 / 1) for cvae_conv_down_variant — two samples per tile off / on for every multi-channel `down` launch; None = automatic
 UP_VARIANT = None    # test hook: (upfull, xpair, c1_walk_units) for cvae_conv_up_variant / the xpair of cvae_conv_fp8; None = the library's automatic choice
 
 

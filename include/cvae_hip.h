@@ -450,9 +450,16 @@ int cvae_linear_bwd_data_bf16(const float* dy, const float* W, float* dx, int64_
 int cvae_linear_bwd_weight_bf16(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N, int64_t dy_stride,
                                 int64_t x_stride, void* workspace, size_t workspace_bytes, void* stream);
 
+/* cvae_conv_down with the two-samples-per-tile form (layers at most half a tile wide: 2D grids up to 8 wide — the 7 x 7 maps of the MNIST model —, used
+ * automatically from 512 workgroups up) forced off (0) / on (1) for this call, -1 = automatic.  Same products in the same order: bit-identical results. */
+int cvae_conv_down_variant(const void* L, const void* w, const float* bias, const void* mask, void* S,
+                           int64_t B, int64_t sd, int64_t sh, int64_t sw, int64_t Cs,
+                           int64_t ld, int64_t lh, int64_t lw, int64_t Cl, int nd, int dtype, int act,
+                           void* workspace, size_t workspace_bytes, int xpair, void* stream);
 /* cvae_conv_up with the kernel form chosen by the CALLER for this one call instead of by launch size (the library keeps no process-wide tuning state):
  *   upfull        -1 automatic; 0 / 1: never / whenever it fits — the whole-K `up` kernel (bf16, 64 / 128 / 256 input channels, 32 output channels);
- *   xpair         -1 automatic; 0 / 1: one sample per tile / two side by side — 3D layers at most 4 source voxels wide (the decoder's 4^3 input);
+ *   xpair         -1 automatic; 0 / 1: one sample per tile / two side by side — 3D layers at most 4 source voxels wide (the decoder's 4^3 input), 2D layers
+ *                 at most 8 wide (automatic from 2048 / 512 workgroups up);
  *   c1_walk_units  0 automatic; > 0: the single-channel output layer (bf16, 3D) walks z columns when the launch has at least 2 x this many tiles.
  * Every form computes the same products in the same order (bit-identical results; the tests run each narrow case through both). */
 int cvae_conv_up_variant(const void* S, const void* w, const float* bias, const void* mask, void* L,

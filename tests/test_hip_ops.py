@@ -271,6 +271,46 @@ def test_conv_up_two_samples_per_tile_is_bit_identical(B, Cs, Cl, ssize, act, ma
     assert torch.equal(outs["paired"], outs["single"])
 
 
+@pytest.mark.parametrize("kind,B,Cbig,Csmall,ssize,act,masked", [
+    ("down", 3, 32, 64, (7, 7), "relu", False), ("down", 4, 32, 64, (7, 7), None, True), ("down", 5, 64, 128, (3, 8), "relu", True), ("down", 2, 32, 64, (9, 5), None, False),
+    ("up", 3, 32, 64, (7, 7), "relu", False), ("up", 4, 32, 64, (7, 7), None, True), ("up", 5, 64, 128, (3, 8), "relu", True), ("up", 2, 64, 64, (10, 4), None, False)])
+def test_conv_2d_two_samples_per_tile_is_bit_identical(kind, B, Cbig, Csmall, ssize, act, masked):
+    """bf16 2D layers whose small side is at most 8 wide — the 7 x 7 maps of the MNIST model (mnist_test/01_baseline_causal_vae/models.py:13-14, 45-46), where
+    one image fills 49 of a tile's 8 x 16 positions: large launches put two samples side by side in one tile, `down` (conv forward, ConvTranspose data gradient)
+    and `up` (ConvTranspose forward, conv data gradient) alike.  Same products in the same order: the bits must not move — odd batch, masked output,
+    rows narrower than 8 — and they match the fp32 convolution."""
+    g = torch.Generator().manual_seed(29)
+    lsize = tuple(2 * s for s in ssize)
+    if kind == "down":
+        x = rnd(torch.randn(B, Cbig, *lsize, generator=g), torch.bfloat16)
+        w = torch.randn(Csmall, Cbig, 4, 4, generator=g) / math.sqrt(Cbig * 16)
+        b = torch.randn(Csmall, generator=g)
+        y_ref = F.conv2d(x, rnd(w, torch.bfloat16), b, stride=2, padding=1)
+    else:
+        x = rnd(torch.randn(B, Csmall, *ssize, generator=g), torch.bfloat16)
+        w = torch.randn(Csmall, Cbig, 4, 4, generator=g) / math.sqrt(Csmall * 4)
+        b = torch.randn(Cbig, generator=g)
+        y_ref = F.conv_transpose2d(x, rnd(w, torch.bfloat16), b, stride=2, padding=1)
+    if act == "relu":
+        y_ref = F.relu(y_ref)
+    mask = (torch.rand(y_ref.shape, generator=g) > 0.4).float() if masked else None
+    if masked:
+        y_ref = y_ref * mask
+    xg, bg = to_cl(x, torch.bfloat16), b.to(DEV)
+    wp = ops.pack_weight(w.to(DEV), 2, kind == "up", torch.bfloat16)
+    mg = to_cl(mask, torch.bfloat16) if masked else None
+    outs = {}
+    prev_u, prev_d = ops.UP_VARIANT, ops.DOWN_VARIANT
+    try:
+        for name, xp in [("single", 0), ("paired", 1)]:
+            ops.UP_VARIANT, ops.DOWN_VARIANT = (0, xp, 0), xp       # cvae_conv_up_variant(xpair) / cvae_conv_down_variant(xpair)
+            outs[name] = (ops._conv_down(xg, wp, bg, mg, Csmall, 2, act) if kind == "down" else ops._conv_up(xg, wp, bg, mg, Cbig, 2, act)).clone()
+    finally:
+        ops.UP_VARIANT, ops.DOWN_VARIANT = prev_u, prev_d
+    close(from_cl(outs["single"], 2), y_ref, torch.bfloat16, "y")
+    assert torch.equal(outs["paired"], outs["single"])
+
+
 # --------------------------------------------------------------------------------------------- fp8 (e4m3) inference path
 def _e4m3_decode(codes):
     """uint8 OCP e4m3 codes -> fp32 (the CPU checker's own decode: torch.float8_e4m3fn is that format)."""
