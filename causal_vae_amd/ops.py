@@ -434,6 +434,27 @@ def _conv_down(Lt, wp, bias, mask, Cs, nd, act, out_dtype=None, mask_bits=None, 
     return (S, None) if want_bits is not None else S
 
 
+_GRAD_AT_APPLY = [True]
+
+
+def _backward_may_follow(ctx):
+    """Inside Function.forward: was autograd recording when apply() was called, and does any input ask for a gradient?  (ctx.needs_input_grad alone ignores
+    torch.no_grad(), and grad mode is always off inside forward.)  Decides whether a ReLU layer leaves its mask bits: an inference pass writes none."""
+    return _GRAD_AT_APPLY[0] and any(ctx.needs_input_grad)
+
+
+class _GradModeAtApply:
+    """Mixin for the conv Functions: records torch.is_grad_enabled() at the call."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        _GRAD_AT_APPLY[0] = torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _GRAD_AT_APPLY[0] = True
+
+
 DOWN_VARIANT = None  # test hook: xpair (0 / 1) for cvae_conv_down_variant — two samples per tile off / on for every multi-channel `down` launch; None = automatic
 UP_VARIANT = None    # test hook: (upfull, xpair, c1_walk_units) for cvae_conv_up_variant / the xpair of cvae_conv_fp8; None = the library's automatic choice
 
@@ -586,7 +607,7 @@ def _act_bwd(g, y, act):
     return out
 
 
-class ConvDown(torch.autograd.Function):
+class ConvDown(_GradModeAtApply, torch.autograd.Function):
     """nn.Conv{2,3}d(k=4, s=2, p=1) + bias + activation on channels-last tensors.
 
     in_is_relu_out: the input is itself a ReLU output, so the ReLU mask of the *producer* is fused into this op's
@@ -614,18 +635,18 @@ class ConvDown(torch.autograd.Function):
             sd, sh, sw = (ld // 2 if nd == 3 else 1), lh // 2, lw // 2
             y = _empty((B, sd, sh, sw, Cs), torch.bfloat16, x)
             y8 = torch.empty((B, sd, sh, sw, Cs), dtype=torch.uint8, device=x.device)
-            f8["bits"] = _bits_for(y) if (MASK_BITS and act == "relu") else None
+            f8["bits"] = _bits_for(y) if (MASK_BITS and act == "relu" and _backward_may_follow(ctx)) else None
             check(L.timed(f"conv_down nd{nd} B{B} L{ld}x{lh}x{lw}x{Cl} -> S{Cs}", lib.cvae_conv_down_image_f8, ptr(x), L.dtype_code(x.dtype), ptr(weight.contiguous()), ptr(bias),
                           ptr(y), ptr(y8), ptr(f8["inv_scale"]), ptr(f8.get("amax")), ptr(f8["bits"]), B, sd, sh, sw, Cs, ld, lh, lw, nd, L.act_code(act), stream()), "conv_down_image_f8")
             f8["y8"] = y8
             bits = f8.get("bits")
         elif f8 is not None:
-            want_bits = MASK_BITS and act == "relu"
+            want_bits = MASK_BITS and act == "relu" and _backward_may_follow(ctx)
             res = conv_fp8(False, f8["xq"], f8["wq"], bias, Cs, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"), want_bits=want_bits)
             y, f8["y8"], bits = res
         else:
             wp = packed[0] if packed is not None else pack_weight(weight, nd, False, out_dtype or x.dtype)
-            y, bits = _conv_down(x, wp, bias, None, Cs, nd, act, out_dtype, want_bits=MASK_BITS and act == "relu")
+            y, bits = _conv_down(x, wp, bias, None, Cs, nd, act, out_dtype, want_bits=MASK_BITS and act == "relu" and _backward_may_follow(ctx))     # no backward to come (inference): no mask
         if bits is not None:
             y._relu_bits = bits                              # travels with the activation to the layer whose backward applies this ReLU
         ctx.x_bits = getattr(x, "_relu_bits", None) if (MASK_BITS and in_is_relu_out) else None
@@ -663,7 +684,7 @@ class ConvDown(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
-class ConvUp(torch.autograd.Function):
+class ConvUp(_GradModeAtApply, torch.autograd.Function):
     """nn.ConvTranspose{2,3}d(k=4, s=2, p=1) + bias + activation on channels-last tensors (flags as ConvDown)."""
 
     @staticmethod
@@ -672,11 +693,11 @@ class ConvUp(torch.autograd.Function):
         Cl = weight.shape[1]
         if f8 is not None:                                   # forward product on fp8 operands (see ConvDown.forward)
             res = conv_fp8(True, f8["xq"], f8["wq"], bias, Cl, nd, act, dscale=f8["dscale"], want_out8=f8.get("want_out8", False), amax=f8.get("amax"),
-                           want_bits=MASK_BITS and act == "relu")
+                           want_bits=MASK_BITS and act == "relu" and _backward_may_follow(ctx))
             y, f8["y8"], bits = res
         else:
             wp = packed[1] if packed is not None else pack_weight(weight, nd, True, x.dtype)
-            y, bits = _conv_up(x, wp, bias, None, Cl, nd, act, want_bits=MASK_BITS and act == "relu")
+            y, bits = _conv_up(x, wp, bias, None, Cl, nd, act, want_bits=MASK_BITS and act == "relu" and _backward_may_follow(ctx))
         if bits is not None:
             y._relu_bits = bits
         ctx.x_bits = getattr(x, "_relu_bits", None) if (MASK_BITS and in_is_relu_out) else None
