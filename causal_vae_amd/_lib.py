@@ -82,6 +82,7 @@ SIGNATURES = {
     "cvae_conv_down_variant": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _i, _p],
     "cvae_linear_fwd_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
     "cvae_linear_bwd_data_bf16": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
+    "cvae_linear_bwd_data_inact": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i64, _i, _i, _p, _sz, _p],
     "cvae_linear_bwd_weight_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
     "cvae_bn1d_train_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _p],
     "cvae_bn1d_train_bwd": [_p] * 8 + [_i64, _i64, _p],

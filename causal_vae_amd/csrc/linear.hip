@@ -16,6 +16,14 @@
 #include "common.h"
 #include <type_traits>
 
+// Optional last step of an epilogue: C[m][n] *= act'(src[m][n]) with act' taken from the activation's OUTPUT (common.h act_grad_from_out) — the data gradient of a
+// linear layer whose input was the previous layer's activation output leaves the GEMM already multiplied by that activation's derivative (one elementwise
+// launch fewer per layer; the same fp32 product the separate pass would form).
+struct EpiMul { const float* src; int64_t ld; int act; };
+__device__ __forceinline__ float epi_mul(float v, const EpiMul& em, int64_t gm, int64_t gn) {
+    return em.src ? v * act_grad_from_out(em.src[gm * em.ld + gn], em.act) : v;
+}
+
 #define LT 64
 #define LK 16
 #define AS_STRIDE 17   // As[64][17]  : A-fragment reads (lane -> row) conflict-free
@@ -24,7 +32,7 @@
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                        const float* __restrict__ bias, int64_t M, int64_t N, int64_t K,
                                                        int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
-                                                       int64_t k_per_split, int act, float* __restrict__ slabs) {
+                                                       int64_t k_per_split, int act, float* __restrict__ slabs, EpiMul em) {
     __shared__ float As[LT * AS_STRIDE];
     __shared__ float Bs[LK * BS_STRIDE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 if (gm < M && gn < N) {
                     float v = acc[i][j][r];
                     if (slabs) slabs[((size_t)blockIdx.z * M + gm) * N + gn] = v;          // split-K partial: slab blockIdx.z
-                    else C[gm * ldc + gn] = apply_act(v + (bias ? bias[gn] : 0.f), act);
+                    else C[gm * ldc + gn] = epi_mul(apply_act(v + (bias ? bias[gn] : 0.f), act), em, gm, gn);
                 }
             }
 }
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                         const float* __restrict__ bias, int64_t M, int64_t N, int64_t K,
                                                         int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
-                                                        int64_t k_per_split, int act, float* __restrict__ slabs) {
+                                                        int64_t k_per_split, int act, float* __restrict__ slabs, EpiMul em) {
     __shared__ __attribute__((aligned(16))) bf16 As[LT * S16];
     __shared__ __attribute__((aligned(16))) bf16 Bs[LT * S16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
             const int64_t gm = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (gm < M) {
                 if (slabs) slabs[((size_t)blockIdx.z * M + gm) * N + gn] = acc[e];
-                else C[gm * ldc + gn] = apply_act(acc[e] + bv, act);
+                else C[gm * ldc + gn] = epi_mul(apply_act(acc[e] + bv, act), em, gm, gn);
             }
         }
     }
@@ -206,7 +214,7 @@ template <bool A_KC, bool B_KC, int BK>
 __global__ __launch_bounds__(256) void gemm_bf16_t128_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                              const float* __restrict__ bias, int64_t M, int64_t N, int64_t K,
                                                              int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
-                                                             int64_t k_per_split, int act, float* __restrict__ slabs, int tn, int tm, int n_slow) {
+                                                             int64_t k_per_split, int act, float* __restrict__ slabs, int tn, int tm, int n_slow, EpiMul em) {
     constexpr int BT = 128, PR = BK + 8, PT = 160, NL = BK / 8;      // NL: 16-byte loads per thread per operand per stage
     constexpr int IMG = (BT * PR > BK * PT) ? BT * PR : BK * PT;
     __shared__ __attribute__((aligned(16))) bf16 As[IMG];
@@ -358,6 +366,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_t128_kernel(const float* __rest
                 if (!slabs) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + ((bias && gn + e < N) ? bias[gn + e] : 0.f), act);
+                    if (em.src) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (gn + e < N) v[e] = epi_mul(v[e], em, gm, gn + e);
+                    }
                 }
                 if (gn + 3 < N) *(F4U*)dst = F4U{v[0], v[1], v[2], v[3]};
                 else {
@@ -388,13 +400,13 @@ static bool gemm_t128_ok(int64_t M, int64_t N, int64_t sam, int64_t sak, int64_t
 
 // C[m][c] = act(sum_s slabs[s][m][c] + bias[c]), s in index order
 __global__ void slab_sum_bias_act_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C, const float* __restrict__ bias, int64_t M, int64_t N,
-                                         int64_t ldc, int act) {
+                                         int64_t ldc, int act, EpiMul em = EpiMul{nullptr, 0, 0}) {
     const int64_t n = M * N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / N, c = i - m * N;
         float v = 0.f;
         for (int sp = 0; sp < splits; ++sp) v += slabs[(size_t)sp * n + i];
-        C[m * ldc + c] = apply_act(v + (bias ? bias[c] : 0.f), act);
+        C[m * ldc + c] = epi_mul(apply_act(v + (bias ? bias[c] : 0.f), act), em, m, c);
     }
 }
 
@@ -419,7 +431,8 @@ static int64_t gemm_splits(int64_t M, int64_t N, int64_t K, int64_t* k_per_split
     return (K + k_per_split - 1) / k_per_split;
 }
 static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias, int64_t M, int64_t N, int64_t K,
-                    int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int act, float* ws, size_t ws_bytes, hipStream_t stream, bool bf16_math = false) {
+                    int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int act, float* ws, size_t ws_bytes, hipStream_t stream, bool bf16_math = false,
+                    EpiMul em = EpiMul{nullptr, 0, 0}) {
     if (M < 0 || N <= 0 || K <= 0 || ldc < N) return CVAE_E_BADSHAPE;
     if (M == 0) return CVAE_OK;
     if (!A || !Bm || !C) return CVAE_E_NULLPTR;
@@ -433,12 +446,12 @@ static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias
         const dim3 grid((unsigned)(tn128 * tm128 * sp));
         const bool akc = sak == 1, bkc = sbk == 1;
         const int n_slow = N > M;
-#define T128(AK, BKC) hipLaunchKernelGGL((gemm_bf16_t128_kernel<AK, BKC, CVAE_GEMM_T128_BK>), grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, kps, act, sl, (int)tn128, (int)tm128, n_slow)
+#define T128(AK, BKC) hipLaunchKernelGGL((gemm_bf16_t128_kernel<AK, BKC, CVAE_GEMM_T128_BK>), grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, kps, act, sl, (int)tn128, (int)tm128, n_slow, sl ? EpiMul{nullptr, 0, 0} : em)
         if (akc) { if (bkc) T128(true, true); else T128(true, false); } else { if (bkc) T128(false, true); else T128(false, false); }
 #undef T128
         CVAE_CHECK_LAUNCH();
         if (sl) {
-            hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, (const float*)sl, (int)sp, C, bias, M, N, ldc, act);
+            hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, (const float*)sl, (int)sp, C, bias, M, N, ldc, act, em);
             CVAE_CHECK_LAUNCH();
         }
         return CVAE_OK;
@@ -450,11 +463,12 @@ static int gemm_f32(const float* A, const float* Bm, float* C, const float* bias
     if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float))) { splits = 1; k_per_split = ((K + LK - 1) / LK) * LK; }
     float* slabs = splits > 1 ? ws : nullptr;
     dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
-    if (bf16_math) hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, k_per_split, act, slabs);
-    else hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, k_per_split, act, slabs);
+    const EpiMul emk = slabs ? EpiMul{nullptr, 0, 0} : em;   // split-K: the slab sum applies it
+    if (bf16_math) hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, k_per_split, act, slabs, emk);
+    else hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, A, Bm, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, k_per_split, act, slabs, emk);
     CVAE_CHECK_LAUNCH();
     if (slabs) {
-        hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, (const float*)slabs, (int)splits, C, bias, M, N, ldc, act);
+        hipLaunchKernelGGL(slab_sum_bias_act_kernel, dim3(cvae_grid_1d(M * N, 256)), dim3(256), 0, stream, (const float*)slabs, (int)splits, C, bias, M, N, ldc, act, em);
         CVAE_CHECK_LAUNCH();
     }
     return CVAE_OK;
@@ -713,6 +727,16 @@ extern "C" int cvae_linear_bwd_data_bf16(const float* dy, const float* W, float*
     if (dy_stride < N || dx_stride < K) return CVAE_E_BADSHAPE;
     if (M <= SK_M) return CVAE_E_UNSUPPORTED;
     return gemm_f32(dy, W, dx, nullptr, M, K, N, dy_stride, 1, K, 1, dx_stride, CVAE_ACT_NONE, (float*)workspace, workspace_bytes, (hipStream_t)stream, true);
+}
+// dx = (dy . W) * act'(x_in): the data gradient through this layer AND through the activation that produced this layer's input x_in [M][K] (act' from the
+// activation's output, i.e. from x_in itself) in the GEMM's epilogue — the previous layer then skips its own activation-gradient pass.  Batches above the skinny range.
+extern "C" int cvae_linear_bwd_data_inact(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N, int64_t dy_stride, int64_t dx_stride,
+                                          const float* x_in, int64_t x_stride, int in_act, int bf16_math, void* workspace, size_t workspace_bytes, void* stream) {
+    if (dy_stride < N || dx_stride < K || x_stride < K) return CVAE_E_BADSHAPE;
+    if (M <= SK_M) return CVAE_E_UNSUPPORTED;
+    if (in_act != CVAE_ACT_NONE && !x_in) return CVAE_E_NULLPTR;
+    const EpiMul em = (in_act == CVAE_ACT_NONE) ? EpiMul{nullptr, 0, 0} : EpiMul{x_in, x_stride, in_act};
+    return gemm_f32(dy, W, dx, nullptr, M, K, N, dy_stride, 1, K, 1, dx_stride, CVAE_ACT_NONE, (float*)workspace, workspace_bytes, (hipStream_t)stream, bf16_math != 0, em);
 }
 extern "C" int cvae_linear_bwd_weight_bf16(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N, int64_t dy_stride,
                                            int64_t x_stride, void* workspace, size_t workspace_bytes, void* stream) {

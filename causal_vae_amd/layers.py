@@ -81,9 +81,9 @@ class ConvTranspose3d(_ConvBase, nn.ConvTranspose3d):
 class Linear(nn.Linear):
     math = None            # torch.bfloat16 (set_linear_math): bf16 MFMA operands for large-batch products; None / float32: exact fp32
 
-    def forward(self, x, act=None):
+    def forward(self, x, act=None, in_act=None, grad_premasked=False):
         require_gpu(x)
-        return ops.Linear.apply(x, self.weight, self.bias, act, self.math)
+        return ops.Linear.apply(x, self.weight, self.bias, act, self.math, in_act, grad_premasked)
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -321,6 +321,9 @@ class DeconvStack(nn.Sequential):
         return x
 
 
+MLP_CHAIN = __import__("os").environ.get("CVAE_MLP_CHAIN", "1") != "0"      # (env switch: A/B runs) activation gradients handed to the next layer's GEMM
+
+
 class MLP(nn.Sequential):
     """Sequential of Linear / BatchNorm1d / activation layers; Linear + activation pairs run as one kernel."""
 
@@ -328,11 +331,18 @@ class MLP(nn.Sequential):
         require_gpu(x)
         mods = list(self)
         i = 0
+        # batches above 16 (GEMM path): a Linear + activation whose output feeds the next Linear directly hands the activation gradient to that layer's data-gradient
+        # GEMM (ops.Linear in_act / grad_premasked) — inside this Sequential the activation output has no other consumer
+        chain = MLP_CHAIN and x.dim() == 2 and x.shape[0] > 16 and torch.is_grad_enabled()
+        prev_act = None                                      # activation whose output is the current x (and whose Linear was told its gradient arrives premasked)
         while i < len(mods):
             m = mods[i]
             if isinstance(m, Linear):
                 act = _act_of(mods[i + 1]) if i + 1 < len(mods) else None
-                x = m(x, act=act)
+                nxt = i + (2 if act else 1)
+                hand = chain and act in ("relu", "sigmoid", "leaky02") and nxt < len(mods) and isinstance(mods[nxt], Linear)
+                x = m(x, act=act, in_act=prev_act, grad_premasked=hand)
+                prev_act = act if hand else None
                 i += 2 if act else 1
             elif isinstance(m, BatchNorm1d):
                 x = m(x)

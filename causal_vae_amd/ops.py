@@ -1002,7 +1002,10 @@ class Linear(torch.autograd.Function):
     math = torch.bfloat16: operands rounded to bf16 inside the GEMM kernels (fp32 accumulate) for batches > 16 and M*K*N >= LINEAR_BF16_MIN_WORK."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, math=None):
+    def forward(ctx, x, weight, bias, act, math=None, in_act=None, grad_premasked=False):
+        """in_act: x is the OUTPUT of that activation and this layer is its only consumer — the data gradient leaves this layer's backward already multiplied by
+        the activation's derivative (cvae_linear_bwd_data_inact); grad_premasked: the gradient arriving at this layer's output already carries act'(y) (the next
+        layer was given in_act = act).  layers.MLP sets the pair for consecutive layers at batch sizes above 16: one elementwise launch fewer per layer."""
         L.require_gpu(x, weight, bias)
         if x.dtype != torch.float32:
             raise L.CvaeError("linear layers run in float32")
@@ -1018,18 +1021,22 @@ class Linear(torch.autograd.Function):
         else:
             check(L.timed(f"linear_fwd M{M} K{K} N{N}", lib.cvae_linear_fwd, ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()), "linear_fwd")
         ctx.save_for_backward(x, weight, y)
+        if (in_act not in (None, "none") or grad_premasked) and M <= 16:
+            raise L.CvaeError("Linear: in_act / grad_premasked are for batches above 16 (the skinny kernels fuse the activation gradient on the consuming side)")
         ctx.cfg = (act, bias is not None, b16)
+        ctx.chain = (in_act if in_act not in (None, "none") else None, bool(grad_premasked))
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         act, has_bias, b16 = ctx.cfg
+        in_act, premasked = ctx.chain
         g = g.contiguous()
         M, K = x.shape
         N = weight.shape[0]
         fused = act not in (None, "none") and M <= 16          # skinny kernels apply act'(y) on the fly
-        if act not in (None, "none") and not fused:
+        if act not in (None, "none") and not fused and not premasked:
             g = _act_bwd(g, y, act)
         ya, ac = (ptr(y), L.act_code(act)) if fused else (None, L.ACT_NONE)
         dx = dw = db = None
@@ -1051,12 +1058,15 @@ class Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), torch.float32, g)
             _t2, wp2, wb2 = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 1), g)
-            if b16:
+            if in_act is not None:
+                check(L.timed(f"linear_bwd_data M{M} K{K} N{N}" + (" bf16" if b16 else ""), lib.cvae_linear_bwd_data_inact, ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ptr(x), K,
+                              L.act_code(in_act), int(b16), wp2, wb2, stream()), "linear_bwd_data_inact")
+            elif b16:
                 check(L.timed(f"linear_bwd_data M{M} K{K} N{N} bf16", lib.cvae_linear_bwd_data_bf16, ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, wp2, wb2, stream()), "linear_bwd_data_bf16")
             else:
                 check(L.timed(f"linear_bwd_data M{M} K{K} N{N}", lib.cvae_linear_bwd_data, ptr(g), ptr(weight), ptr(dx), M, K, N, N, K, ya, ac, wp2, wb2, stream()), "linear_bwd_data")
         fork.join(dw, db)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class BatchNorm1dTrain(torch.autograd.Function):

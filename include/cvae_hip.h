@@ -447,6 +447,11 @@ int cvae_linear_fwd_bf16(const float* x, const float* W, const float* b, float* 
                          int act, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_linear_bwd_data_bf16(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N, int64_t dy_stride, int64_t dx_stride,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* dx = (dy . W) * act'(x_in): cvae_linear_bwd_data(_bf16) with the derivative of the activation that produced this layer's INPUT x_in [M][K] (taken from its output,
+ * i.e. from x_in: ReLU / LeakyReLU / Sigmoid) applied in the GEMM's epilogue (or its split-K slab sum) — in an MLP the previous layer then needs no activation-gradient
+ * pass of its own (causal_cascade/models.py:24-31's Linear-ReLU-Linear chains; one launch fewer per layer at batch sizes above 16).  bf16_math as cvae_linear_*_bf16. */
+int cvae_linear_bwd_data_inact(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N, int64_t dy_stride, int64_t dx_stride,
+                               const float* x_in, int64_t x_stride, int in_act, int bf16_math, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_linear_bwd_weight_bf16(const float* dy, const float* x, float* dW, float* db, int64_t M, int64_t K, int64_t N, int64_t dy_stride,
                                 int64_t x_stride, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -751,6 +751,47 @@ def test_linear_bf16_math_forward_backward(M, K, N, act):
     assert l2(y.detach().cpu(), f(F.linear(x, w, b))) < 5e-3
 
 
+@pytest.mark.parametrize("M,dims,acts,math_", [(1024, (22, 512, 64, 12), ("relu", "relu", None), None), (300, (700, 130, 257, 19), ("leaky02", "sigmoid", None), None),
+                                               (1024, (3158, 512, 256, 24), ("relu", "relu", None), torch.bfloat16), (128, (64, 64, 10), ("relu", None), None)])
+def test_mlp_activation_gradient_in_the_next_layers_gemm_is_bit_identical(M, dims, acts, math_):
+    """layers.MLP at batch sizes above 16: the data gradient of layer l + 1 leaves its GEMM already multiplied by act'(output of layer l)
+    (cvae_linear_bwd_data_inact: in the epilogue, or in the split-K slab sum) and layer l skips its activation-gradient launch.  The same fp32 products:
+    every gradient is bit-identical to the layer-by-layer form, in the exact-fp32 and the bf16-operand GEMMs, split-K and whole-K, ragged tiles."""
+    from causal_vae_amd import layers
+    g = torch.Generator().manual_seed(31)
+    mods = []
+    for i, a in enumerate(acts):
+        mods.append(layers.Linear(dims[i], dims[i + 1]))
+        if a:
+            mods.append({"relu": torch.nn.ReLU(), "leaky02": torch.nn.LeakyReLU(0.2), "sigmoid": torch.nn.Sigmoid()}[a])
+    mlp = layers.MLP(*mods).to(DEV)
+    if math_ is not None:
+        layers.set_linear_math(mlp, math_)
+    x = torch.randn(M, dims[0], generator=g).to(DEV)
+    gy = torch.randn(M, dims[-1], generator=g).to(DEV)
+    old, ops.LINEAR_BF16_MIN_WORK = ops.LINEAR_BF16_MIN_WORK, 0
+    res = []
+    try:
+        for chained in (True, False):
+            xg = x.clone().requires_grad_(True)
+            mlp.zero_grad(set_to_none=True)
+            if chained:
+                y = mlp(xg)
+            else:                                            # the same modules one by one: no hand-off between layers
+                y, i = xg, 0
+                while i < len(mods):
+                    a = layers._act_of(mods[i + 1]) if i + 1 < len(mods) else None
+                    y = mods[i](y, act=a)
+                    i += 2 if a else 1
+            y.backward(gy)
+            res.append((y.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in mlp.parameters()]))
+    finally:
+        ops.LINEAR_BF16_MIN_WORK = old
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B", [2, 4, 100])
 def test_batchnorm1d_train_and_eval(B):
     g = torch.Generator().manual_seed(8)
