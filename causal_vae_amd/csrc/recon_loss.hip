@@ -112,6 +112,27 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
         const int z = r % d;
         const int b = r / d;
         const int x0 = 4 * xg, ow0 = 8 * xg;
+        // The target rows this thread compares with (2 x 2 output rows of 8) are requested FIRST, all of them, so that they travel while the source rows are
+        // loaded and interpolated: with the loads inside the row loop every row was its own round trip (5 dependent trips per thread in a one-round grid:
+        // 22 us for 52 MB).  The two neighbours a row needs beyond its 8 columns (MODE 3) come from the adjacent lanes; lanes 0 / 63 fetch them.
+        float4 xa_[2][2], xb_[2][2];
+        float xl_[2][2], xr_[2][2];
+        if (MODE == 1 || MODE == 3) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    const int od = sdz ? 2 * z + a : z, oh = 2 * y + bq;
+                    const size_t rowoff = ((size_t)(b * D + od) * H + oh) * W;
+                    xa_[a][bq] = *(const float4*)(xin + rowoff + ow0);
+                    xb_[a][bq] = *(const float4*)(xin + rowoff + ow0 + 4);
+                    if (MODE == 3) {
+                        const float lft = __shfl_up(xb_[a][bq].w, 1), rgt = __shfl_down(xa_[a][bq].x, 1);
+                        xl_[a][bq] = (ow0 > 0) ? (lane > 0 ? lft : xin[rowoff + ow0 - 1]) : 0.f;
+                        xr_[a][bq] = (ow0 + 8 < W) ? (lane < 63 ? rgt : xin[rowoff + ow0 + 8]) : 0.f;
+                    }
+                }
+        }
         // w-interpolated rows P[zr][yr][j] of the 3 x 3 source rows around (z, y): zr <-> z - 1 + zr, yr <-> y - 1 + yr (clamped)
         float P[3][3][NJ];
         const float2 ew0 = even_w(ow0);
@@ -175,17 +196,17 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
                         *(f32x4*)(dst + rowoff + ow0 + 4) = ob;
                     }
                 } else {
-                    const float4 xa = *(const float4*)(xin + rowoff + ow0), xb = *(const float4*)(xin + rowoff + ow0 + 4);
+                    const float4 xa = xa_[a][bq], xb = xb_[a][bq];
                     const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
                     if (MODE == 1) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { const float df = o[j] - xv[j]; sse += df * df; }
                     } else {
                         float g[10];
-                        g[0] = (ow0 > 0) ? o[0] - xin[rowoff + ow0 - 1] : 0.f;
+                        g[0] = (ow0 > 0) ? o[0] - xl_[a][bq] : 0.f;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { g[1 + j] = o[1 + j] - xv[j]; sse += g[1 + j] * g[1 + j]; }
-                        g[9] = (ow0 + 8 < W) ? o[9] - xin[rowoff + ow0 + 8] : 0.f;
+                        g[9] = (ow0 + 8 < W) ? o[9] - xr_[a][bq] : 0.f;
                         float t1v[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {                // outputs 2 (x0 + q) - 1 + c  ->  local g index 2 q + c
