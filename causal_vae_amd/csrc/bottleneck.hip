@@ -60,6 +60,38 @@ template <typename V> __device__ __forceinline__ void st_stream(float* p, const 
     } else *(V*)p = val;
 }
 
+// global -> LDS copies of the level kernels: ALL of a thread's loads are issued before the first LDS store (U per pass, predicated on a clamped address).  The plain
+// loop `for (i = tid; i < n; i += 256) dst[i] = src[i]` compiles to load / wait / store per iteration — a dependent global round trip (~1.5 us) per 256 elements, which
+// is what these few-microsecond kernels then consist of.
+template <int U>
+__device__ __forceinline__ void copy_g2l(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    for (int base = threadIdx.x; base < n; base += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[min(base + 256 * u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (base + 256 * u < n) dst[base + 256 * u] = v[u];
+    }
+}
+// the same for the 64 consecutive weight rows of a dec_input block: n = 64 * K4 floats (K4 % 4 == 0) as float4 runs into rows of pitch KP
+__device__ __forceinline__ void copy_rows_g2l(float* __restrict__ ws, const float* __restrict__ wsrc, int n, int K4, int KP) {
+    constexpr int U = 8;                                     // 64 * 128 / 4 / 256: one pass up to K4 = 128
+    for (int base = threadIdx.x * 4; base < n; base += 1024 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *(const float4*)(wsrc + min(base + 1024 * u, n - 4));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + 1024 * u;
+            if (i < n) {
+                const int r = i / K4, k = i - r * K4;
+                float* d = ws + r * KP + k;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ int pool_lo(int o, int in, int out) { return (o * in) / out; }
 __device__ __forceinline__ int pool_hi(int o, int in, int out) { return ((o + 1) * in + out - 1) / out; }
 
@@ -404,7 +436,7 @@ __global__ __launch_bounds__(256) void mulv_fwd_kernel(TailDims d, TailParams p,
         const size_t o = (size_t)min(j, d.Z - 1) * d.N2 + min(lane + 64 * u, d.N2 - 1);
         wmp[u] = p.Wmu[o]; wlp[u] = p.Wlv[o];
     }
-    for (int i = tid; i < M * d.N2; i += 256) h2s[i] = sv.h2[i];
+    copy_g2l<4>(h2s, sv.h2, M * d.N2);
     __syncthreads();
     if (j >= d.Z) return;
     float am[BN_MAXM], al[BN_MAXM];
@@ -452,17 +484,11 @@ __global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restr
     const int tid = threadIdx.x;
     const size_t row0 = (size_t)blockIdx.x * 64;
     const float* wsrc = Wd + row0 * K4;
-    if ((K4 & 3) == 0) {
-        for (int i = tid * 4; i < 64 * K4; i += 1024) {
-            const float4 w4 = *(const float4*)(wsrc + i);
-            const int r = i / K4, k = i - r * K4;
-            float* d = ws + r * KP + k;
-            d[0] = w4.x; d[1] = w4.y; d[2] = w4.z; d[3] = w4.w;
-        }
-    } else {
+    if ((K4 & 3) == 0) copy_rows_g2l(ws, wsrc, 64 * K4, K4, KP);
+    else {
         for (int i = tid; i < 64 * K4; i += 256) { const int r = i / K4, k = i - r * K4; ws[r * KP + k] = wsrc[i]; }
     }
-    for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
+    copy_g2l<2>(zs, zm, M * K4);
     __syncthreads();
     const int r = tid & 63, q = tid >> 6;
     const int kq = (K4 + 3) / 4, ka = q * kq, kb = min(K4, ka + kq);
@@ -508,20 +534,22 @@ __global__ __launch_bounds__(256) void dec_input_bwd_kernel(const T* __restrict_
     const float* wsrc = Wd + row0 * K4;
     float* wdst = dWd + row0 * K4;
     const bool v4 = (K4 & 3) == 0;                           // rows start 16-byte aligned
-    if (v4) {
-        for (int i = tid * 4; i < R * K4; i += 1024) {
-            const float4 w4 = *(const float4*)(wsrc + i);
-            const int r = i / K4, k = i - r * K4;
-            float* d = ws + r * KP + k;
-            d[0] = w4.x; d[1] = w4.y; d[2] = w4.z; d[3] = w4.w;
+    {                                                        // this block's M x 64 gradient values first (the scattered side), then the contiguous runs
+        constexpr int UG = (BN_MAXM * R) / 256;              // <= 4 values per thread
+        float gv[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int i = min(tid + 256 * u, M * R - 1);
+            const int m = i / R, n = (int)row0 + (i - m * R), c = n / S, sc = n - c * S;
+            gv[u] = to_f32(gcl[((size_t)m * S + sc) * C + c]);
         }
-    } else {
-        for (int i = tid; i < R * K4; i += 256) { const int r = i / K4, k = i - r * K4; ws[r * KP + k] = wsrc[i]; }
-    }
-    for (int i = tid; i < M * K4; i += 256) zs[i] = zm[i];
-    for (int i = tid; i < M * R; i += 256) {
-        const int m = i / R, n = (int)row0 + (i - m * R), c = n / S, sc = n - c * S;
-        gs[i] = to_f32(gcl[((size_t)m * S + sc) * C + c]);
+        if (v4) copy_rows_g2l(ws, wsrc, R * K4, K4, KP);
+        else {
+            for (int i = tid; i < R * K4; i += 256) { const int r = i / K4, k = i - r * K4; ws[r * KP + k] = wsrc[i]; }
+        }
+        copy_g2l<2>(zs, zm, M * K4);
+#pragma unroll
+        for (int u = 0; u < UG; ++u) if (tid + 256 * u < M * R) gs[tid + 256 * u] = gv[u];
     }
     __syncthreads();
     if (v4) {
@@ -820,7 +848,7 @@ __global__ __launch_bounds__(256) void fc2_bwd_kernel(TailDims d, TailParams p, 
     float w0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) w0[u] = p.W2[(size_t)min(q + 16 * u, N - 1) * K + min(k, K - 1)];
-    for (int i = tid; i < M * N; i += 256) dhs[i] = dh2[i];
+    copy_g2l<4>(dhs, dh2, M * N);
     for (int i = tid; i < M * 16; i += 256) h1c[i] = (k0 + (i & 15) < K) ? sv.h1[(i >> 4) * K + k0 + (i & 15)] : 0.f;
     __syncthreads();
     float acc[BN_MAXM];
