@@ -1425,6 +1425,7 @@ struct WgradEntry {
     const void* S; const void* L; float* ws; float* bias_ws;
     ConvGeom g;
     int n_split, cb, tg, bias_mode;
+    int xb;             // 2D layers at most TW / 2 wide: two samples per tile, side by side in x (the 7 x 7 maps of the MNIST model fill 49 of a tile's 128 positions)
 };
 struct WgradTable { WgradEntry e[WG_MULTI_MAX]; int blk_start[WG_MULTI_MAX + 1]; int count; };
 
@@ -1438,6 +1439,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     float* __restrict__ bias_ws = tb.e[ti].bias_ws;
     const ConvGeom g = tb.e[ti].g;
     const int n_split = tb.e[ti].n_split, bias_mode = tb.e[ti].bias_mode, grid_y = tb.e[ti].cb;
+    const int xb = (ND == 2) ? tb.e[ti].xb : 0;
     // the layer's own grid (n_split, cb, tg), x fastest
     int lb = (int)blockIdx.x - tb.blk_start[ti];
     const int bx = lb % n_split; lb /= n_split;
@@ -1445,7 +1447,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     using TL = Tile<ND, 128>;
     constexpr int NT = 512;
     constexpr int TD = TL::TD, TH = TL::TH, TW = TL::TW;
-    constexpr int IH = 2 * TH + 2, IW = 2 * TW + 2;          // L tile: TD planes (one kd) x IH x IW positions x 32 cl
+    // L tile: TD planes (one kd) x IH x IW positions x 32 cl.  2D: two more columns, so that two samples' halos (2 (TW / 2) + 2 columns each) fit side by side (xb)
+    constexpr int IW1 = 2 * TW + 2, IW = IW1 + (ND == 2 ? 2 : 0), IH = 2 * TH + 2;
     constexpr int SROW = 64 * sizeof(T), LROW = 32 * sizeof(T);
     constexpr int S_BYTES = 128 * SROW;
     constexpr int FB = 8 * sizeof(T);
@@ -1465,7 +1468,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     constexpr int LHALF = IW / 2, LPLANE = TD * IH * LHALF;  // rows per line / per parity plane
     auto s_byte = [](int m, int c) -> int { return m * SROW + ((((c >> 3) ^ (((m >> 1) & 1) << 2)) << 3) + (c & 7)) * (int)sizeof(T); };
     auto l_row = [](int line, int x) -> int { return (x & 1) * LPLANE + line * LHALF + (x >> 1); };
-    const int tiles_per_b = g.tiles_d * g.tiles_h * g.tiles_w, total_tiles = g.B * tiles_per_b;
+    const int tiles_per_b = g.tiles_d * g.tiles_h * g.tiles_w, total_tiles = (xb ? (g.B + 1) / 2 : g.B) * tiles_per_b;
 #ifdef CVAE_STAMP
     const unsigned stamp_wg = blockIdx.x;
     if (t == 0 && stamp_wg < CVAE_STAMP_WGS) {
@@ -1503,10 +1506,11 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
         const int tw_i = tt % g.tiles_w; tt /= g.tiles_w;
         const int th_i = tt % g.tiles_h; tt /= g.tiles_h;
         const int td_i = tt % g.tiles_d;
-        const int b = tt / g.tiles_d;
+        const int b = (tt / g.tiles_d) * (1 + xb);            // xb: samples b (tile columns 0 .. TW / 2 - 1) and b + 1 (the other half)
         const int o0d = td_i * TD, o0h = th_i * TH, o0w = tw_i * TW;
         const T* Sb = S + (size_t)b * s_sample + cs0;
         const T* Lb = L + (size_t)b * l_sample + cl0;
+        const bool b1ok = b + 1 < g.B;
         okmask = 0;
         int tz = t;
         asm volatile("" : "+v"(tz));                         // opaque: keeps the per-piece index math inside the call (hoisted, it spills)
@@ -1514,9 +1518,10 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
         for (int i = 0; i < SN; ++i) {
             const int it = tz + i * NT, piece = it & 7, m = it >> 3;
             const int w = m % TW, hh = m / TW % TH, d = m / (TW * TH);
-            const int od = o0d + d, oh = o0h + hh, ow = o0w + w;
-            const bool ok = (od < g.sd) & (oh < g.sh) & (ow < g.sw);
-            const unsigned off = ((min(od, g.sd - 1) * g.sh + min(oh, g.sh - 1)) * g.sw + min(ow, g.sw - 1)) * g.Cs + piece * 8;
+            const int sx = (xb && w >= TW / 2) ? 1 : 0;
+            const int od = o0d + d, oh = o0h + hh, ow = o0w + w - sx * (TW / 2);
+            const bool ok = (od < g.sd) & (oh < g.sh) & (ow < g.sw) & (!sx | b1ok);
+            const unsigned off = ((min(od, g.sd - 1) * g.sh + min(oh, g.sh - 1)) * g.sw + min(ow, g.sw - 1)) * g.Cs + piece * 8 + ((sx && b1ok) ? (unsigned)s_sample : 0u);
             piece_load_raw<T>(sp[i], Sb + off);
             okmask |= (unsigned)ok << i;
         }
@@ -1524,9 +1529,10 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
         for (int i = 0; i < LN; ++i) {
             const int it = tz + i * NT, piece = it & 3, pos = min(it >> 2, LNPOS - 1);
             const int x = pos % IW, y = pos / IW % IH, d = pos / (IW * IH);
-            const int lz = (ND == 3) ? 2 * (o0d + d) - 1 + kd : 0, ly = 2 * o0h - 1 + y, lx = 2 * o0w - 1 + x;
-            const bool ok = (lz >= 0) & (lz < g.ld) & (ly >= 0) & (ly < g.lh) & (lx >= 0) & (lx < g.lw);
-            const unsigned off = ((min(max(lz, 0), g.ld - 1) * g.lh + min(max(ly, 0), g.lh - 1)) * g.lw + min(max(lx, 0), g.lw - 1)) * g.Cl + piece * 8;
+            const int sx = (xb && x >= IW / 2) ? 1 : 0;
+            const int lz = (ND == 3) ? 2 * (o0d + d) - 1 + kd : 0, ly = 2 * o0h - 1 + y, lx = 2 * o0w - 1 + x - sx * (IW / 2);
+            const bool ok = (lz >= 0) & (lz < g.ld) & (ly >= 0) & (ly < g.lh) & (lx >= 0) & (lx < g.lw) & (!sx | b1ok) & (xb | (x < IW1));
+            const unsigned off = ((min(max(lz, 0), g.ld - 1) * g.lh + min(max(ly, 0), g.lh - 1)) * g.lw + min(max(lx, 0), g.lw - 1)) * g.Cl + piece * 8 + ((sx && b1ok) ? (unsigned)l_sample : 0u);
             piece_load_raw<T>(lp[i], Lb + off);
             okmask |= (unsigned)ok << (SN + i);
         }
@@ -1566,7 +1572,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
             for (int j = 0; j < 32; ++j) {
                 const int pp = pg + 16 * j;
                 const int xx = pp % (2 * TW), yy = pp / (2 * TW) % (2 * TH), dd = pp / (4 * TW * TH);
-                bacc += to_f32(*(const T*)(l_lds + l_row(dd * IH + yy + 1, xx + 1) * LROW + c * (int)sizeof(T)));
+                const int xs = xx + 1 + ((xb && xx >= TW) ? 2 : 0);           // xb: the second sample's own columns start two columns further right
+                bacc += to_f32(*(const T*)(l_lds + l_row(dd * IH + yy + 1, xs) * LROW + c * (int)sizeof(T)));
             }
         }
         if constexpr (sizeof(T) == 2) {
@@ -1584,7 +1591,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
             for (int jj = 0; jj < 2; ++jj) {
                 const int r0 = 8 * hk + 4 * jj + q;
                 abase[jj] = s_lds + s_byte(r0, sg * 32 + 16 * colblk + 4 * p);
-                bbase[jj] = l_lds + l_row(2 * (r0 / TW) + kh, 2 * (r0 % TW)) * LROW + (16 * colblk + 4 * p) * 2;
+                bbase[jj] = l_lds + l_row(2 * (r0 / TW) + kh, 2 * (r0 % TW) + ((xb && (r0 % TW) >= TW / 2) ? 2 : 0)) * LROW + (16 * colblk + 4 * p) * 2;
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -1618,7 +1625,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
                 const float a = *(const float*)(s_lds + s_byte(m, sg * 32 + r));
 #pragma unroll
                 for (int kw = 0; kw < 4; ++kw) {
-                    const float bv = *(const float*)(l_lds + l_row(line, 2 * w + kw) * LROW + r * 4);
+                    const float bv = *(const float*)(l_lds + l_row(line, 2 * w + kw + ((xb && w >= TW / 2) ? 2 : 0)) * LROW + r * 4);
                     acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[kw], 0, 0, 0);
                 }
             }
@@ -1725,9 +1732,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceTable tb) 
 }
 
 #define WGRAD_MAX_WG 512
+#ifndef CVAE_WGRAD_XPAIR
+#define CVAE_WGRAD_XPAIR 1
+#endif
 template <typename T, int ND> constexpr size_t wgrad_lds_bytes() {
     using TL = Tile<ND, 128>;
-    return (size_t)128 * 64 * sizeof(T) + (size_t)TL::TD * (2 * TL::TH + 2) * (2 * TL::TW + 2) * 32 * sizeof(T);
+    return (size_t)128 * 64 * sizeof(T) + (size_t)TL::TD * (2 * TL::TH + 2) * (2 * TL::TW + 2 + (ND == 2 ? 2 : 0)) * 32 * sizeof(T);
 }
 // Launch geometry of one layer's weight gradient: fills the two table entries, returns the workgroup counts of the main and the reduce pass.
 template <typename T, int ND>
@@ -1735,7 +1745,9 @@ int plan_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbias,
                int* reduce_blocks, long long n_split_req = 0) {
     using TL = Tile<ND, 128>;
     g.tiles_d = (g.sd + TL::TD - 1) / TL::TD; g.tiles_h = (g.sh + TL::TH - 1) / TL::TH; g.tiles_w = (g.sw + TL::TW - 1) / TL::TW;
-    const long long total_tiles = (long long)g.B * g.tiles_d * g.tiles_h * g.tiles_w;
+    // 2D layers at most half a tile wide (7 x 7, 4 x 4 maps): two samples per tile — a property of the layer's shape alone, like the slab count below
+    const int xb = (CVAE_WGRAD_XPAIR && ND == 2 && g.sw <= TL::TW / 2 && g.B >= 2) ? 1 : 0;
+    const long long total_tiles = (long long)(xb ? (g.B + 1) / 2 : g.B) * g.tiles_d * g.tiles_h * g.tiles_w;
     const int cb = (g.Cs / 64) * (g.Cl / 32), tg = (ND == 3) ? 4 : 1;
     // each workgroup ends with a 128 KB slab: ~2 workgroups per CU at most, and >= 4 tiles of work per slab
     long long n_split = WGRAD_MAX_WG / ((long long)cb * tg);   // in-step scan of 256 / 512 / 768 / 1024: 234 / 231 / 248 / 253 us for the six launches + reductions
@@ -1767,7 +1779,7 @@ int plan_wgrad(const void* S, const void* L, float* ws, float* dW, float* dbias,
     const long long wgs = (long long)cb * tg * n_split;
     float* bias_ws = ws + (size_t)(wgs > WGRAD_MAX_WG ? wgs : WGRAD_MAX_WG) * 32768;
     if (!dbias) bias_mode = 0;
-    *me = WgradEntry{S, L, ws, bias_ws, g, (int)n_split, cb, tg, bias_mode};
+    *me = WgradEntry{S, L, ws, bias_ws, g, (int)n_split, cb, tg, bias_mode, xb};
     *main_blocks = (int)wgs;
     const int dw_blocks = cb * tg * 4 * 32;
     const int bias_n = bias_mode == 1 ? g.Cs : (bias_mode == 2 ? g.Cl : 0), bias_width = bias_mode == 1 ? 64 : 32;
