@@ -378,6 +378,14 @@ __global__ __launch_bounds__(256) void up2x_bwd_b_kernel(const float* __restrict
     const int b = r / d;
     const Win4 wz = win4(z, d, D, sd, D != d), wy = win4(y, h, H, sh, true);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // all 16 rows of t1 this voxel group reads are requested first, unconditionally, from clamped row indices (a row with weight 0 — beyond the volume, or
+    // the unstrided depth axis — is loaded and not used): with the loads inside the weight tests every row was a dependent round trip of a one-round grid
+    float4 tv[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+            tv[a][bb] = *(const float4*)(t1 + ((size_t)(b * D + min(max(wz.j0 + a, 0), D - 1)) * H + min(max(wy.j0 + bb, 0), H - 1)) * w + 4 * xg);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         if (wz.w[a] == 0.f) continue;
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(256) void up2x_bwd_b_kernel(const float* __restrict
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
             if (wy.w[bb] == 0.f) continue;
-            const float4 v = *(const float4*)(t1 + ((size_t)(b * D + wz.j0 + a) * H + (wy.j0 + bb)) * w + 4 * xg);
+            const float4 v = tv[a][bb];
             pl[0] += wy.w[bb] * v.x; pl[1] += wy.w[bb] * v.y; pl[2] += wy.w[bb] * v.z; pl[3] += wy.w[bb] * v.w;
         }
 #pragma unroll
