@@ -994,11 +994,17 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     for (int c0 = 0; c0 < C; c0 += 256) {
         const int cw = min(256, C - c0);                     // multiple of 64
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (4 * l < cw)
-            for (int ns = q; ns < NS; ns += 4) {
-                const float4 v = *(const float4*)(dxp + (((size_t)ns * M + b) * S + s) * C + c0 + 4 * l);
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        if (4 * l < cw) {
+            constexpr int U = 8;                             // partials in flight (clamped index, predicated add: same order of the sum)
+            for (int n0 = q; n0 < NS; n0 += 4 * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = *(const float4*)(dxp + (((size_t)min(n0 + 4 * u, NS - 1) * M + b) * S + s) * C + c0 + 4 * l);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (n0 + 4 * u < NS) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
             }
+        }
         part[q][l] = a;
         __syncthreads();
         if (q == 0) {

@@ -723,9 +723,17 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
-        for (int k = 0; k < ksplit; ++k) {
-            const float4 a = *(const float4*)(ws + (size_t)k * total + i8), b = *(const float4*)(ws + (size_t)k * total + i8 + 4);
-            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        constexpr int U = 8;                                 // slab loads in flight (clamped index, predicated add: same order of the sum)
+        for (int k0 = 0; k0 < ksplit; k0 += U) {
+            float4 a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float* p = ws + (size_t)min(k0 + u, ksplit - 1) * total + i8;
+                a[u] = *(const float4*)p; b[u] = *(const float4*)(p + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u < ksplit) { v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w; v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w; }
         }
         const float accs = f8.dscale ? f8.dscale[0] : acc_scale;
         const int c = (int)(i8 % Cout);
@@ -1717,9 +1725,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceTable tb) 
     const int row = rowpair * 2 + (lane64 >> 5), col = lane64 & 31;
     const float* base = ws + (size_t)grp * n_split * 32768 + ((kh * 4) * 64 + row) * 32 + col;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int x = q; x < n_split; x += 4) {
-        const float* p = base + (size_t)x * 32768;
-        a.x += p[0]; a.y += p[2048]; a.z += p[4096]; a.w += p[6144];
+    // U slabs' loads are issued before the first add (clamped slab index, predicated add: the order of the sum is unchanged).  The plain loop compiled to
+    // load / wait / add per slab: one dependent round trip per slab, 16-64 of them per thread.
+    constexpr int U = 8;
+    for (int x0 = q; x0 < n_split; x0 += 4 * U) {
+        float v[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* p = base + (size_t)min(x0 + 4 * u, n_split - 1) * 32768;
+            v[u][0] = p[0]; v[u][1] = p[2048]; v[u][2] = p[4096]; v[u][3] = p[6144];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (x0 + 4 * u < n_split) { a.x += v[u][0]; a.y += v[u][1]; a.z += v[u][2]; a.w += v[u][3]; }
     }
     part[q][lane64] = a;
     __syncthreads();

@@ -405,7 +405,14 @@ __global__ void slab_sum_bias_act_kernel(const float* __restrict__ slabs, int sp
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / N, c = i - m * N;
         float v = 0.f;
-        for (int sp = 0; sp < splits; ++sp) v += slabs[(size_t)sp * n + i];
+        constexpr int U = 8;                                 // slab loads in flight (clamped index, predicated add: same order of the sum)
+        for (int s0 = 0; s0 < splits; s0 += U) {
+            float sv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) sv[u] = slabs[(size_t)min(s0 + u, splits - 1) * n + i];
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (s0 + u < splits) v += sv[u];
+        }
         C[m * ldc + c] = epi_mul(apply_act(v + (bias ? bias[c] : 0.f), act), em, m, c);
     }
 }

@@ -127,9 +127,10 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
                     xa_[a][bq] = *(const float4*)(xin + rowoff + ow0);
                     xb_[a][bq] = *(const float4*)(xin + rowoff + ow0 + 4);
                     if (MODE == 3) {
+                        const float el = xin[rowoff + max(ow0 - 1, 0)], er = xin[rowoff + min(ow0 + 8, W - 1)];      // unconditional, clamped (see the source rows below)
                         const float lft = __shfl_up(xb_[a][bq].w, 1), rgt = __shfl_down(xa_[a][bq].x, 1);
-                        xl_[a][bq] = (ow0 > 0) ? (lane > 0 ? lft : xin[rowoff + ow0 - 1]) : 0.f;
-                        xr_[a][bq] = (ow0 + 8 < W) ? (lane < 63 ? rgt : xin[rowoff + ow0 + 8]) : 0.f;
+                        xl_[a][bq] = (ow0 > 0) ? (lane > 0 ? lft : el) : 0.f;
+                        xr_[a][bq] = (ow0 + 8 < W) ? (lane < 63 ? rgt : er) : 0.f;
                     }
                 }
         }
@@ -145,9 +146,12 @@ __global__ __launch_bounds__(256) void up2x_block_kernel(const T* __restrict__ s
                 const T* row = src + ((size_t)(b * d + zi) * h + yi) * w;
                 float v[6];                                  // source x0 - 1 .. x0 + 4 (clamped): one vector load, the two ends from the neighbouring lanes
                 load4_f32(row + x0, v + 1);
+                // the two ends: from the neighbouring lanes, except at the ends of the wave — fetched by EVERY lane from a clamped index and selected (a load inside
+                // a lane-dependent branch makes the compiler wait for everything in flight at each of the nine rows)
+                const float el = to_f32(row[max(x0 - 1, 0)]), er = to_f32(row[min(x0 + 4, w - 1)]);
                 const float lft = __shfl_up(v[4], 1), rgt = __shfl_down(v[1], 1);
-                v[0] = (xg == 0) ? v[1] : (lane > 0 ? lft : to_f32(row[x0 - 1]));
-                v[5] = (xg == wg - 1) ? v[4] : (lane < 63 ? rgt : to_f32(row[x0 + 4]));
+                v[0] = (xg == 0) ? v[1] : (lane > 0 ? lft : el);
+                v[5] = (xg == wg - 1) ? v[4] : (lane < 63 ? rgt : er);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int jj = J0 + j;                   // ow = ow0 + jj, jj in [-1, 8]
