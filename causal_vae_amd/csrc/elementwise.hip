@@ -266,8 +266,17 @@ __global__ void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ 
     const int c_in = threadIdx.x % cl, r_in = threadIdx.x / cl;
     const int64_t c = (int64_t)blockIdx.y * cl + c_in;
     float acc = 0.f;
-    if (r_in < rows && c < C)
-        for (int64_t p = (int64_t)blockIdx.x * rows + r_in; p < P; p += (int64_t)gridDim.x * rows) acc += to_f32(x[p * C + c]);
+    if (r_in < rows && c < C) {
+        constexpr int U = 8;                                 // loads in flight per thread (clamped row, predicated add: same order of the sum)
+        const int64_t stride = (int64_t)gridDim.x * rows;
+        for (int64_t p0 = (int64_t)blockIdx.x * rows + r_in; p0 < P; p0 += U * stride) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int64_t p = p0 + u * stride; v[u] = to_f32(x[(p < P ? p : P - 1) * C + c]); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (p0 + u * stride < P) acc += v[u];
+        }
+    }
     red[threadIdx.x] = acc;
     __syncthreads();
     if (r_in == 0 && c < C) {
@@ -281,7 +290,14 @@ __global__ __launch_bounds__(256) void channel_sum_finish_kernel(const float* __
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += part[(size_t)r * C + c];
+    constexpr int U = 8;
+    for (int r0 = 0; r0 < rows; r0 += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = part[(size_t)min(r0 + u, rows - 1) * C + c];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (r0 + u < rows) s += v[u];
+    }
     out[c] = s;
 }
 // Row blocks (gx) a launch over [P][C] would use when scratch is available
