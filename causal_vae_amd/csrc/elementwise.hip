@@ -41,10 +41,15 @@ __global__ void transpose_cs_kernel(const TS* __restrict__ src, TD* __restrict__
     const int64_t b = blockIdx.z;
     const int64_t s0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+    // a thread's 16 loads are issued together from clamped indices, then stored to LDS (a load under a bounds test: one dependent round trip per row pass)
     if (TO_NSC) {   // src [C][S] -> dst [S][C]
-        for (int r = ty; r < 64; r += 4) {
-            int64_t c = c0 + r, s = s0 + tx;
-            tile[r][tx] = (c < C && s < S) ? to_f32(src[(b * C + c) * S + s]) : 0.f;
+        {
+            float v[16];
+            const int64_t s = s0 + tx, sc = s < S ? s : S - 1;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int64_t c = c0 + ty + 4 * u; v[u] = to_f32(src[(b * C + (c < C ? c : C - 1)) * S + sc]); }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tile[ty + 4 * u][tx] = (c0 + ty + 4 * u < C && s < S) ? v[u] : 0.f;
         }
         __syncthreads();
         for (int r = ty; r < 64; r += 4) {
@@ -52,9 +57,13 @@ __global__ void transpose_cs_kernel(const TS* __restrict__ src, TD* __restrict__
             if (s < S && c < C) dst[(b * S + s) * C + c] = from_f32<TD>(tile[tx][r]);
         }
     } else {        // src [S][C] -> dst [C][S]
-        for (int r = ty; r < 64; r += 4) {
-            int64_t s = s0 + r, c = c0 + tx;
-            tile[r][tx] = (c < C && s < S) ? to_f32(src[(b * S + s) * C + c]) : 0.f;
+        {
+            float v[16];
+            const int64_t c = c0 + tx, cc = c < C ? c : C - 1;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int64_t sr = s0 + ty + 4 * u; v[u] = to_f32(src[(b * S + (sr < S ? sr : S - 1)) * C + cc]); }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tile[ty + 4 * u][tx] = (c < C && s0 + ty + 4 * u < S) ? v[u] : 0.f;
         }
         __syncthreads();
         for (int r = ty; r < 64; r += 4) {
@@ -407,9 +416,13 @@ __global__ __launch_bounds__(256) void flatten_fwd_kernel(const T* __restrict__ 
     const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const T* xb = x + (size_t)b * V * C;
-    for (int r = ty; r < 64; r += 4) {
-        const int p = p0 + r, c = c0 + tx;
-        tile[r][tx] = (p < V && c < C) ? to_f32(xb[(size_t)p * C + c]) : 0.f;
+    {   // all 16 loads of a thread first, from clamped indices (a load under a bounds test is a dependent round trip per iteration), then the LDS stores
+        float v[16];
+        const int c = c0 + tx, cc = min(c, C - 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = to_f32(xb[(size_t)min(p0 + ty + 4 * u, V - 1) * C + cc]);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tile[ty + 4 * u][tx] = (p0 + ty + 4 * u < V && c < C) ? v[u] : 0.f;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -423,17 +436,25 @@ __global__ __launch_bounds__(256) void flatten_bwd_kernel(const float* __restric
     __shared__ float tile[64][65];
     const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {
-        const int c = c0 + r, p = p0 + tx;
-        tile[r][tx] = (c < C && p < V) ? dout[(size_t)b * dstride + (size_t)c * V + p] : 0.f;
+    float mk[16];
+    {   // the 16 gradient loads and the 16 mask loads of a thread are issued together, from clamped indices (see flatten_fwd_kernel)
+        float v[16];
+        const int p = p0 + tx, pc = min(p, V - 1), cm = min(c0 + tx, C - 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = dout[(size_t)b * dstride + (size_t)min(c0 + ty + 4 * u, C - 1) * V + pc];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mk[u] = mask ? to_f32(mask[((size_t)b * V + min(p0 + ty + 4 * u, V - 1)) * C + cm]) : 1.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tile[ty + 4 * u][tx] = (c0 + ty + 4 * u < C && p < V) ? v[u] : 0.f;
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int p = p0 + r, c = c0 + tx;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int r = ty + 4 * u, p = p0 + r, c = c0 + tx;
         if (p < V && c < C) {
             const size_t i = ((size_t)b * V + p) * C + c;
             const float g = tile[tx][r];
-            dx[i] = from_f32<T>((!mask || to_f32(mask[i]) > 0.f) ? g : 0.f);
+            dx[i] = from_f32<T>(mk[u] > 0.f ? g : 0.f);
         }
     }
 }
