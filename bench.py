@@ -295,13 +295,16 @@ def run_volume(args, rank, world, dev):
         from causal_vae_amd.optim import clip_grad_norm_
         from causal_vae_amd.vessel import loss_function as vessel_loss, total_loss
 
+        zero_lv = torch.zeros(args.batch, 12, device=dev)    # unit variance (a constant of the workload, not a per-step fill)
+
         def vessel_step_fn():
             """The vessel recipe's step on volumes (vessel_analysis/01_train/train.py:18-60, 70-86): pos-weighted MSE-sum + 0.3 * background L1 +
             0.5 * KLD + Gaussian NLL of m (unit variance: the lift has no m_logvar head), clip_grad_norm_(5.0), Adam."""
             opt.zero_grad(set_to_none=True)
             recon_x, m_hat, mu, logvar = model(x, m, t)
-            recon, kld, morph, sparsity = vessel_loss(recon_x, x, m_hat, m, mu, logvar, m_hat, torch.zeros_like(m_hat))
-            loss = total_loss(recon, kld, morph, sparsity, beta=0.5)
+            with _ops.zero_pool(8, x):                       # as vessel/train.py:train_step: the loss scalars' zero fills pooled
+                recon, kld, morph, sparsity = vessel_loss(recon_x, x, m_hat, m, mu, logvar, m_hat, zero_lv)
+                loss = total_loss(recon, kld, morph, sparsity, beta=0.5)
             _ops.backward_from(loss)
             if reducer is not None:
                 reducer()
