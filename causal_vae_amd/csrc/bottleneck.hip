@@ -129,11 +129,20 @@ __global__ __launch_bounds__(256) void pool_cat_fwd_kernel(const T* __restrict__
     const int ow = s % OW, oh = (s / OW) % OH, od = s / (OW * OH);
     const int d0 = pool_lo(od, D, OD), d1 = pool_hi(od, D, OD), h0 = pool_lo(oh, H, OH), h1 = pool_hi(oh, H, OH), w0 = pool_lo(ow, W, OW), w1 = pool_hi(ow, W, OW);
     const float inv = 1.f / (float)((d1 - d0) * (h1 - h0) * (w1 - w0));
+    const int nh = h1 - h0, nw = w1 - w0, nvox = (d1 - d0) * nh * nw;
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.f;
-        for (int d = d0; d < d1; ++d)
-            for (int h = h0; h < h1; ++h)
-                for (int w = w0; w < w1; ++w) acc += to_f32(y[((((size_t)b * D + d) * H + h) * W + w) * C + c]);
+        constexpr int U = 8;                                 // window voxels in flight (clamped index, predicated add: the order of the sum is the nested loops')
+        for (int v0 = 0; v0 < nvox; v0 += U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int vi = min(v0 + u, nvox - 1), w = vi % nw, h = (vi / nw) % nh, d = vi / (nw * nh);
+                v[u] = to_f32(y[((((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w) * C + c]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (v0 + u < nvox) acc += v[u];
+        }
         row[c * S + s] = acc * inv;
     }
 }
