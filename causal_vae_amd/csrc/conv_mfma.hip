@@ -1667,13 +1667,13 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void conv_wgrad_kernel
     }
     const int col = lane & 31, hq = lane >> 5;
     float* slab = ws + ((size_t)(bz * grid_y + by) * n_split + bx) * 32768;
+    // slab layout [kh][64 cs][32 cl][kw]: the lane owns the four kw values of (cs row, cl col), so they leave as ONE 16-byte store (32 lanes = 512 contiguous
+    // bytes) and wgrad_reduce_kernel reads them back as one 16-byte load per slab — a quarter of the memory instructions of the [kh][kw][cs][cl] form on both sides
 #pragma unroll
-    for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = sg * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
-            slab[((kh * 4 + kw) * 64 + row) * 32 + col] = acc[kw][e];
-        }
+    for (int e = 0; e < 16; ++e) {
+        const int row = sg * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
+        *(float4*)(slab + ((kh * 64 + row) * 32 + col) * 4) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+    }
 #ifdef CVAE_STAMP
     __builtin_amdgcn_s_waitcnt(0);
     STAMP(27);
@@ -1723,21 +1723,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceTable tb) 
     const int kd = grp / cb, blk = grp % cb;
     const int lane64 = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int row = rowpair * 2 + (lane64 >> 5), col = lane64 & 31;
-    const float* base = ws + (size_t)grp * n_split * 32768 + ((kh * 4) * 64 + row) * 32 + col;
+    const float* base = ws + (size_t)grp * n_split * 32768 + ((kh * 64 + row) * 32 + col) * 4;      // slab layout [kh][cs][cl][kw]
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     // U slabs' loads are issued before the first add (clamped slab index, predicated add: the order of the sum is unchanged).  The plain loop compiled to
     // load / wait / add per slab: one dependent round trip per slab, 16-64 of them per thread.
     constexpr int U = 8;
     for (int x0 = q; x0 < n_split; x0 += 4 * U) {
-        float v[U][4];
+        float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float* p = base + (size_t)min(x0 + 4 * u, n_split - 1) * 32768;
-            v[u][0] = p[0]; v[u][1] = p[2048]; v[u][2] = p[4096]; v[u][3] = p[6144];
-        }
+        for (int u = 0; u < U; ++u) v[u] = *(const float4*)(base + (size_t)min(x0 + 4 * u, n_split - 1) * 32768);
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (x0 + 4 * u < n_split) { a.x += v[u][0]; a.y += v[u][1]; a.z += v[u][2]; a.w += v[u][3]; }
+            if (x0 + 4 * u < n_split) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
     }
     part[q][lane64] = a;
     __syncthreads();
