@@ -103,6 +103,16 @@ class RcclComm:
         code = 0 if flat.dtype == torch.float32 else 1
         self._check(self.lib().cvae_dp_allreduce_sum(self._h, flat.data_ptr(), flat.numel(), code, torch.cuda.current_stream(flat.device).cuda_stream), "cvae_dp_allreduce_sum")
 
+    def reduce_scatter_sum(self, flat):
+        """First half of the exchange: afterwards slice `rank` of numel / world elements holds the sum (numel % world == 0)."""
+        code = 0 if flat.dtype == torch.float32 else 1
+        self._check(self.lib().cvae_dp_reduce_scatter_sum(self._h, flat.data_ptr(), flat.numel(), code, torch.cuda.current_stream(flat.device).cuda_stream), "cvae_dp_reduce_scatter_sum")
+
+    def all_gather(self, flat):
+        """Second half: every rank's slice is copied to all ranks."""
+        code = 0 if flat.dtype == torch.float32 else 1
+        self._check(self.lib().cvae_dp_all_gather(self._h, flat.data_ptr(), flat.numel(), code, torch.cuda.current_stream(flat.device).cuda_stream), "cvae_dp_all_gather")
+
     def async_on_side_stream(self, flat):
         if self._side is None:
             self._side = torch.cuda.Stream(device=flat.device)

@@ -41,7 +41,8 @@ int cvae_dp_rank(const void* comm);
 /* flat[0..n) <- sum over ranks, in place, enqueued on `stream` (capturable in a HIP graph as far as RCCL's kernels are).  dtype CVAE_DP_F32 / _BF16. */
 int cvae_dp_allreduce_sum(void* comm, void* flat, size_t n, int dtype, void* stream);
 /* The two halves separately (overlap: reduce-scatter the first bucket under the rest of the backward, all-gather later): slice r of n / world elements
- * (n % world == 0 required) holds the sum after the first call; the second call fills every other slice. */
+ * (n % world == 0 required) holds the sum after the first call; the second call fills every other slice.  These two always go through RCCL, also on a
+ * one-rank communicator (where cvae_dp_allreduce_sum returns at once): the one-rank tests run ncclReduceScatter / ncclAllGather through them. */
 int cvae_dp_reduce_scatter_sum(void* comm, void* flat, size_t n, int dtype, void* stream);
 int cvae_dp_all_gather(void* comm, void* flat, size_t n, int dtype, void* stream);
 int cvae_dp_destroy(void* comm);

@@ -237,6 +237,13 @@ def mode_dp_abi1(rank, world, dev):
     COMM[0].all_reduce_sum(flat)
     COMM[0].async_on_side_stream(flat).wait()
     assert torch.equal(flat.cpu(), torch.arange(1000, dtype=torch.float32))
+    # the two halves called directly DO go through RCCL on one rank (ncclReduceScatter / ncclAllGather in place): symbols, datatypes, the stream argument
+    for dt in (torch.float32, torch.bfloat16):
+        buf = torch.arange(4096, device=dev).to(dt)
+        COMM[0].reduce_scatter_sum(buf)
+        COMM[0].all_gather(buf)
+        torch.cuda.synchronize()
+        assert torch.equal(buf.cpu(), torch.arange(4096).to(dt))
     try:
         mode_nccl1(rank, world, dev)
     finally:
