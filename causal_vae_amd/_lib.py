@@ -82,6 +82,11 @@ SIGNATURES = {
     "cvae_conv_down_variant": [_p, _p, _p, _p, _p] + [_i64] * 9 + [_i, _i, _i, _p, _sz, _i, _p],
     "cvae_linear_fwd_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _sz, _p],
     "cvae_linear_bwd_data_bf16": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
+    "cvae_small_dense_supported": [_i64, _i64, _i64],
+    "cvae_small_dense_workspace_bytes": [_i64, _i64, _i64],
+    "cvae_small_dense_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p],
+    "cvae_small_dense_bwd_data": [_p, _p, _p, _p, _i, _p, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "cvae_small_dense_bwd_weight": [_p, _p, _p, _p, _p, _i, _i64, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
     "cvae_linear_bwd_data_inact": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _i64, _i, _i, _p, _sz, _p],
     "cvae_linear_bwd_weight_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p],
     "cvae_bn1d_train_fwd": [_p] * 8 + [_i64, _i64, _f, _f, _p],
@@ -144,7 +149,8 @@ SIGNATURES = {
 }
 _RESTYPE = {"cvae_strerror": C.c_char_p, "cvae_conv_packed_weight_bytes": _sz, "cvae_conv_wgrad_workspace_bytes": _sz,
             "cvae_conv_data_workspace_bytes": _sz, "cvae_elbo_up2x_partials": _i64, "cvae_channel_sum_workspace_bytes": _sz,
-            "cvae_linear_workspace_bytes": _sz, "cvae_reduce_workspace_bytes": _sz, "cvae_bn2d_workspace_bytes": _sz}
+            "cvae_linear_workspace_bytes": _sz, "cvae_reduce_workspace_bytes": _sz, "cvae_bn2d_workspace_bytes": _sz,
+            "cvae_small_dense_workspace_bytes": _sz}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library disagree: fail at import

@@ -997,6 +997,9 @@ class UpsampleLinear(torch.autograd.Function):
 LINEAR_BF16_MIN_WORK = 1 << 24      # M * K * N below which a bf16-math Linear stays on the fp32 kernels (launch-bound there, and exact)
 
 
+SMALL_DENSE = __import__("os").environ.get("CVAE_SMALL_DENSE", "1") != "0"    # (env switch: A/B runs) small layers at large batch through csrc/small_dense.hip
+
+
 class Linear(torch.autograd.Function):
     """nn.Linear + optional fused activation.  fp32 tensors always; math = torch.float32: exact-fp32 MFMA (default);
     math = torch.bfloat16: operands rounded to bf16 inside the GEMM kernels (fp32 accumulate) for batches > 16 and M*K*N >= LINEAR_BF16_MIN_WORK."""
@@ -1014,6 +1017,16 @@ class Linear(torch.autograd.Function):
         N = weight.shape[0]
         b16 = math == torch.bfloat16 and M > 16 and M * K * N >= LINEAR_BF16_MIN_WORK
         y = _empty((M, N), torch.float32, x)
+        small = SMALL_DENSE and not b16 and bool(lib.cvae_small_dense_supported(M, K, N))     # small layer, large batch: the weight lives in LDS (csrc/small_dense.hip)
+        if small:
+            check(L.timed(f"linear_fwd M{M} K{K} N{N} small", lib.cvae_small_dense_fwd, ptr(x), ptr(weight.contiguous()), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), stream()),
+                  "small_dense_fwd")
+            ctx.save_for_backward(x, weight, y)
+            ctx.cfg = (act, bias is not None, b16)
+            ctx.chain = (in_act if in_act not in (None, "none") else None, bool(grad_premasked))
+            ctx.small = True
+            return y
+        ctx.small = False
         _t, wp, wb = _scratch(lib.cvae_linear_workspace_bytes(M, K, N, 0), x)
         if b16:
             check(L.timed(f"linear_fwd M{M} K{K} N{N} bf16", lib.cvae_linear_fwd_bf16, ptr(x), ptr(weight), ptr(bias), ptr(y), M, K, N, K, N, L.act_code(act), wp, wb, stream()),
@@ -1035,6 +1048,25 @@ class Linear(torch.autograd.Function):
         g = g.contiguous()
         M, K = x.shape
         N = weight.shape[0]
+        if ctx.small:
+            # this layer's activation gradient (unless the next layer already applied it) and the previous layer's (in_act) both ride in these launches
+            has_act = act not in (None, "none") and not premasked
+            ya, ac = (ptr(y), L.act_code(act)) if has_act else (None, L.ACT_NONE)
+            dx = dw = db = None
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(weight)
+                db = _empty((N,), torch.float32, g) if (has_bias and ctx.needs_input_grad[2]) else None
+                _t, wp, wb = _scratch(lib.cvae_small_dense_workspace_bytes(M, K, N), g)
+                check(L.timed(f"linear_bwd_weight M{M} K{K} N{N} small", lib.cvae_small_dense_bwd_weight, ptr(g), ptr(x), ptr(dw), ptr(db), ya, ac, M, K, N, N, K, N, wp, wb,
+                              stream()), "small_dense_bwd_weight")
+                if not ctx.needs_input_grad[1]:
+                    dw = None
+            if ctx.needs_input_grad[0]:
+                dx = _empty((M, K), torch.float32, g)
+                check(L.timed(f"linear_bwd_data M{M} K{K} N{N} small", lib.cvae_small_dense_bwd_data, ptr(g), ptr(weight.contiguous()), ptr(dx), ya, ac,
+                              ptr(x) if in_act is not None else None, L.act_code(in_act) if in_act is not None else L.ACT_NONE, M, K, N, N, K, N, K, stream()),
+                      "small_dense_bwd_data")
+            return dx, dw, db, None, None, None, None
         fused = act not in (None, "none") and M <= 16          # skinny kernels apply act'(y) on the fly
         if act not in (None, "none") and not fused and not premasked:
             g = _act_bwd(g, y, act)

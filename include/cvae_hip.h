@@ -447,6 +447,20 @@ int cvae_linear_fwd_bf16(const float* x, const float* W, const float* b, float* 
                          int act, void* workspace, size_t workspace_bytes, void* stream);
 int cvae_linear_bwd_data_bf16(const float* dy, const float* W, float* dx, int64_t M, int64_t K, int64_t N, int64_t dy_stride, int64_t dx_stride,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* ---- nn.Linear (+ activation) for SMALL layers at LARGE batch (csrc/small_dense.hip): M > 16 rows, K, N <= 512 and N * K <= 12288 weights — the MLP heads of
+ * mnist_test/01_baseline_causal_vae/models.py:24-37, 93-111 at batch 1024.  The weight lives in LDS; one launch forward, one for the data gradient, two for the
+ * weight + bias gradient (per-workgroup partials in `workspace`, summed in index order: no atomics).  fp32 throughout.
+ *   fwd         y = act(x W^T + b)
+ *   bwd_data    dx = ((dy * act'(y_act)) W) * in_act'(x_in)     y_act / x_in may be NULL (ACT_NONE): both activation gradients ride in this launch
+ *   bwd_weight  dW = (dy * act'(y_act))^T x,  db = column sums of (dy * act'(y_act))  (db may be NULL) */
+int cvae_small_dense_supported(int64_t M, int64_t K, int64_t N);
+size_t cvae_small_dense_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int cvae_small_dense_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int64_t K, int64_t N, int64_t x_stride, int64_t y_stride, int act, void* stream);
+int cvae_small_dense_bwd_data(const float* dy, const float* W, float* dx, const float* y_act, int act, const float* x_in, int in_act, int64_t M, int64_t K, int64_t N,
+                              int64_t dy_stride, int64_t dx_stride, int64_t y_stride, int64_t x_stride, void* stream);
+int cvae_small_dense_bwd_weight(const float* dy, const float* x, float* dW, float* db, const float* y_act, int act, int64_t M, int64_t K, int64_t N, int64_t dy_stride,
+                                int64_t x_stride, int64_t y_stride, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dx = (dy . W) * act'(x_in): cvae_linear_bwd_data(_bf16) with the derivative of the activation that produced this layer's INPUT x_in [M][K] (taken from its output,
  * i.e. from x_in: ReLU / LeakyReLU / Sigmoid) applied in the GEMM's epilogue (or its split-K slab sum) — in an MLP the previous layer then needs no activation-gradient
  * pass of its own (causal_cascade/models.py:24-31's Linear-ReLU-Linear chains; one launch fewer per layer at batch sizes above 16).  bf16_math as cvae_linear_*_bf16. */

@@ -698,14 +698,17 @@ def test_cat_many_pieces_one_launch_partial_gradients():
 
 # --------------------------------------------------------------------------------------------- linear / BN
 @pytest.mark.parametrize("M,K,N,act", [(4, 16415, 512, "relu"), (4, 76, 16384, None), (4, 256, 64, None), (128, 3158, 512, "relu"),
-                                       (1024, 22, 3136, "relu"), (7, 10, 64, "leaky02"), (2, 19, 64, None)])
+                                       (1024, 22, 3136, "relu"), (7, 10, 64, "leaky02"), (2, 19, 64, None),
+                                       # small layers at large batch (csrc/small_dense.hip): the MNIST heads, ragged row blocks, every activation
+                                       (1024, 10, 64, "relu"), (1024, 64, 10, None), (1000, 512, 20, None), (1024, 128, 12, "sigmoid"), (129, 96, 128, "leaky02"),
+                                       (17, 3, 5, "relu"), (1024, 22, 512, "relu")])
 def test_linear_forward_backward(M, K, N, act):
     g = torch.Generator().manual_seed(7)
     x = torch.randn(M, K, generator=g).requires_grad_(True)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).requires_grad_(True)
     b = torch.randn(N, generator=g).requires_grad_(True)
     y_ref = F.linear(x, w, b)
-    y_ref = {"relu": F.relu, "leaky02": lambda v: F.leaky_relu(v, 0.2), None: lambda v: v}[act](y_ref)
+    y_ref = {"relu": F.relu, "leaky02": lambda v: F.leaky_relu(v, 0.2), "sigmoid": torch.sigmoid, None: lambda v: v}[act](y_ref)
     gy = torch.randn(M, N, generator=g)
     gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, w, b], gy)
     xg, wg, bg = (v.detach().to(DEV).requires_grad_(True) for v in (x, w, b))
